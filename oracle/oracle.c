@@ -1,0 +1,484 @@
+/*
+ * oracle.c -- CPU restatement of the reference's detect-and-track hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (object_tracking_amd/)
+ * may import, link or call this file; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg do, and only as the checker / reported baseline.
+ *
+ * Each function cites the reference file:line it follows (paths relative to
+ * the upstream ktzsh/object-tracking tree).
+ *
+ * Parity status
+ *   - decode_netout / NMS / bbox_iou: PINNED.  Checked against golden vectors
+ *     produced by executing the reference's own numpy code
+ *     (utility/utils.py:113-188,208-270) -- see tools/make_goldens.py and
+ *     tests/golden/decode_*.npz.
+ *   - conv / BN / LeakyReLU / maxpool / space_to_depth / ConvLSTM2D / LSTM /
+ *     Dense: PARITY UNPINNED versus Keras/TensorFlow (un-vendored, unpinned
+ *     third-party dependency that cannot run in this image; the reference holds
+ *     no tests or fixtures for them).  They restate the public Keras 2.x / TF1
+ *     layer semantics named at the reference call sites and are cross-checked
+ *     against torch-CPU (an independent implementation) in tests/.
+ *
+ * All tensors are float32, NHWC, dense.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* utility/utils.py:150-153  normalize(): image / 255.  (numpy float64 divide,
+ * cast to float32 at the Keras input boundary, KerasYOLO.py:527-531). */
+ORC_API void orc_normalize_u8(const uint8_t *img, int64_t n, float *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = (float)((double)img[i] / 255.0);
+}
+
+/* Conv2D(strides=(1,1), padding='same'), kernel HWIO, optional bias.
+ * KerasYOLO.py:279 (and every conv_N ctor down to :399);
+ * MultiObjDetTracker.py:182 (tconv_2). */
+ORC_API void orc_conv2d(const float *in, int B, int H, int W, int Cin,
+                        const float *w, int KS, int Cout, const float *bias,
+                        float *out)
+{
+    const int pad = KS / 2;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < H; ++h) {
+            float *acc = (float *)malloc(sizeof(float) * (size_t)Cout);
+            for (int x = 0; x < W; ++x) {
+                for (int co = 0; co < Cout; ++co) acc[co] = bias ? bias[co] : 0.0f;
+                for (int ky = 0; ky < KS; ++ky) {
+                    const int ih = h + ky - pad;
+                    if (ih < 0 || ih >= H) continue;
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const int iw = x + kx - pad;
+                        if (iw < 0 || iw >= W) continue;
+                        const float *ip = in + (((size_t)b * H + ih) * W + iw) * Cin;
+                        const float *wp = w + ((size_t)(ky * KS + kx) * Cin) * Cout;
+                        for (int ci = 0; ci < Cin; ++ci) {
+                            const float v = ip[ci];
+                            const float *wr = wp + (size_t)ci * Cout;
+                            for (int co = 0; co < Cout; ++co) acc[co] = fmaf(v, wr[co], acc[co]);
+                        }
+                    }
+                }
+                memcpy(out + (((size_t)b * H + h) * W + x) * Cout, acc,
+                       sizeof(float) * (size_t)Cout);
+            }
+            free(acc);
+        }
+}
+
+/* BatchNormalization() in inference mode (moving statistics, Keras default
+ * epsilon = 1e-3 because no epsilon= is passed) followed by LeakyReLU(alpha).
+ * KerasYOLO.py:280-281.  Formulation: tf.nn.batch_normalization,
+ * inv = gamma * rsqrt(var + eps); y = x * inv + (beta - mean * inv). */
+ORC_API void orc_bn_leaky(float *x, int64_t npix, int C, const float *gamma,
+                          const float *beta, const float *mean,
+                          const float *var, float eps, float alpha)
+{
+    float *inv = (float *)malloc(sizeof(float) * (size_t)C);
+    float *sh = (float *)malloc(sizeof(float) * (size_t)C);
+    for (int c = 0; c < C; ++c) {
+        inv[c] = gamma[c] * (1.0f / sqrtf(var[c] + eps));
+        sh[c] = beta[c] - mean[c] * inv[c];
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < npix; ++p) {
+        float *r = x + p * C;
+        for (int c = 0; c < C; ++c) {
+            const float y = r[c] * inv[c] + sh[c];
+            r[c] = y > 0.0f ? y : alpha * y;
+        }
+    }
+    free(inv);
+    free(sh);
+}
+
+/* LeakyReLU alone (identity BN) -- helper for tests. */
+ORC_API void orc_leaky(float *x, int64_t n, float alpha)
+{
+    for (int64_t i = 0; i < n; ++i) x[i] = x[i] > 0.0f ? x[i] : alpha * x[i];
+}
+
+/* MaxPooling2D(pool_size=(2,2)) 'valid', stride 2.  KerasYOLO.py:282. */
+ORC_API void orc_maxpool2(const float *in, int B, int H, int W, int C, float *out)
+{
+    const int H2 = H / 2, W2 = W / 2;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < H2; ++h)
+            for (int x = 0; x < W2; ++x) {
+                const float *p00 = in + (((size_t)b * H + 2 * h) * W + 2 * x) * C;
+                const float *p01 = p00 + C;
+                const float *p10 = p00 + (size_t)W * C;
+                const float *p11 = p10 + C;
+                float *o = out + (((size_t)b * H2 + h) * W2 + x) * C;
+                for (int c = 0; c < C; ++c) {
+                    float m = p00[c];
+                    if (p01[c] > m) m = p01[c];
+                    if (p10[c] > m) m = p10[c];
+                    if (p11[c] > m) m = p11[c];
+                    o[c] = m;
+                }
+            }
+}
+
+/* tf.space_to_depth(x, block_size=2), NHWC:
+ * out[b,h,w,(dy*2+dx)*C + c] = in[b,2h+dy,2w+dx,c].  KerasYOLO.py:241-242. */
+ORC_API void orc_space_to_depth2(const float *in, int B, int H, int W, int C,
+                                 float *out)
+{
+    const int H2 = H / 2, W2 = W / 2;
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < H2; ++h)
+            for (int x = 0; x < W2; ++x)
+                for (int dy = 0; dy < 2; ++dy)
+                    for (int dx = 0; dx < 2; ++dx)
+                        memcpy(out + ((((size_t)b * H2 + h) * W2 + x) * 4 + (dy * 2 + dx)) * C,
+                               in + (((size_t)b * H + 2 * h + dy) * W + 2 * x + dx) * C,
+                               sizeof(float) * (size_t)C);
+}
+
+/* concatenate([a, b]) on the channel axis.  KerasYOLO.py:391 (skip first),
+ * MultiObjDetTracker.py:175 (x_bbox first). */
+ORC_API void orc_concat_c(const float *a, int Ca, const float *b, int Cb,
+                          int64_t npix, float *out)
+{
+    for (int64_t p = 0; p < npix; ++p) {
+        memcpy(out + p * (Ca + Cb), a + p * Ca, sizeof(float) * (size_t)Ca);
+        memcpy(out + p * (Ca + Cb) + Ca, b + p * Cb, sizeof(float) * (size_t)Cb);
+    }
+}
+
+static inline float hard_sigmoid(float x)
+{
+    /* Keras 2.x K.hard_sigmoid: clip(0.2*x + 0.5, 0, 1) */
+    float y = 0.2f * x + 0.5f;
+    return y < 0.0f ? 0.0f : (y > 1.0f ? 1.0f : y);
+}
+
+/* One time step of ConvLSTM2D(U,(3,3),padding='same'), Keras 2.x defaults:
+ * activation tanh, recurrent_activation hard_sigmoid, bias on the input conv
+ * only, gate order i,f,c,o on the last kernel axis.
+ * MultiObjDetTracker.py:176.
+ *   z = conv(x, Wk) + bias + conv(h, Uk);  i,f,o = hs(z_i,z_f,z_o)
+ *   c' = f*c + i*tanh(z_c);  h' = o*tanh(c')
+ * x [B,H,W,Cx]; h,c [B,H,W,U]; Wk [3,3,Cx,4U]; Uk [3,3,U,4U]; bias [4U]. */
+ORC_API void orc_convlstm_step(const float *x, int B, int H, int W, int Cx,
+                               const float *h, const float *c, int U,
+                               const float *Wk, const float *Uk,
+                               const float *bias, float *h_out, float *c_out)
+{
+    const size_t npix = (size_t)B * H * W;
+    float *zx = (float *)malloc(sizeof(float) * npix * 4 * U);
+    float *zh = (float *)malloc(sizeof(float) * npix * 4 * U);
+    orc_conv2d(x, B, H, W, Cx, Wk, 3, 4 * U, bias, zx);
+    orc_conv2d(h, B, H, W, U, Uk, 3, 4 * U, NULL, zh);
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < (int64_t)npix; ++p) {
+        const float *a = zx + p * 4 * U, *r = zh + p * 4 * U;
+        for (int j = 0; j < U; ++j) {
+            const float gi = hard_sigmoid(a[j] + r[j]);
+            const float gf = hard_sigmoid(a[U + j] + r[U + j]);
+            const float gc = tanhf(a[2 * U + j] + r[2 * U + j]);
+            const float go = hard_sigmoid(a[3 * U + j] + r[3 * U + j]);
+            const float cn = gf * c[p * U + j] + gi * gc;
+            c_out[p * U + j] = cn;
+            h_out[p * U + j] = go * tanhf(cn);
+        }
+    }
+    free(zx);
+    free(zh);
+}
+
+/* One time step of LSTM(U, implementation=2), Keras 2.x defaults (tanh /
+ * hard_sigmoid, gate order i,f,c,o): z = x.W + h.Ur + b in one fused matmul.
+ * models_tracking/TinyTracker.py:36.
+ * x [B,D]; h,c [B,U]; Wk [D,4U]; Ur [U,4U]; bias [4U]. */
+ORC_API void orc_lstm_step(const float *x, int B, int D, const float *h,
+                           const float *c, int U, const float *Wk,
+                           const float *Ur, const float *bias, float *h_out,
+                           float *c_out)
+{
+    float *z = (float *)malloc(sizeof(float) * (size_t)4 * U);
+    for (int b = 0; b < B; ++b) {
+        for (int n = 0; n < 4 * U; ++n) z[n] = bias[n];
+        for (int d = 0; d < D; ++d) {
+            const float v = x[(size_t)b * D + d];
+            const float *wr = Wk + (size_t)d * 4 * U;
+            for (int n = 0; n < 4 * U; ++n) z[n] += v * wr[n];
+        }
+        for (int d = 0; d < U; ++d) {
+            const float v = h[(size_t)b * U + d];
+            const float *wr = Ur + (size_t)d * 4 * U;
+            for (int n = 0; n < 4 * U; ++n) z[n] += v * wr[n];
+        }
+        for (int j = 0; j < U; ++j) {
+            const float gi = hard_sigmoid(z[j]);
+            const float gf = hard_sigmoid(z[U + j]);
+            const float gc = tanhf(z[2 * U + j]);
+            const float go = hard_sigmoid(z[3 * U + j]);
+            const float cn = gf * c[(size_t)b * U + j] + gi * gc;
+            c_out[(size_t)b * U + j] = cn;
+            h_out[(size_t)b * U + j] = go * tanhf(cn);
+        }
+    }
+    free(z);
+}
+
+/* Dense(O, activation='sigmoid').  TinyTracker.py:37. */
+ORC_API void orc_dense_sigmoid(const float *x, int B, int U, const float *Wd,
+                               const float *bd, int O, float *out)
+{
+    for (int b = 0; b < B; ++b)
+        for (int o = 0; o < O; ++o) {
+            float s = bd[o];
+            for (int j = 0; j < U; ++j) s += x[(size_t)b * U + j] * Wd[(size_t)j * O + o];
+            out[(size_t)b * O + o] = 1.0f / (1.0f + expf(-s));
+        }
+}
+
+/* GlobalMaxPooling2D over (w,h).  TinyTracker.py:33 (pool == 'Global'). */
+ORC_API void orc_global_maxpool(const float *in, int B, int HW, int C, float *out)
+{
+    for (int b = 0; b < B; ++b) {
+        float *o = out + (size_t)b * C;
+        const float *p = in + (size_t)b * HW * C;
+        for (int c = 0; c < C; ++c) o[c] = p[c];
+        for (int i = 1; i < HW; ++i)
+            for (int c = 0; c < C; ++c)
+                if (p[(size_t)i * C + c] > o[c]) o[c] = p[(size_t)i * C + c];
+    }
+}
+
+/* MaxPooling2D((4,4), strides=(4,4)) + Flatten.  TinyTracker.py:29-31
+ * (pool == 'Max').  Output order is Keras Flatten of (H/4, W/4, C). */
+ORC_API void orc_maxpool4_flatten(const float *in, int B, int H, int W, int C,
+                                  float *out)
+{
+    const int H4 = H / 4, W4 = W / 4;
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < H4; ++h)
+            for (int x = 0; x < W4; ++x)
+                for (int c = 0; c < C; ++c) {
+                    float m = -INFINITY;
+                    for (int dy = 0; dy < 4; ++dy)
+                        for (int dx = 0; dx < 4; ++dx) {
+                            const float v = in[(((size_t)b * H + 4 * h + dy) * W + 4 * x + dx) * C + c];
+                            if (v > m) m = v;
+                        }
+                    out[(((size_t)b * H4 + h) * W4 + x) * C + c] = m;
+                }
+}
+
+/* ---------------------------------------------------------------------------
+ * decode_netout + NMS.  utility/utils.py:208-257 with sigmoid :259,
+ * softmax :262-270, BoundBox :113-136, bbox_iou :155-173,
+ * interval_overlap :175-188.  float32 arithmetic throughout (numpy >= 2
+ * scalar promotion keeps np.float32 op python-scalar in float32).
+ * ------------------------------------------------------------------------- */
+
+/* utils.py:175-188 */
+static float interval_overlap(float x1, float x2, float x3, float x4)
+{
+    if (x3 < x1) {
+        if (x4 < x1) return 0.0f;
+        return (x2 < x4 ? x2 : x4) - x1;
+    } else {
+        if (x2 < x3) return 0.0f;
+        return (x2 < x4 ? x2 : x4) - x3;
+    }
+}
+
+/* utils.py:155-173.  Boxes are (x,y,w,h) centre format. */
+ORC_API float orc_bbox_iou(const float *b1, const float *b2)
+{
+    const float x1_min = b1[0] - b1[2] / 2, x1_max = b1[0] + b1[2] / 2;
+    const float y1_min = b1[1] - b1[3] / 2, y1_max = b1[1] + b1[3] / 2;
+    const float x2_min = b2[0] - b2[2] / 2, x2_max = b2[0] + b2[2] / 2;
+    const float y2_min = b2[1] - b2[3] / 2, y2_max = b2[1] + b2[3] / 2;
+    const float iw = interval_overlap(x1_min, x1_max, x2_min, x2_max);
+    const float ih = interval_overlap(y1_min, y1_max, y2_min, y2_max);
+    const float inter = iw * ih;
+    const float a1 = b1[2] * b1[3];
+    const float a2 = b2[2] * b2[3];
+    const float uni = (a1 + a2) - inter;
+    return inter / uni;
+}
+
+static float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); } /* utils.py:259 */
+
+typedef struct {
+    float score;
+    int idx;
+} sc_t;
+
+/* descending score; ties -> higher candidate index first (the reference's
+ * reversed(np.argsort) leaves tie order undefined, utils.py:240; this is the
+ * build's documented choice). */
+static int sc_cmp(const void *a, const void *b)
+{
+    const sc_t *p = (const sc_t *)a, *q = (const sc_t *)b;
+    if (p->score > q->score) return -1;
+    if (p->score < q->score) return 1;
+    return q->idx - p->idx;
+}
+
+/* netout [GH,GW,NB,5+NC] is transformed IN PLACE exactly like the reference
+ * (utils.py:214-216 and the NMS zeroing :252 through the `classes` views).
+ * Output rows, in creation (row,col,b) order, for boxes surviving the final
+ * filter (utils.py:255): out_box[i*8 + {0..7}] = x,y,w,h,conf,label,score,cell
+ * where cell = (row*GW+col)*NB+b.  Returns the number of surviving boxes (may
+ * exceed cap; only the first cap are written). */
+ORC_API int orc_decode_netout(float *netout, int GH, int GW, int NB, int NC,
+                              float obj_thr, float nms_thr,
+                              const float *anchors, float *out_box, int cap)
+{
+    const int S = 5 + NC;
+    const int ncell = GH * GW * NB;
+    /* softmax(): GLOBAL max / min over the whole class block (utils.py:263-266) */
+    float gmax = -INFINITY;
+    for (int i = 0; i < ncell; ++i)
+        for (int c = 0; c < NC; ++c)
+            if (netout[i * S + 5 + c] > gmax) gmax = netout[i * S + 5 + c];
+    float gmin = INFINITY;
+    for (int i = 0; i < ncell; ++i)
+        for (int c = 0; c < NC; ++c) {
+            const float v = netout[i * S + 5 + c] - gmax;
+            if (v < gmin) gmin = v;
+        }
+    const int rescale = gmin < -100.0f;
+    for (int i = 0; i < ncell; ++i) {
+        float *r = netout + (size_t)i * S;
+        r[4] = sigmoidf_(r[4]); /* :214 */
+        float sum = 0.0f;
+        for (int c = 0; c < NC; ++c) {
+            float v = r[5 + c] - gmax;
+            if (rescale) v = v / gmin * -100.0f;
+            v = expf(v);
+            r[5 + c] = v;
+            sum += v;
+        }
+        for (int c = 0; c < NC; ++c) {
+            float p = r[4] * (r[5 + c] / sum); /* :215 */
+            r[5 + c] = p > obj_thr ? p : 0.0f;   /* :216 */
+        }
+    }
+    /* candidate boxes (:218-236) */
+    int *cand = (int *)malloc(sizeof(int) * (size_t)ncell);
+    float *bx = (float *)malloc(sizeof(float) * 4 * (size_t)ncell);
+    int n = 0;
+    for (int row = 0; row < GH; ++row)
+        for (int col = 0; col < GW; ++col)
+            for (int b = 0; b < NB; ++b) {
+                const int i = (row * GW + col) * NB + b;
+                const float *r = netout + (size_t)i * S;
+                int any = 0;
+                for (int c = 0; c < NC; ++c)
+                    if (r[5 + c] != 0.0f) { any = 1; break; }
+                if (!any) continue;
+                bx[n * 4 + 0] = ((float)col + sigmoidf_(r[0])) / (float)GW;
+                bx[n * 4 + 1] = ((float)row + sigmoidf_(r[1])) / (float)GH;
+                bx[n * 4 + 2] = anchors[2 * b + 0] * expf(r[2]) / (float)GW;
+                bx[n * 4 + 3] = anchors[2 * b + 1] * expf(r[3]) / (float)GH;
+                cand[n++] = i;
+            }
+    /* per-class greedy NMS (:239-252) */
+    sc_t *ord = (sc_t *)malloc(sizeof(sc_t) * (size_t)(n > 0 ? n : 1));
+    for (int c = 0; c < NC; ++c) {
+        for (int k = 0; k < n; ++k) {
+            ord[k].score = netout[(size_t)cand[k] * S + 5 + c];
+            ord[k].idx = k;
+        }
+        qsort(ord, (size_t)n, sizeof(sc_t), sc_cmp);
+        for (int i = 0; i < n; ++i) {
+            const int ii = ord[i].idx;
+            if (netout[(size_t)cand[ii] * S + 5 + c] == 0.0f) continue;
+            for (int j = i + 1; j < n; ++j) {
+                const int jj = ord[j].idx;
+                if (orc_bbox_iou(bx + ii * 4, bx + jj * 4) >= nms_thr)
+                    netout[(size_t)cand[jj] * S + 5 + c] = 0.0f;
+            }
+        }
+    }
+    /* final filter (:255): post-NMS argmax label, score > obj_thr */
+    int m = 0;
+    for (int k = 0; k < n; ++k) {
+        const float *r = netout + (size_t)cand[k] * S;
+        int lab = 0;
+        for (int c = 1; c < NC; ++c)
+            if (r[5 + c] > r[5 + lab]) lab = c;
+        const float sc = r[5 + lab];
+        if (sc > obj_thr) {
+            if (m < cap) {
+                float *o = out_box + (size_t)m * 8;
+                o[0] = bx[k * 4 + 0];
+                o[1] = bx[k * 4 + 1];
+                o[2] = bx[k * 4 + 2];
+                o[3] = bx[k * 4 + 3];
+                o[4] = r[4];
+                o[5] = (float)lab;
+                o[6] = sc;
+                o[7] = (float)cand[k];
+            }
+            ++m;
+        }
+    }
+    free(ord);
+    free(bx);
+    free(cand);
+    return m;
+}
+
+/* ---------------------------------------------------------------------------
+ * Track-ID assignment.  BUILD-DEFINED: the reference has no association step
+ * and never reads `trackid`; MultiObjDetTracker.predict
+ * (MultiObjDetTracker.py:295-315) only decodes each frame.  Specification
+ * (DESIGN.md "Track identity"): frames of one clip are visited in order; the
+ * boxes of frame t are visited in decode order; box i takes the id of the
+ * not-yet-claimed frame-(t-1) box j of the SAME label with the largest
+ * bbox_iou(i,j) provided that IoU >= assoc_thr (ties -> lowest j); otherwise
+ * it opens a new id (ids count up from 0 per clip).
+ *   boxes  [T, cap, 8]  rows as written by orc_decode_netout
+ *   counts [T]
+ *   ids    [T, cap]     output; -1 in unused slots
+ * Returns the number of ids opened. */
+ORC_API int orc_associate_clip(const float *boxes, const int *counts, int T,
+                               int cap, float assoc_thr, int *ids)
+{
+    int next_id = 0;
+    char *claimed = (char *)malloc((size_t)(cap > 0 ? cap : 1));
+    for (int t = 0; t < T; ++t) {
+        const int n = counts[t] < cap ? counts[t] : cap;
+        for (int i = 0; i < cap; ++i) ids[t * cap + i] = -1;
+        const int np_ = t > 0 ? (counts[t - 1] < cap ? counts[t - 1] : cap) : 0;
+        memset(claimed, 0, (size_t)(cap > 0 ? cap : 1));
+        for (int i = 0; i < n; ++i) {
+            const float *bi = boxes + ((size_t)t * cap + i) * 8;
+            int best = -1;
+            float best_iou = -1.0f;
+            for (int j = 0; j < np_; ++j) {
+                if (claimed[j]) continue;
+                const float *bj = boxes + ((size_t)(t - 1) * cap + j) * 8;
+                if (bj[5] != bi[5]) continue;
+                const float iou = orc_bbox_iou(bi, bj);
+                if (iou >= assoc_thr && iou > best_iou) {
+                    best_iou = iou;
+                    best = j;
+                }
+            }
+            if (best >= 0) {
+                claimed[best] = 1;
+                ids[t * cap + i] = ids[(t - 1) * cap + best];
+            } else {
+                ids[t * cap + i] = next_id++;
+            }
+        }
+    }
+    free(claimed);
+    return next_id;
+}

@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for decode_netout / NMS / bbox_iou by EXECUTING the
+reference's own numpy code.
+
+Runs only in the build container (needs /root/reference).  The reference module
+utility/utils.py is Python 2 (print statement at line 10) and imports cv2, so it
+cannot be imported; its hot-path block -- BoundBox, WeightReader, normalize,
+bbox_iou, interval_overlap (lines 113-188) and decode_netout, sigmoid, softmax
+(lines 208-270) -- is py3-clean and numpy-only.  This script reads those line
+ranges at run time and exec()s them with `np` in scope; no reference source is
+copied into this repository, only the resulting data (inputs + expected outputs)
+is written to tests/golden/*.npz.
+
+    python tools/make_goldens.py            # rewrites tests/golden/
+"""
+import os
+import sys
+
+import numpy as np
+
+REF = os.environ.get("REFERENCE_ROOT", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+ANCHORS = [0.57273, 0.677385, 1.87446, 2.06253, 3.33843, 5.47434, 7.88282, 3.52778, 9.77052, 9.16828]
+
+
+def load_reference_slice():
+    path = os.path.join(REF, "utility", "utils.py")
+    with open(path) as f:
+        lines = f.read().split("\n")
+    src = "\n".join(lines[112:188] + lines[207:270])
+    ns = {"np": np}
+    exec(compile(src, path + "[113-188,208-270]", "exec"), ns)
+    return ns
+
+
+def planted_grid(seed, G, C, n_obj, dup_every=3):
+    """SURVEY.md section 8c recipe: background logits with objectness pushed
+    down, n_obj planted objects, every dup_every-th duplicated into the next
+    cell (same class, shifted tx) to force NMS suppressions."""
+    rs = np.random.RandomState(seed)
+    g = rs.randn(G, G, 5, 5 + C).astype(np.float32)
+    g[..., 4] -= 4.0
+    cells = rs.permutation(G * (G - 1))[:n_obj]
+    for k, cell in enumerate(cells):
+        row, col = divmod(int(cell), G - 1)
+        b = int(rs.randint(0, 5))
+        cls = int(rs.randint(0, C))
+        g[row, col, b, 4] = 4.0 + rs.rand()
+        g[row, col, b, 5 + cls] += 12.0 + rs.rand()
+        if dup_every and k % dup_every == 0:
+            g[row, col + 1, b, :] = g[row, col, b, :]
+            g[row, col + 1, b, 0] -= 3.0
+            g[row, col + 1, b, 4] -= 0.25 + 0.5 * rs.rand()  # distinct score, no ties
+    return g
+
+
+def run_case(ns, netout, obj_thr, nms_thr, nb_class):
+    work = netout.copy()
+    boxes = ns["decode_netout"](work, obj_thr, nms_thr, ANCHORS, nb_class)
+    rows = np.zeros((len(boxes), 7), dtype=np.float64)
+    cls = np.zeros((len(boxes), nb_class), dtype=np.float32)
+    for i, b in enumerate(boxes):
+        rows[i] = [b.x, b.y, b.w, b.h, b.c, b.get_label(), b.get_score()]
+        cls[i] = b.classes
+    return rows, cls, work
+
+
+def main():
+    ns = load_reference_slice()
+    os.makedirs(OUT, exist_ok=True)
+    cases = {}
+
+    # --- big planted cases ---
+    cases["g13_c80_n24"] = (planted_grid(101, 13, 80, 24), 0.5, 0.45, 80)
+    cases["g13_c12_n32"] = (planted_grid(102, 13, 12, 32), 0.5, 0.45, 12)
+    cases["g19_c12_n128"] = (planted_grid(103, 19, 12, 128), 0.5, 0.45, 12)
+
+    # --- edge cases on small grids ---
+    rs = np.random.RandomState(7)
+    bg = rs.randn(3, 3, 5, 5 + 12).astype(np.float32)
+    bg[..., 4] -= 6.0
+    cases["g3_background"] = (bg, 0.5, 0.45, 12)
+
+    # softmax rescale branch: one logit far below the global max (utils.py:265-266)
+    g = planted_grid(11, 5, 12, 6)
+    g[0, 0, 0, 5 + 3] = -250.0
+    cases["g5_rescale"] = (g, 0.5, 0.45, 12)
+
+    # two classes above a LOW threshold in one box; the stronger one is
+    # suppressed by a neighbour so the post-NMS argmax relabels (utils.py:255)
+    g = np.full((3, 3, 5, 5 + 4), -8.0, dtype=np.float32)
+    g[..., :4] = 0.0
+    g[1, 1, 2, 4] = 6.0                           # box A: anchor 2, scores ~0.60 / ~0.40
+    g[1, 1, 2, 5:9] = [2.0, 1.6, -6.0, -6.0]
+    g[1, 1, 3, 4] = 8.0                           # box B: same centre, anchor 3, class 0 ~1.0
+    g[1, 1, 3, 5:9] = [6.0, -6.0, -6.0, -6.0]     # IoU(A,B) ~ 0.34 >= 0.3 -> A.class0 zeroed
+    cases["g3_relabel"] = (g, 0.3, 0.3, 4)
+
+    # low thresholds, many survivors & suppressions, non-square class count
+    cases["g7_c5_lowthr"] = (planted_grid(21, 7, 5, 30, dup_every=2), 0.3, 0.3, 5)
+    # high nms threshold (nothing suppressed) / tiny nms threshold (aggressive)
+    cases["g7_c12_nms09"] = (planted_grid(22, 7, 12, 20, dup_every=2), 0.5, 0.9, 12)
+    cases["g7_c12_nms01"] = (planted_grid(23, 7, 12, 20, dup_every=2), 0.5, 0.1, 12)
+    # single class
+    cases["g5_c1"] = (planted_grid(24, 5, 1, 8), 0.5, 0.45, 1)
+    # dense: every cell hot (maximum candidate count for the grid)
+    g = np.random.RandomState(25).randn(4, 4, 5, 5 + 3).astype(np.float32)
+    g[..., 4] = 5.0 + np.random.RandomState(26).rand(4, 4, 5).astype(np.float32)
+    g[..., 5] += 9.0 + np.random.RandomState(27).rand(4, 4, 5).astype(np.float32)
+    cases["g4_dense"] = (g, 0.5, 0.45, 3)
+
+    summary = []
+    for name, (netout, obj_thr, nms_thr, C) in cases.items():
+        rows, cls, post = run_case(ns, netout, obj_thr, nms_thr, C)
+        # reject exact score ties between surviving boxes of one class (tie order
+        # is undefined in the reference, utils.py:240)
+        for c in range(C):
+            s = post[..., 5 + c].ravel()
+            s = s[s != 0]
+            assert len(np.unique(s)) == len(s), (name, "score tie in class", c)
+        small = netout.size <= 5 * 5 * 5 * 17
+        np.savez_compressed(
+            os.path.join(OUT, "decode_%s.npz" % name),
+            netout=netout, obj_threshold=np.float32(obj_thr), nms_threshold=np.float32(nms_thr),
+            anchors=np.asarray(ANCHORS, dtype=np.float32), nb_class=np.int32(C),
+            boxes=rows, classes=cls,
+            **({"netout_post": post} if small else {}))
+        summary.append((name, netout.shape, len(rows)))
+
+    # --- bbox_iou known answers (utils.py:155-188) ---
+    rs = np.random.RandomState(5)
+    BB = ns["BoundBox"]
+    pairs = rs.rand(256, 8).astype(np.float32)
+    pairs[:, 2:4] = pairs[:, 2:4] * 0.5 + 0.01
+    pairs[:, 6:8] = pairs[:, 6:8] * 0.5 + 0.01
+    pairs[:32, 4:6] = pairs[:32, 0:2]            # concentric
+    pairs[32:40, 4:] = pairs[32:40, :4]          # identical -> 1.0
+    pairs[40:48, 4] = pairs[40:48, 0] + 5.0      # disjoint -> 0.0
+    iou = np.zeros(256, dtype=np.float64)
+    for i, p in enumerate(pairs):
+        iou[i] = ns["bbox_iou"](BB(*p[:4]), BB(*p[4:]))
+    np.savez_compressed(os.path.join(OUT, "bbox_iou.npz"), pairs=pairs, iou=iou)
+
+    # --- WeightReader known answer (utils.py:138-148): offset starts at 4 ---
+    blob = np.arange(64, dtype=np.float32)
+    p = os.path.join(OUT, "_tmp.weights")
+    blob.tofile(p)
+    wr = ns["WeightReader"](p)
+    a = wr.read_bytes(5).copy()
+    b = wr.read_bytes(3).copy()
+    os.remove(p)
+    np.savez_compressed(os.path.join(OUT, "weight_reader.npz"), blob=blob, first5=a, next3=b)
+
+    # --- normalize known answer (utils.py:150-153) ---
+    img = np.arange(256, dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "normalize.npz"), img=img, out=ns["normalize"](img))
+
+    for s in summary:
+        print("%-18s grid %-18s -> %d boxes" % (s[0], s[1], s[2]))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
