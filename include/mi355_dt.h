@@ -1,0 +1,168 @@
+/*
+ * mi355_dt.h -- C ABI of libmi355_dt.so: the MI355X (gfx950) detect-and-track
+ * hot path of ktzsh/object-tracking.
+ *
+ * The reference has no FFI on this path: its hot path is Keras calls made from
+ * two Python classes.  The in-tree precedent for
+ * "Python host <-> C-ABI .so" is models_detection/YOLO.py:6-37,58-119 (ctypes
+ * over libdarknet.so).  Each entry point below names the reference call it
+ * replaces.  Conventions:
+ *   - every function returns 0 on success, non-zero on error; the message is
+ *     available from dt_last_error(ctx);
+ *   - pointers named d_* are DEVICE pointers (e.g. torch tensor.data_ptr());
+ *     pointers named h_* are HOST pointers; the caller owns all of them;
+ *   - all tensors are dense float32 NHWC unless stated; frames may be uint8;
+ *   - every launch goes to the stream set with dt_set_stream (default: the
+ *     null stream); calls are asynchronous with respect to the host unless
+ *     stated; one dt_ctx per GPU per process, not re-entrant across threads;
+ *   - there is NO CPU fallback: without a gfx950 device every compute entry
+ *     point fails with DT_ERR_DEVICE.
+ */
+#ifndef MI355_DT_H
+#define MI355_DT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* exported from a library built with -fvisibility=hidden */
+#define DT_API __attribute__((visibility("default")))
+
+#define DT_OK 0
+#define DT_ERR_ARG 1      /* bad argument / shape */
+#define DT_ERR_DEVICE 2   /* HIP error (no device, launch failure, OOM) */
+#define DT_ERR_STATE 3    /* weights not loaded / wrong call order */
+
+#define DT_FRAMES_U8 0    /* uint8 HWC frames; x/255. fused into conv_1 (utils.py:150-153) */
+#define DT_FRAMES_F32 1   /* float32 frames, already normalised */
+
+#define DT_BOX_FLOATS 8   /* x, y, w, h, conf, label, score, cell */
+
+typedef struct dt_ctx dt_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+DT_API int dt_create(dt_ctx **out);
+DT_API void dt_destroy(dt_ctx *ctx);
+DT_API const char *dt_last_error(dt_ctx *ctx);
+DT_API int dt_set_stream(dt_ctx *ctx, void *hip_stream);
+/* ABI version of this header: major*100+minor */
+DT_API int dt_abi_version(void);
+
+/* ---- detector: KerasYOLO ---------------------------------------------- */
+/* Replaces KerasYOLO.load_model graph construction (KerasYOLO.py:277-405) for
+ * image_h x image_w inputs (multiples of 32), nb_box anchors per cell and
+ * nb_class classes; anchors[2*nb_box] as KerasYOLO.ANCHORS (KerasYOLO.py:45). */
+DT_API int dt_detector_config(dt_ctx *ctx, int image_h, int image_w, int nb_box,
+                       int nb_class, const float *h_anchors);
+
+/* Replaces init_weights + WeightReader (KerasYOLO.py:244-274,
+ * utility/utils.py:138-148).  h_blob = float32 contents of a darknet .weights
+ * file INCLUDING its 4-float header (the reader's offset starts at 4).  Folds
+ * inference BatchNorm (eps 1e-3) into each kernel and uploads.  *consumed
+ * receives the reader offset after conv_23 (may be NULL). */
+DT_API int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t n_floats,
+                            size_t *consumed);
+
+/* Replaces model.predict([input_image, dummy])  (KerasYOLO.py:531) and the
+ * two-output detector Model of MultiObjDetTracker.py:162-164.
+ *   d_frames  [batch, H, W, 3] uint8 or float32 (frames_dtype)
+ *   d_netout  [batch, G, G, nb_box*(5+C)]  raw conv_23 output     (may be NULL)
+ *   d_feat    [batch, G, G, 1024]          'conv_feat' activation (may be NULL) */
+DT_API int dt_detect_forward(dt_ctx *ctx, const void *d_frames, int frames_dtype,
+                      int batch, float *d_netout, float *d_feat);
+
+/* Replaces KerasYOLO.extract's intermediate_layer_model for the named taps the
+ * reference reaches for: "conv_23", "conv_feat", "act_13" (26x26x512 skip
+ * tensor, the TinyTracker feature layer, config.json:9).  Valid after a
+ * dt_detect_forward of the same batch; copies into d_out. */
+DT_API int dt_detector_tap(dt_ctx *ctx, const char *name, int batch, float *d_out);
+
+/* ---- decode_netout + NMS (utility/utils.py:208-257) -------------------- */
+/*   d_netout  [batch, GH, GW, NB, 5+NC]  raw logits (NOT modified)
+ *   d_boxes   [batch, cap, DT_BOX_FLOATS] surviving boxes in (row,col,b) order
+ *   d_counts  [batch] int32: number of survivors (may exceed cap; extra dropped)
+ *   d_classes [batch, cap, NC] post-NMS class scores per box (may be NULL)
+ *   d_post    [batch, GH, GW, NB, 5+NC] the reference's in-place-mutated netout
+ *             (conf / thresholded class scores after NMS) (may be NULL)        */
+DT_API int dt_decode(dt_ctx *ctx, const float *d_netout, int batch, int GH, int GW,
+              int NB, int NC, float obj_threshold, float nms_threshold,
+              const float *h_anchors, int cap, float *d_boxes, int *d_counts,
+              float *d_classes, float *d_post);
+
+/* bbox_iou (utility/utils.py:155-173) on n pairs: d_pairs [n,8] -> d_iou [n] */
+DT_API int dt_bbox_iou(dt_ctx *ctx, const float *d_pairs, int n, float *d_iou);
+
+/* ---- tracker: MultiObjDetTracker --------------------------------------- */
+/* Replaces MultiObjDetTracker.load_model's recurrent head
+ * (MultiObjDetTracker.py:175-183) + load_weights (:291-293).  Keras layouts:
+ *   h_kernel     [3,3,Cb+1024,4U]  ConvLSTM2D input kernel, x_bbox channels first
+ *   h_recurrent  [3,3,U,4U]        recurrent kernel
+ *   h_bias       [4U]              gate order i,f,c,o
+ *   h_out_kernel [1,1,U,Cb]        'tconv_2' 1x1 conv,  h_out_bias [Cb]
+ * with Cb = nb_box*(5+C), U = units (512). */
+DT_API int dt_tracker_load(dt_ctx *ctx, int units, const float *h_kernel,
+                    const float *h_recurrent, const float *h_bias,
+                    const float *h_out_kernel, const float *h_out_bias);
+
+/* Replaces model.predict([x, b]) of the tracker model (MultiObjDetTracker.py:307).
+ *   d_frames [n_clips, T, H, W, 3]
+ *   d_trk    [n_clips, T, G, G, Cb]  'tracking' output grid   (may be NULL)
+ *   d_det    [n_clips, T, G, G, Cb]  'detection' output grid  (may be NULL)
+ * ConvLSTM state is zero at t=0 of every call (stateless Keras RNN). */
+DT_API int dt_track_forward(dt_ctx *ctx, const void *d_frames, int frames_dtype,
+                     int n_clips, int T, float *d_trk, float *d_det);
+
+/* Track identity (BUILD-DEFINED, DESIGN.md "Track identity"; the reference has
+ * none).  d_boxes [n_clips,T,cap,8], d_counts [n_clips,T]
+ * -> d_ids [n_clips,T,cap] int32 (-1 unused), d_nids [n_clips] ids opened. */
+DT_API int dt_associate(dt_ctx *ctx, const float *d_boxes, const int *d_counts,
+                 int n_clips, int T, int cap, float assoc_threshold,
+                 int *d_ids, int *d_nids);
+
+/* ---- TinyTracker (models_tracking/TinyTracker.py:25-41) ---------------- */
+/*   h_kernel [D,4U], h_recurrent [U,4U], h_bias [4U], h_dense_kernel [U,4],
+ *   h_dense_bias [4]; D = feature width + 4.  pool: 0 = 'Global', 1 = 'Max'. */
+DT_API int dt_tiny_load(dt_ctx *ctx, int D, int units, const float *h_kernel,
+                 const float *h_recurrent, const float *h_bias,
+                 const float *h_dense_kernel, const float *h_dense_bias);
+
+/* Replaces model_tracker.predict([img_fv, det]).
+ *   d_feat [n_seq, T, fh, fw, fc], d_det [n_seq, T, 4] -> d_out [n_seq, T, 4] */
+DT_API int dt_tiny_forward(dt_ctx *ctx, const float *d_feat, const float *d_det,
+                    int n_seq, int T, int fh, int fw, int fc, int pool,
+                    float *d_out);
+
+/* ---- layer-level entry points (used by the parity tests) --------------- */
+/* Conv2D 'same' stride 1 (+ optional folded bias, LeakyReLU slope, fused 2x2
+ * maxpool) through the MFMA implicit-GEMM kernel.  h_kernel is Keras HWIO
+ * [k,k,Cin,Cout]; Cin must be a multiple of 32 (use dt_conv1 for RGB input).
+ *   pool: 0 none, 1 pooled output only, 2 both (d_out unpooled, d_out2 pooled) */
+DT_API int dt_conv2d(dt_ctx *ctx, const float *d_in, int B, int H, int W, int Cin,
+              const float *h_kernel, int k, int Cout, const float *h_bias,
+              float leaky_slope, int pool, float *d_out, float *d_out2);
+
+/* One ConvLSTM2D step (MultiObjDetTracker.py:176): d_x [B,H,W,Cx] with Cx a
+ * multiple of 32, d_h/d_c [B,H,W,U] -> d_h_out/d_c_out. */
+DT_API int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int W, int Cx,
+                     const float *d_h, const float *d_c, int U,
+                     const float *h_kernel, const float *h_recurrent,
+                     const float *h_bias, float *d_h_out, float *d_c_out);
+
+/* ---- profiling --------------------------------------------------------- */
+/* When enabled every kernel launch is bracketed by HIP events on the ctx
+ * stream.  dt_profile_read synchronises the stream and returns, per kernel
+ * family, launches / total ms / algorithmic flops / algorithmic bytes since the
+ * last reset.  names: "conv_igemm", "conv1_direct", "convlstm_gates",
+ * "decode_nms", "associate", "lstm_step", "pool", "misc". */
+DT_API int dt_profile_enable(dt_ctx *ctx, int on);
+DT_API int dt_profile_reset(dt_ctx *ctx);
+DT_API int dt_profile_read(dt_ctx *ctx, const char *name, int64_t *launches,
+                    double *total_ms, double *flops, double *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_DT_H */

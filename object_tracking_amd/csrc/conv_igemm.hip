@@ -1,0 +1,338 @@
+// conv_igemm.hip -- fp32 implicit-GEMM convolution on the CDNA4 matrix cores.
+//
+// Computes the reference's  Conv2D(k,'same',stride 1) [+ folded BatchNorm bias
+// + LeakyReLU(0.1)] [+ MaxPooling2D(2,2)] block (models_detection/KerasYOLO.py:
+// 279-396) and the ConvLSTM2D recurrent convolution + gate update
+// (models_tracking/MultiObjDetTracker.py:176) as ONE kernel family:
+//
+//     Out[M = B*H*W, N = Cout] = A[M, K = k*k*Cin] * Wt[N, K]^T
+//
+// A is never materialised: a row m is an output pixel, column k = tap*Cin + ci
+// is read straight from the NHWC activation tensor (zero outside the image).
+//
+// MI355X design notes
+//   * v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak): 64-lane wavefront
+//     tiles of 32x32; each wave owns TM x TN such tiles, 4 waves per workgroup.
+//   * K is consumed in chunks of 32 floats of ONE tap, so a chunk of A is 32
+//     contiguous floats per pixel (128 B -> coalesced float4 loads, 8 lanes/row).
+//   * LDS tiles are [rows][32+4] floats: k contiguous so one ds_read_b128 feeds
+//     four MFMA k-steps; the +4 pad makes the 16-lane b128 groups conflict-free.
+//     Lanes 0-31 take k-slots {0..3}, lanes 32-63 {4..7} of every 8 -- A and B
+//     use the same permutation of K so the contraction is unchanged.
+//   * global -> VGPR -> LDS double buffering: next chunk's loads are issued
+//     before the current chunk's MFMAs, written to the other LDS buffer after
+//     them; one barrier per chunk.
+//   * ORD_QUAD row order m = ((b*H/2+h2)*W/2+w2)*4 + dy*2+dx puts the four
+//     pixels of a 2x2 pooling window in four consecutive accumulator registers
+//     of one lane (C/D layout row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)), so
+//     MaxPooling2D and tf.space_to_depth are free in the epilogue.
+//   * EPI_GATES: the N axis is packed [j/32][gate][j%32]; a wave's four 32-wide
+//     column tiles are the i,f,c,o pre-activations of the same 32 hidden
+//     channels, so the LSTM cell update happens in registers.
+#include "dt_internal.h"
+
+#define LDK 36  // LDS row stride in floats (32 + 4 pad)
+
+__device__ __forceinline__ float leaky_act(float v, float slope) { return v > 0.0f ? v : v * slope; }
+
+__device__ __forceinline__ float hard_sigmoid_f(float x)
+{
+    // Keras 2.x hard_sigmoid: clip(0.2*x + 0.5, 0, 1)
+    float y = __fmaf_rn(0.2f, x, 0.5f);
+    return fminf(fmaxf(y, 0.0f), 1.0f);
+}
+
+template <int ORDER>
+__device__ __forceinline__ void decode_row(int m, int H, int W, int &b, int &h, int &w)
+{
+    if (ORDER == ORD_LINEAR) {
+        const int hw = H * W;
+        b = m / hw;
+        const int r = m - b * hw;
+        h = r / W;
+        w = r - h * W;
+    } else {
+        const int q = m >> 2, d = m & 3;
+        const int W2 = W >> 1, hw2 = (H >> 1) * W2;
+        b = q / hw2;
+        const int r = q - b * hw2;
+        const int h2 = r / W2;
+        const int w2 = r - h2 * W2;
+        h = 2 * h2 + (d >> 1);
+        w = 2 * w2 + (d & 1);
+    }
+}
+
+template <int KS, int BM, int BN, int WGM, int WGN, int ORDER, int EPI>
+__global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
+{
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;    // MFMA tiles per wave
+    constexpr int PA = BM / 32, PB = BN / 32;      // loader passes (32 rows / pass)
+    constexpr int TAPS = KS * KS;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sA = smem;                  // [2][BM][LDK]
+    float *sB = smem + 2 * BM * LDK;   // [2][BN][LDK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // XCD-aware tile order: blocks that share an A row-panel (same m-tile) are
+    // consecutive in blockIdx.x, i.e. spread over the 8 XCDs; weights (B) are
+    // small enough to live in every L2.  Grid: x = n-tiles fastest.
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tile_n = blockIdx.x % ntn;
+    const int tile_m = blockIdx.x / ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- loader set-up ----------------------------------------------------
+    const int lr = tid >> 3;        // 0..31 row within pass
+    const int lc = (tid & 7) * 4;   // float offset within the 32-float chunk
+    const float *a_ptr[PA];
+    unsigned a_mask[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + lr + 32 * i;
+        unsigned mask = 0;
+        const float *ptr = p.in;
+        if (m < p.M) {
+            int b, h, w;
+            decode_row<ORDER>(m, p.H, p.W, b, h, w);
+            ptr = p.in + (long long)b * p.in_bs + (long long)(h * p.W + w) * p.in_ld + lc;
+            if (KS == 1) {
+                mask = 1u;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ih = h + t / 3 - 1, iw = w + t % 3 - 1;
+                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) mask |= 1u << t;
+                }
+            }
+        }
+        a_ptr[i] = ptr;
+        a_mask[i] = mask;
+    }
+    const float *b_ptr[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) b_ptr[i] = p.wt + (long long)(n0 + lr + 32 * i) * p.K + lc;
+
+    const int cpt = p.Cin >> 5;     // 32-float chunks per tap
+    const int nk = TAPS * cpt;
+
+    f32x4 ra[PA], rb[PB];
+    auto gload = [&](int tap, int cc, int kc) {
+        int aoff;
+        if (KS == 1)
+            aoff = cc * 32;
+        else
+            aoff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.in_ld + cc * 32;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((a_mask[i] >> tap) & 1u) v = *reinterpret_cast<const f32x4 *>(a_ptr[i] + aoff);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(b_ptr[i] + kc * 32);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            *reinterpret_cast<f32x4 *>(&sA[(buf * BM + lr + 32 * i) * LDK + lc]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            *reinterpret_cast<f32x4 *>(&sB[(buf * BN + lr + 32 * i) * LDK + lc]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // ---- main loop ----------------------------------------------------------
+    gload(0, 0, 0);
+    lstore(0);
+    __syncthreads();
+
+    const int fr = lane & 31;          // fragment row within a 32-row tile
+    const int fk = (lane >> 5) * 4;    // k sub-slot: lanes 0-31 -> 0..3, 32-63 -> 4..7
+    int tap = 0, cc = 0;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int cur = kc & 1;
+        int ntap = tap, ncc = cc + 1;
+        if (ncc == cpt) { ncc = 0; ntap = tap + 1; }
+        const bool more = (kc + 1) < nk;
+        if (more) gload(ntap, ncc, kc + 1);
+
+        const float *cA = sA + (cur * BM + wm * WTM + fr) * LDK + fk;
+        const float *cB = sB + (cur * BN + wn * WTN + fr) * LDK + fk;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(cA + i * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(cB + j * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        tap = ntap;
+        cc = ncc;
+    }
+
+    // ---- epilogue -----------------------------------------------------------
+    const int hi = lane >> 5;
+    if (EPI == EPI_GATES) {
+        // TN == 4: tile j = gate (i,f,c,o) of hidden channel jc
+        static_assert(EPI != EPI_GATES || TN == 4, "gates need 4 column tiles per wave");
+        const int colbase = n0 + wn * WTN;            // multiple of 128
+        const int jc = (colbase >> 2) + fr;           // hidden channel
+        const int hw = p.H * p.W;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row < p.M) {
+                    const int b = row / hw;
+                    const int pix = row - b * hw;
+                    const float *xp = p.xproj + (long long)b * p.xp_bs + (long long)pix * p.xp_ld + colbase + fr;
+                    const float zi = acc[i][0][r] + xp[0];
+                    const float zf = acc[i][1][r] + xp[32];
+                    const float zc = acc[i][2][r] + xp[64];
+                    const float zo = acc[i][3][r] + xp[96];
+                    float *cp = p.cstate + (long long)b * p.c_bs + (long long)pix * p.c_ld + jc;
+                    const float gi = hard_sigmoid_f(zi), gf = hard_sigmoid_f(zf), go = hard_sigmoid_f(zo);
+                    const float cn = gf * (*cp) + gi * tanhf(zc);
+                    *cp = cn;
+                    p.out[(long long)b * p.out_bs + (long long)pix * p.out_ld + jc] = go * tanhf(cn);
+                }
+            }
+        return;
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WTN + j * 32 + fr;
+            const bool cok = col < p.N;
+            const float bv = (p.bias != nullptr) ? p.bias[col] : 0.0f;  // bias is padded to Npad
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int rbase = m0 + wm * WTM + i * 32 + 8 * g + 4 * hi;
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = leaky_act(acc[i][j][4 * g + q] + bv, p.slope);
+                if (!cok || rbase >= p.M) continue;
+                if (EPI == EPI_PLAIN) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (rbase + q < p.M) p.out[(long long)(rbase + q) * p.out_ld + col] = v[q];
+                } else if (EPI == EPI_S2D) {
+                    // tf.space_to_depth(2): pixel m>>2, channel (m&3)*N + col
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        p.out[(long long)(rbase >> 2) * p.out_ld + q * p.N + col] = v[q];
+                } else {
+                    const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    if (EPI == EPI_POOL) {
+                        p.out[(long long)(rbase >> 2) * p.out_ld + col] = mx;
+                    } else {  // EPI_POOL_BOTH: out = unpooled (standard NHWC), out2 = pooled
+                        p.out2[(long long)(rbase >> 2) * p.out2_ld + col] = mx;
+                        int b, h, w;
+                        decode_row<ORD_QUAD>(rbase, p.H, p.W, b, h, w);
+                        float *o = p.out + ((long long)(b * p.H + h) * p.W + w) * p.out_ld + col;
+                        o[0] = v[0];
+                        o[p.out_ld] = v[1];
+                        o[(long long)p.W * p.out_ld] = v[2];
+                        o[(long long)(p.W + 1) * p.out_ld] = v[3];
+                    }
+                }
+            }
+        }
+}
+
+template <int KS, int BM, int BN, int WGM, int WGN, int ORDER, int EPI>
+static int launch_one(hipStream_t st, const ConvArgs &a)
+{
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    auto kern = conv_igemm_f32<KS, BM, BN, WGM, WGN, ORDER, EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return 1;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ntn)), dim3(256), lds, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+template <int KS, int ORDER, int EPI>
+static int launch_cfg(hipStream_t st, const ConvArgs &a, int cfg)
+{
+    if (cfg == CFG_128x64) return launch_one<KS, 128, 64, 4, 1, ORDER, EPI>(st, a);
+    return launch_one<KS, 128, 128, 2, 2, ORDER, EPI>(st, a);
+}
+
+int launch_conv_igemm(hipStream_t st, const ConvArgs &a, int ks, int order, int epi, int cfg)
+{
+    if (a.Cin % 32 != 0 || a.K != ks * ks * a.Cin) return 2;
+    if (epi == EPI_GATES) {
+        if (order != ORD_LINEAR) return 2;
+        if (ks == 3) return launch_one<3, 128, 128, 4, 1, ORD_LINEAR, EPI_GATES>(st, a);
+        return launch_one<1, 128, 128, 4, 1, ORD_LINEAR, EPI_GATES>(st, a);
+    }
+    if (order == ORD_LINEAR) {
+        if (epi != EPI_PLAIN) return 2;
+        return ks == 3 ? launch_cfg<3, ORD_LINEAR, EPI_PLAIN>(st, a, cfg) : launch_cfg<1, ORD_LINEAR, EPI_PLAIN>(st, a, cfg);
+    }
+    // ORD_QUAD
+    switch (epi) {
+    case EPI_POOL:
+        return ks == 3 ? launch_cfg<3, ORD_QUAD, EPI_POOL>(st, a, cfg) : launch_cfg<1, ORD_QUAD, EPI_POOL>(st, a, cfg);
+    case EPI_POOL_BOTH:
+        return ks == 3 ? launch_cfg<3, ORD_QUAD, EPI_POOL_BOTH>(st, a, cfg) : 2;
+    case EPI_S2D:
+        return ks == 1 ? launch_cfg<1, ORD_QUAD, EPI_S2D>(st, a, cfg) : 2;
+    default:
+        return 2;
+    }
+}
+
+void pack_conv_weights(const float *hwio, int ks, int cin_src, int cout_src, const int *cin_map, int cin_dst,
+                       const int *n_map, int npad, const float *scale, float *dst)
+{
+    const int taps = ks * ks;
+    const size_t K = (size_t)taps * cin_dst;
+    for (int n = 0; n < npad; ++n) {
+        float *row = dst + (size_t)n * K;
+        const int ns = n_map ? n_map[n] : (n < cout_src ? n : -1);
+        if (ns < 0) {
+            for (size_t k = 0; k < K; ++k) row[k] = 0.0f;
+            continue;
+        }
+        const float sc = scale ? scale[ns] : 1.0f;
+        for (int t = 0; t < taps; ++t)
+            for (int ci = 0; ci < cin_dst; ++ci) {
+                const int cs = cin_map ? cin_map[ci] : (ci < cin_src ? ci : -1);
+                row[(size_t)t * cin_dst + ci] =
+                    cs < 0 ? 0.0f : hwio[((size_t)t * cin_src + cs) * cout_src + ns] * sc;
+            }
+    }
+}

@@ -1,0 +1,166 @@
+// Internal declarations shared by the HIP translation units of libmi355_dt.so.
+// gfx950 (MI355X, CDNA4) only -- no other target is supported or compiled.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355_dt.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------
+// implicit-GEMM convolution (conv_igemm.hip)
+// ---------------------------------------------------------------------------
+enum { ORD_LINEAR = 0, ORD_QUAD = 1 };
+enum { EPI_PLAIN = 0, EPI_POOL = 1, EPI_POOL_BOTH = 2, EPI_S2D = 3, EPI_GATES = 4 };
+
+struct ConvArgs {
+    // input activation: pixel (b,h,w) at in + b*in_bs + (h*W+w)*in_ld, Cin floats read
+    const float *in;
+    long long in_bs;
+    int in_ld;
+    // packed weights [Npad][K], k = tap*Cin + ci (k contiguous); bias [Npad] or null
+    const float *wt;
+    const float *bias;
+    // primary output (dense unless EPI_GATES): row r at out + r*out_ld (+ col)
+    float *out;
+    long long out_bs;
+    int out_ld;
+    // secondary output: pooled tensor for EPI_POOL_BOTH
+    float *out2;
+    int out2_ld;
+    // EPI_GATES: z = acc + xproj; c updated in place; h written to out
+    const float *xproj;
+    long long xp_bs;
+    int xp_ld;
+    float *cstate;
+    long long c_bs;
+    int c_ld;
+    int B, H, W, Cin, N, M, K;
+    float slope;  // LeakyReLU slope; 1.0f = linear
+};
+
+// Tile configurations of the MFMA kernel
+enum { CFG_128x128 = 0, CFG_128x64 = 1 };
+
+int launch_conv_igemm(hipStream_t st, const ConvArgs &a, int ks, int order, int epi, int cfg);
+
+// host-side packing: Keras HWIO kernel -> [npad][ks*ks*cin_dst], k contiguous.
+//   cin_map[cin_dst]: source input channel or -1 (zero);  n_map[npad]: source
+//   output channel or -1 (zero row);  scale[cout_src] multiplies each output
+//   channel (folded BatchNorm) or null.
+void pack_conv_weights(const float *hwio, int ks, int cin_src, int cout_src, const int *cin_map,
+                       int cin_dst, const int *n_map, int npad, const float *scale, float *dst);
+
+// ---------------------------------------------------------------------------
+// other kernels
+// ---------------------------------------------------------------------------
+int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, int H, int W,
+                        const float *w_packed /*[27][32]*/, const float *bias /*[32]*/,
+                        const float *lut /*[256] or null*/, float slope, float *out /*[B,H/2,W/2,32]*/);
+
+int launch_decode(hipStream_t st, const float *netout, long long frame_stride, int batch, int GH, int GW, int NB,
+                  int NC, float obj_thr, float nms_thr, const float *anchors_dev, int cap, float *boxes,
+                  int *counts, float *classes, float *post, float *scratch /*[batch][ncell*(5+NC)] or null*/);
+
+int launch_bbox_iou(hipStream_t st, const float *pairs, int n, float *iou);
+
+int launch_associate(hipStream_t st, const float *boxes, const int *counts, int n_clips, int T, int cap,
+                     float thr, int *ids, int *nids);
+
+int launch_convlstm_gates_only(hipStream_t st, const float *xproj, long long xp_bs, int xp_ld, float *cstate,
+                               long long c_bs, int c_ld, float *hout, long long h_bs, int h_ld, int B, int HW,
+                               int U);
+
+int launch_global_maxpool(hipStream_t st, const float *in, int n, int HW, int C, float *out, int out_ld);
+int launch_maxpool4_flatten(hipStream_t st, const float *in, int n, int H, int W, int C, float *out, int out_ld);
+int launch_copy_cols(hipStream_t st, const float *src, int src_ld, float *dst, int dst_ld, long long rows,
+                     int cols);
+int launch_lstm_step(hipStream_t st, const float *xproj /*[B][4U] gate-interleaved*/, long long xp_bs,
+                     const float *h_prev, long long h_bs, float *cstate, const float *Ur_packed /*[U][4U]*/,
+                     float *h_out, long long ho_bs, int B, int U);
+int launch_lstm_step0(hipStream_t st, const float *xproj, long long xp_bs, float *cstate, float *h_out,
+                      long long ho_bs, int B, int U);
+int launch_dense_sigmoid(hipStream_t st, const float *h, long long h_bs, const float *Wd /*[U][O]*/,
+                         const float *bd, int B, int U, int O, float *out, long long out_bs);
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct ProfEntry {
+    int64_t launches = 0;
+    double ms = 0, flops = 0, bytes = 0;
+};
+
+struct PendingEvent {
+    hipEvent_t a, b;
+    std::string name;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ConvLayer {
+    int idx, ks, cin, cout, npad, pool;  // pool: reference MaxPooling2D after this layer
+    float *wt = nullptr;                 // device, packed
+    float *bias = nullptr;               // device, [npad]
+};
+
+struct dt_ctx {
+    std::string err;
+    hipStream_t stream = nullptr;
+    int device_ok = 0;
+    // detector
+    int image_h = 0, image_w = 0, nb_box = 0, nb_class = 0, cb = 0;
+    float anchors[64];
+    float *anchors_dev = nullptr;
+    bool det_loaded = false;
+    ConvLayer layers[24];   // 1..23
+    float *conv1_w = nullptr, *conv1_b = nullptr, *lut255 = nullptr;
+    // tracker head
+    bool trk_loaded = false;
+    int trk_units = 0, trk_cx = 0 /*padded z channels*/;
+    float *trk_wx = nullptr, *trk_bx = nullptr;   // input conv, N gate-interleaved
+    float *trk_wh = nullptr;                      // recurrent conv
+    float *trk_wo = nullptr, *trk_bo = nullptr;   // tconv_2 1x1
+    int trk_wo_npad = 0;
+    // tiny tracker
+    bool tiny_loaded = false;
+    int tiny_D = 0, tiny_Dpad = 0, tiny_U = 0;
+    float *tiny_wx = nullptr, *tiny_bx = nullptr, *tiny_ur = nullptr, *tiny_wd = nullptr, *tiny_bd = nullptr;
+    // workspaces (grown on demand)
+    std::map<std::string, DevBuf> ws;
+    int last_batch = 0;
+    // profiling
+    bool prof = false;
+    std::map<std::string, ProfEntry> prof_tab;
+    std::vector<PendingEvent> pending;
+};
+
+int dt_fail(dt_ctx *ctx, int code, const char *fmt, ...);
+float *ws_get(dt_ctx *ctx, const char *name, size_t bytes, bool zero_on_grow = false);
+
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return dt_fail(ctx, DT_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                           __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// profiling scope helper
+struct ProfScope {
+    dt_ctx *ctx;
+    PendingEvent ev;
+    bool on;
+    ProfScope(dt_ctx *c, const char *name, double flops, double bytes);
+    ~ProfScope();
+};

@@ -1,0 +1,724 @@
+// network.hip -- context, weight loading and layer sequencing behind the C ABI
+// (include/mi355_dt.h).  Graph topology follows the reference:
+//   detector  models_detection/KerasYOLO.py:277-405 (weight order :244-274)
+//   tracker   models_tracking/MultiObjDetTracker.py:160-189
+//   tiny      models_tracking/TinyTracker.py:25-41
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+
+#include "dt_internal.h"
+
+static const float BN_EPS = 1e-3f;   // Keras BatchNormalization default (no epsilon= passed)
+static const float LEAKY = 0.1f;     // LeakyReLU(alpha=0.1)
+static char g_static_err[512] = "";
+
+// (idx, k, cin, cout, pool_after) -- main trunk, KerasYOLO.py:279-384
+static const int TRUNK[20][5] = {
+    {1, 3, 3, 32, 1},      {2, 3, 32, 64, 1},     {3, 3, 64, 128, 0},    {4, 1, 128, 64, 0},
+    {5, 3, 64, 128, 1},    {6, 3, 128, 256, 0},   {7, 1, 256, 128, 0},   {8, 3, 128, 256, 1},
+    {9, 3, 256, 512, 0},   {10, 1, 512, 256, 0},  {11, 3, 256, 512, 0},  {12, 1, 512, 256, 0},
+    {13, 3, 256, 512, 1},  {14, 3, 512, 1024, 0}, {15, 1, 1024, 512, 0}, {16, 3, 512, 1024, 0},
+    {17, 1, 1024, 512, 0}, {18, 3, 512, 1024, 0}, {19, 3, 1024, 1024, 0}, {20, 3, 1024, 1024, 0}};
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int dt_fail(dt_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else snprintf(g_static_err, sizeof(g_static_err), "%s", buf);
+    return code;
+}
+
+float *ws_get(dt_ctx *ctx, const char *name, size_t bytes, bool zero_on_grow)
+{
+    DevBuf &b = ctx->ws[name];
+    if (b.bytes < bytes) {
+        if (b.p) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(b.p);
+            b.p = nullptr;
+            b.bytes = 0;
+        }
+        if (hipMalloc(&b.p, bytes) != hipSuccess) {
+            b.p = nullptr;
+            dt_fail(ctx, DT_ERR_DEVICE, "hipMalloc(%zu) failed for workspace %s", bytes, name);
+            return nullptr;
+        }
+        b.bytes = bytes;
+        if (zero_on_grow) (void)hipMemsetAsync(b.p, 0, bytes, ctx->stream);
+    }
+    return static_cast<float *>(b.p);
+}
+
+ProfScope::ProfScope(dt_ctx *c, const char *name, double flops, double bytes) : ctx(c), on(c->prof)
+{
+    if (!on) return;
+    ev.name = name;
+    (void)hipEventCreate(&ev.a);
+    (void)hipEventCreate(&ev.b);
+    ProfEntry &e = ctx->prof_tab[name];
+    e.launches += 1;
+    e.flops += flops;
+    e.bytes += bytes;
+    (void)hipEventRecord(ev.a, ctx->stream);
+}
+ProfScope::~ProfScope()
+{
+    if (!on) return;
+    (void)hipEventRecord(ev.b, ctx->stream);
+    ctx->pending.push_back(ev);
+}
+
+static int upload(dt_ctx *ctx, float **dst, const std::vector<float> &h)
+{
+    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(dst), h.size() * sizeof(float)));
+    HIP_TRY(ctx, hipMemcpy(*dst, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return DT_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int dt_abi_version(void) { return 100; }
+
+extern "C" int dt_create(dt_ctx **out)
+{
+    if (!out) return dt_fail(nullptr, DT_ERR_ARG, "dt_create: null out");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return dt_fail(nullptr, DT_ERR_DEVICE,
+                       "dt_create: no HIP device visible -- libmi355_dt has no CPU fallback");
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return dt_fail(nullptr, DT_ERR_DEVICE, "dt_create: hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return dt_fail(nullptr, DT_ERR_DEVICE, "dt_create: device is %s; this library is built for gfx950 only",
+                       prop.gcnArchName);
+    dt_ctx *c = new dt_ctx();
+    c->device_ok = 1;
+    std::vector<float> lut(256);
+    for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);   // utils.py:150-153
+    if (upload(c, &c->lut255, lut) != DT_OK) {
+        snprintf(g_static_err, sizeof(g_static_err), "%s", c->err.c_str());
+        delete c;
+        return DT_ERR_DEVICE;
+    }
+    *out = c;
+    return DT_OK;
+}
+
+extern "C" void dt_destroy(dt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->ws)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    for (int i = 0; i <= 23; ++i) {
+        if (ctx->layers[i].wt) (void)hipFree(ctx->layers[i].wt);
+        if (ctx->layers[i].bias) (void)hipFree(ctx->layers[i].bias);
+    }
+    float *singles[] = {ctx->conv1_w, ctx->conv1_b, ctx->lut255, ctx->anchors_dev, ctx->trk_wx, ctx->trk_bx,
+                        ctx->trk_wh,  ctx->trk_wo,  ctx->trk_bo, ctx->tiny_wx,     ctx->tiny_bx, ctx->tiny_ur,
+                        ctx->tiny_wd, ctx->tiny_bd};
+    for (float *p : singles)
+        if (p) (void)hipFree(p);
+    for (auto &e : ctx->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    delete ctx;
+}
+
+extern "C" const char *dt_last_error(dt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_static_err; }
+
+extern "C" int dt_set_stream(dt_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return DT_ERR_ARG;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return DT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// detector
+// ---------------------------------------------------------------------------
+extern "C" int dt_detector_config(dt_ctx *ctx, int image_h, int image_w, int nb_box, int nb_class,
+                                  const float *h_anchors)
+{
+    if (!ctx) return DT_ERR_ARG;
+    if (image_h <= 0 || image_w <= 0 || image_h % 32 || image_w % 32)
+        return dt_fail(ctx, DT_ERR_ARG, "image size %dx%d must be a positive multiple of 32", image_h, image_w);
+    if (nb_box <= 0 || nb_box > 32 || nb_class <= 0 || !h_anchors)
+        return dt_fail(ctx, DT_ERR_ARG, "bad nb_box/nb_class/anchors");
+    ctx->image_h = image_h; ctx->image_w = image_w;
+    ctx->nb_box = nb_box; ctx->nb_class = nb_class;
+    ctx->cb = nb_box * (5 + nb_class);
+    std::vector<float> a(h_anchors, h_anchors + 2 * nb_box);
+    memcpy(ctx->anchors, h_anchors, sizeof(float) * 2 * nb_box);
+    ctx->det_loaded = false;
+    return upload(ctx, &ctx->anchors_dev, a);
+}
+
+// kernel in the darknet file is (O,I,H,W) (KerasYOLO.py:267-268 reshapes the
+// reversed Keras shape and transposes [2,3,1,0]) -> HWIO
+static void oihw_to_hwio(const float *src, int O, int I, int k, std::vector<float> &dst)
+{
+    dst.resize((size_t)O * I * k * k);
+    for (int o = 0; o < O; ++o)
+        for (int i = 0; i < I; ++i)
+            for (int y = 0; y < k; ++y)
+                for (int x = 0; x < k; ++x)
+                    dst[(((size_t)y * k + x) * I + i) * O + o] = src[(((size_t)o * I + i) * k + y) * k + x];
+}
+
+static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, const float *hwio, const float *scale,
+                           const float *bias_src)
+{
+    ConvLayer &L = ctx->layers[idx];
+    L.idx = idx; L.ks = ks; L.cin = cin; L.cout = cout;
+    L.npad = round_up(cout, 128);
+    std::vector<float> packed((size_t)L.npad * ks * ks * cin);
+    pack_conv_weights(hwio, ks, cin, cout, nullptr, cin, nullptr, L.npad, scale, packed.data());
+    std::vector<float> bias(L.npad, 0.0f);
+    for (int c = 0; c < cout; ++c) bias[c] = bias_src[c];
+    int rc = upload(ctx, &L.wt, packed);
+    if (rc) return rc;
+    return upload(ctx, &L.bias, bias);
+}
+
+extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t n_floats, size_t *consumed)
+{
+    if (!ctx || !h_blob) return DT_ERR_ARG;
+    if (!ctx->cb) return dt_fail(ctx, DT_ERR_STATE, "dt_detector_config must be called first");
+    size_t off = 4;   // WeightReader.offset = 4 (utils.py:140)
+    auto take = [&](size_t n) -> const float * {
+        if (off + n > n_floats) return nullptr;
+        const float *p = h_blob + off;
+        off += n;
+        return p;
+    };
+    struct Spec { int idx, k, cin, cout; };
+    std::vector<Spec> specs;
+    for (auto &t : TRUNK) specs.push_back({t[0], t[1], t[2], t[3]});
+    specs.push_back({21, 1, 512, 64});
+    specs.push_back({22, 3, 1280, 1024});
+    std::vector<float> hwio, scale, shift;
+    for (const Spec &s : specs) {   // file order conv_1 .. conv_22, each: beta, gamma, mean, var, kernel
+        const float *beta = take(s.cout), *gamma = take(s.cout), *mean = take(s.cout), *var = take(s.cout);
+        const float *kern = take((size_t)s.cout * s.cin * s.k * s.k);
+        if (!kern) return dt_fail(ctx, DT_ERR_ARG, "weights blob too short at conv_%d", s.idx);
+        scale.resize(s.cout); shift.resize(s.cout);
+        for (int c = 0; c < s.cout; ++c) {
+            scale[c] = gamma[c] * (1.0f / sqrtf(var[c] + BN_EPS));
+            shift[c] = beta[c] - mean[c] * scale[c];
+        }
+        oihw_to_hwio(kern, s.cout, s.cin, s.k, hwio);
+        if (s.idx == 1) {   // direct kernel layout [27][32]
+            std::vector<float> w(27 * 32);
+            for (int t = 0; t < 27; ++t)
+                for (int c = 0; c < 32; ++c) w[t * 32 + c] = hwio[(size_t)t * 32 + c] * scale[c];
+            int rc = upload(ctx, &ctx->conv1_w, w);
+            if (rc) return rc;
+            rc = upload(ctx, &ctx->conv1_b, shift);
+            if (rc) return rc;
+        } else {
+            int rc = load_conv_layer(ctx, s.idx, s.k, s.cin, s.cout, hwio.data(), scale.data(), shift.data());
+            if (rc) return rc;
+        }
+    }
+    {   // conv_23: bias then kernel, no BN (KerasYOLO.py:264-269)
+        const int co = ctx->cb;
+        const float *bias = take(co);
+        const float *kern = take((size_t)co * 1024);
+        if (!kern) return dt_fail(ctx, DT_ERR_ARG, "weights blob too short at conv_23");
+        oihw_to_hwio(kern, co, 1024, 1, hwio);
+        int rc = load_conv_layer(ctx, 23, 1, 1024, co, hwio.data(), nullptr, bias);
+        if (rc) return rc;
+    }
+    if (consumed) *consumed = off;
+    ctx->det_loaded = true;
+    return DT_OK;
+}
+
+struct Dest { float *p; int ld; };
+
+static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld, int B, int H, int W, float *out,
+                    int out_ld, int order, int epi, float slope, float *out2 = nullptr, int out2_ld = 0)
+{
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.in_ld = in_ld; a.in_bs = (long long)H * W * in_ld;
+    a.wt = L.wt; a.bias = L.bias;
+    a.out = out; a.out_ld = out_ld; a.out_bs = (long long)H * W * out_ld;
+    a.out2 = out2; a.out2_ld = out2_ld;
+    a.B = B; a.H = H; a.W = W; a.Cin = L.cin; a.N = L.cout; a.M = B * H * W; a.K = L.ks * L.ks * L.cin;
+    a.slope = slope;
+    const int cfg = L.cout <= 64 ? CFG_128x64 : CFG_128x128;
+    const double flops = 2.0 * a.M * (double)a.K * L.cout;
+    const double bytes = 4.0 * ((double)a.M * L.cin + (double)a.K * L.cout +
+                                (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0));
+    ProfScope ps(ctx, "conv_igemm", flops, bytes);
+    const int rc = launch_conv_igemm(ctx->stream, a, L.ks, order, epi, cfg);
+    if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "conv_%d launch failed (rc=%d)", L.idx, rc);
+    return DT_OK;
+}
+
+// Runs conv_1 .. conv_23.  feat/netout destinations may alias caller buffers.
+static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, Dest feat, Dest netout)
+{
+    if (!ctx->det_loaded) return dt_fail(ctx, DT_ERR_STATE, "detector weights not loaded");
+    if (B <= 0) return dt_fail(ctx, DT_ERR_ARG, "batch must be positive");
+    if (dtype != DT_FRAMES_U8 && dtype != DT_FRAMES_F32) return dt_fail(ctx, DT_ERR_ARG, "bad frames dtype");
+    const int H = ctx->image_h, W = ctx->image_w;
+    if ((long long)B * (H / 2) * (W / 2) >= (1ll << 31)) return dt_fail(ctx, DT_ERR_ARG, "batch too large");
+    const size_t per_frame = (size_t)(H / 2) * (W / 2) * 32;   // largest activation (floats)
+    float *bufA = ws_get(ctx, "actA", per_frame * B * sizeof(float));
+    float *bufB = ws_get(ctx, "actB", per_frame * B * sizeof(float));
+    float *skip = ws_get(ctx, "skip", (size_t)B * (H / 16) * (W / 16) * 512 * sizeof(float));
+    float *cat = ws_get(ctx, "cat", (size_t)B * (H / 32) * (W / 32) * 1280 * sizeof(float));
+    if (!bufA || !bufB || !skip || !cat) return DT_ERR_DEVICE;
+    ctx->last_batch = B;
+
+    {   // conv_1 + norm_1 + leaky + pool, with x/255 fused
+        ProfScope ps(ctx, "conv1_direct", 2.0 * B * H * W * 27.0 * 32.0,
+                     (double)B * H * W * 3.0 * (dtype == DT_FRAMES_U8 ? 1 : 4) + 4.0 * B * (H / 2) * (W / 2) * 32.0);
+        if (launch_conv1_direct(ctx->stream, frames, dtype, B, H, W, ctx->conv1_w, ctx->conv1_b, ctx->lut255, LEAKY,
+                                bufA))
+            return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");
+    }
+    float *cur = bufA, *nxt = bufB;
+    int h = H / 2, w = W / 2;
+    int rc;
+    for (int li = 1; li < 20; ++li) {   // conv_2 .. conv_20
+        const int idx = TRUNK[li][0], pool = TRUNK[li][4];
+        const ConvLayer &L = ctx->layers[idx];
+        if (idx == 13) {   // skip tapped before the pool (KerasYOLO.py:347)
+            rc = run_conv(ctx, L, cur, L.cin, B, h, w, skip, 512, ORD_QUAD, EPI_POOL_BOTH, LEAKY, nxt, 512);
+        } else if (idx == 20) {   // writes channels [256,1280) of the concat buffer (KerasYOLO.py:391)
+            rc = run_conv(ctx, L, cur, L.cin, B, h, w, cat + 256, 1280, ORD_LINEAR, EPI_PLAIN, LEAKY);
+        } else if (pool) {
+            rc = run_conv(ctx, L, cur, L.cin, B, h, w, nxt, L.cout, ORD_QUAD, EPI_POOL, LEAKY);
+        } else {
+            rc = run_conv(ctx, L, cur, L.cin, B, h, w, nxt, L.cout, ORD_LINEAR, EPI_PLAIN, LEAKY);
+        }
+        if (rc) return rc;
+        if (pool) { h /= 2; w /= 2; }
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    // conv_21 on the skip tensor + tf.space_to_depth(2) -> channels [0,256) (KerasYOLO.py:386-391)
+    rc = run_conv(ctx, ctx->layers[21], skip, 512, B, 2 * h, 2 * w, cat, 1280, ORD_QUAD, EPI_S2D, LEAKY);
+    if (rc) return rc;
+    // conv_22 -> 'conv_feat'
+    rc = run_conv(ctx, ctx->layers[22], cat, 1280, B, h, w, feat.p, feat.ld, ORD_LINEAR, EPI_PLAIN, LEAKY);
+    if (rc) return rc;
+    // conv_23 (bias, linear)
+    rc = run_conv(ctx, ctx->layers[23], feat.p, feat.ld, B, h, w, netout.p, netout.ld, ORD_LINEAR, EPI_PLAIN, 1.0f);
+    return rc;
+}
+
+extern "C" int dt_detect_forward(dt_ctx *ctx, const void *d_frames, int frames_dtype, int batch, float *d_netout,
+                                 float *d_feat)
+{
+    if (!ctx || !d_frames) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    const int G2 = (ctx->image_h / 32) * (ctx->image_w / 32);
+    Dest feat{d_feat, 1024}, net{d_netout, ctx->cb};
+    if (!d_feat) {
+        feat.p = ws_get(ctx, "feat", (size_t)batch * G2 * 1024 * sizeof(float));
+        if (!feat.p) return DT_ERR_DEVICE;
+    }
+    if (!d_netout) {
+        net.p = ws_get(ctx, "netout", (size_t)batch * G2 * ctx->cb * sizeof(float));
+        if (!net.p) return DT_ERR_DEVICE;
+    }
+    return detect_internal(ctx, d_frames, frames_dtype, batch, feat, net);
+}
+
+extern "C" int dt_detector_tap(dt_ctx *ctx, const char *name, int batch, float *d_out)
+{
+    if (!ctx || !name || !d_out) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (batch != ctx->last_batch) return dt_fail(ctx, DT_ERR_STATE, "tap batch %d != last forward batch %d", batch, ctx->last_batch);
+    const int H = ctx->image_h, W = ctx->image_w;
+    const char *wsname = nullptr;
+    size_t n = 0;
+    if (!strcmp(name, "act_13")) { wsname = "skip"; n = (size_t)batch * (H / 16) * (W / 16) * 512; }
+    else if (!strcmp(name, "conv_feat")) { wsname = "feat"; n = (size_t)batch * (H / 32) * (W / 32) * 1024; }
+    else if (!strcmp(name, "conv_23")) { wsname = "netout"; n = (size_t)batch * (H / 32) * (W / 32) * ctx->cb; }
+    else return dt_fail(ctx, DT_ERR_ARG, "unknown tap '%s'", name);
+    auto it = ctx->ws.find(wsname);
+    if (it == ctx->ws.end() || it->second.bytes < n * sizeof(float))
+        return dt_fail(ctx, DT_ERR_STATE, "tap '%s' not materialised by the last forward (caller-owned output?)", name);
+    HIP_TRY(ctx, hipMemcpyAsync(d_out, it->second.p, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    return DT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// decode / iou / associate
+// ---------------------------------------------------------------------------
+extern "C" int dt_decode(dt_ctx *ctx, const float *d_netout, int batch, int GH, int GW, int NB, int NC,
+                         float obj_threshold, float nms_threshold, const float *h_anchors, int cap, float *d_boxes,
+                         int *d_counts, float *d_classes, float *d_post)
+{
+    if (!ctx || !d_netout || !d_boxes || !d_counts || !h_anchors) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (batch <= 0 || cap <= 0 || NB <= 0 || NB > 32 || NC <= 0) return dt_fail(ctx, DT_ERR_ARG, "bad decode shape");
+    float *anch = ws_get(ctx, "dec_anchors", 64 * sizeof(float));
+    if (!anch) return DT_ERR_DEVICE;
+    HIP_TRY(ctx, hipMemcpyAsync(anch, h_anchors, sizeof(float) * 2 * NB, hipMemcpyHostToDevice, ctx->stream));
+    const size_t fsz = (size_t)GH * GW * NB * (5 + NC);
+    float *post = d_post;
+    if (!post) {
+        post = ws_get(ctx, "dec_post", (size_t)batch * fsz * sizeof(float));
+        if (!post) return DT_ERR_DEVICE;
+    }
+    ProfScope ps(ctx, "decode_nms", 0.0, 4.0 * 3.0 * batch * (double)fsz);
+    const int rc = launch_decode(ctx->stream, d_netout, (long long)fsz, batch, GH, GW, NB, NC, obj_threshold,
+                                 nms_threshold, anch, cap, d_boxes, d_counts, d_classes, post, nullptr);
+    if (rc == 2)
+        return dt_fail(ctx, DT_ERR_ARG, "decode: grid %dx%dx%d / %d classes exceeds the LDS-resident limits", GH, GW,
+                       NB, NC);
+    if (rc) return dt_fail(ctx, DT_ERR_DEVICE, "decode launch failed");
+    return DT_OK;
+}
+
+extern "C" int dt_bbox_iou(dt_ctx *ctx, const float *d_pairs, int n, float *d_iou)
+{
+    if (!ctx || !d_pairs || !d_iou) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (launch_bbox_iou(ctx->stream, d_pairs, n, d_iou)) return dt_fail(ctx, DT_ERR_DEVICE, "bbox_iou launch failed");
+    return DT_OK;
+}
+
+extern "C" int dt_associate(dt_ctx *ctx, const float *d_boxes, const int *d_counts, int n_clips, int T, int cap,
+                            float assoc_threshold, int *d_ids, int *d_nids)
+{
+    if (!ctx || !d_boxes || !d_counts || !d_ids || !d_nids) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    ProfScope ps(ctx, "associate", 0.0, 4.0 * n_clips * (double)T * cap * 9.0);
+    const int rc = launch_associate(ctx->stream, d_boxes, d_counts, n_clips, T, cap, assoc_threshold, d_ids, d_nids);
+    if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "associate launch failed");
+    return DT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// tracker head (ConvLSTM2D + 1x1)
+// ---------------------------------------------------------------------------
+static void gate_interleave_map(int U, std::vector<int> &n_map)
+{
+    // packed column n' = (j/32)*128 + g*32 + j%32  <-  Keras column g*U + j
+    n_map.resize((size_t)4 * U);
+    for (int np = 0; np < 4 * U; ++np) {
+        const int jb = np / 128, g = (np % 128) / 32, jj = np % 32;
+        n_map[np] = g * U + jb * 32 + jj;
+    }
+}
+
+extern "C" int dt_tracker_load(dt_ctx *ctx, int units, const float *h_kernel, const float *h_recurrent,
+                               const float *h_bias, const float *h_out_kernel, const float *h_out_bias)
+{
+    if (!ctx || !h_kernel || !h_recurrent || !h_bias || !h_out_kernel || !h_out_bias)
+        return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (!ctx->cb) return dt_fail(ctx, DT_ERR_STATE, "dt_detector_config must be called first");
+    if (units <= 0 || units % 32) return dt_fail(ctx, DT_ERR_ARG, "units must be a positive multiple of 32");
+    const int U = units, Cb = ctx->cb, Csrc = Cb + 1024;
+    const int Cx = round_up(1024 + Cb, 32);   // device z layout: [conv_feat 1024 | x_bbox Cb | zero pad]
+    std::vector<int> cin_map(Cx, -1), n_map;
+    for (int c = 0; c < 1024; ++c) cin_map[c] = Cb + c;          // Keras order: x_bbox first, then x_vis
+    for (int c = 0; c < Cb; ++c) cin_map[1024 + c] = c;
+    gate_interleave_map(U, n_map);
+    std::vector<float> wx((size_t)4 * U * 9 * Cx), wh((size_t)4 * U * 9 * U), bx((size_t)4 * U);
+    pack_conv_weights(h_kernel, 3, Csrc, 4 * U, cin_map.data(), Cx, n_map.data(), 4 * U, nullptr, wx.data());
+    pack_conv_weights(h_recurrent, 3, U, 4 * U, nullptr, U, n_map.data(), 4 * U, nullptr, wh.data());
+    for (int np = 0; np < 4 * U; ++np) bx[np] = h_bias[n_map[np]];
+    const int npad = round_up(Cb, 128);
+    std::vector<float> wo((size_t)npad * U), bo(npad, 0.0f);
+    pack_conv_weights(h_out_kernel, 1, U, Cb, nullptr, U, nullptr, npad, nullptr, wo.data());
+    for (int c = 0; c < Cb; ++c) bo[c] = h_out_bias[c];
+    int rc;
+    if ((rc = upload(ctx, &ctx->trk_wx, wx))) return rc;
+    if ((rc = upload(ctx, &ctx->trk_wh, wh))) return rc;
+    if ((rc = upload(ctx, &ctx->trk_bx, bx))) return rc;
+    if ((rc = upload(ctx, &ctx->trk_wo, wo))) return rc;
+    if ((rc = upload(ctx, &ctx->trk_bo, bo))) return rc;
+    ctx->trk_units = U; ctx->trk_cx = Cx; ctx->trk_wo_npad = npad;
+    ctx->trk_loaded = true;
+    return DT_OK;
+}
+
+// xproj = conv3x3(z, Wx) + b for all frames; then the sequential recurrence
+static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, int T, int gh, int gw, int U,
+                             const float *wx, const float *bx, const float *wh, float *hseq /*[n_clips][T][GG][U]*/)
+{
+    const int GG = gh * gw, F = n_clips * T, N4 = 4 * U;
+    float *xproj = ws_get(ctx, "trk_xproj", (size_t)F * GG * N4 * sizeof(float));
+    float *cst = ws_get(ctx, "trk_c", (size_t)n_clips * GG * U * sizeof(float));
+    if (!xproj || !cst) return DT_ERR_DEVICE;
+    {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = z; a.in_ld = Cx; a.in_bs = (long long)GG * Cx;
+        a.wt = wx; a.bias = bx;
+        a.out = xproj; a.out_ld = N4; a.out_bs = (long long)GG * N4;
+        a.B = F; a.H = gh; a.W = gw; a.Cin = Cx; a.N = N4; a.M = F * GG; a.K = 9 * Cx;
+        a.slope = 1.0f;
+        ProfScope ps(ctx, "conv_igemm", 2.0 * a.M * 9.0 * (ctx->cb + 1024) * N4,
+                     4.0 * ((double)a.M * Cx + (double)a.K * N4 + (double)a.M * N4));
+        if (launch_conv_igemm(ctx->stream, a, 3, ORD_LINEAR, EPI_PLAIN, CFG_128x128))
+            return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM input projection launch failed");
+    }
+    const long long xp_bs = (long long)T * GG * N4, h_bs = (long long)T * GG * U, c_bs = (long long)GG * U;
+    {   // t = 0: h_{-1} = c_{-1} = 0
+        ProfScope ps(ctx, "convlstm_gates", 0.0, 4.0 * n_clips * GG * (3.0 * U + 2.0 * U));
+        if (launch_convlstm_gates_only(ctx->stream, xproj, xp_bs, N4, cst, c_bs, U, hseq, h_bs, U, n_clips, GG, U))
+            return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM t=0 launch failed");
+    }
+    for (int t = 1; t < T; ++t) {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = hseq + (long long)(t - 1) * GG * U; a.in_ld = U; a.in_bs = h_bs;
+        a.wt = wh; a.bias = nullptr;
+        a.out = hseq + (long long)t * GG * U; a.out_ld = U; a.out_bs = h_bs;
+        a.xproj = xproj + (long long)t * GG * N4; a.xp_ld = N4; a.xp_bs = xp_bs;
+        a.cstate = cst; a.c_ld = U; a.c_bs = c_bs;
+        a.B = n_clips; a.H = gh; a.W = gw; a.Cin = U; a.N = N4; a.M = n_clips * GG; a.K = 9 * U;
+        a.slope = 1.0f;
+        ProfScope ps(ctx, "conv_igemm", 2.0 * a.M * (double)a.K * N4,
+                     4.0 * ((double)a.M * U + (double)a.K * N4 + (double)a.M * N4 + 3.0 * a.M * U));
+        if (launch_conv_igemm(ctx->stream, a, 3, ORD_LINEAR, EPI_GATES, CFG_128x128))
+            return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM step launch failed");
+    }
+    return DT_OK;
+}
+
+extern "C" int dt_track_forward(dt_ctx *ctx, const void *d_frames, int frames_dtype, int n_clips, int T,
+                                float *d_trk, float *d_det)
+{
+    if (!ctx || !d_frames) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (!ctx->trk_loaded) return dt_fail(ctx, DT_ERR_STATE, "tracker weights not loaded");
+    if (n_clips <= 0 || T <= 0) return dt_fail(ctx, DT_ERR_ARG, "n_clips and T must be positive");
+    const int gh = ctx->image_h / 32, gw = ctx->image_w / 32, GG = gh * gw;
+    const int F = n_clips * T, U = ctx->trk_units, Cx = ctx->trk_cx, Cb = ctx->cb;
+    float *z = ws_get(ctx, "trk_z", (size_t)F * GG * Cx * sizeof(float), /*zero_on_grow=*/true);
+    float *hseq = ws_get(ctx, "trk_h", (size_t)F * GG * U * sizeof(float));
+    if (!z || !hseq) return DT_ERR_DEVICE;
+    int rc = detect_internal(ctx, d_frames, frames_dtype, F, Dest{z, Cx}, Dest{z + 1024, Cx});
+    if (rc) return rc;
+    rc = convlstm_sequence(ctx, z, Cx, n_clips, T, gh, gw, U, ctx->trk_wx, ctx->trk_bx, ctx->trk_wh, hseq);
+    if (rc) return rc;
+    float *trk = d_trk;
+    if (!trk) {
+        trk = ws_get(ctx, "trk_out", (size_t)F * GG * Cb * sizeof(float));
+        if (!trk) return DT_ERR_DEVICE;
+    }
+    {   // TimeDistributed(Conv2D(Cb,(1,1)))  'tconv_2'  (MultiObjDetTracker.py:182)
+        ConvLayer L;
+        L.idx = 102; L.ks = 1; L.cin = U; L.cout = Cb; L.npad = ctx->trk_wo_npad; L.wt = ctx->trk_wo; L.bias = ctx->trk_bo;
+        rc = run_conv(ctx, L, hseq, U, F, gh, gw, trk, Cb, ORD_LINEAR, EPI_PLAIN, 1.0f);
+        if (rc) return rc;
+    }
+    if (d_det) {
+        ProfScope ps(ctx, "misc", 0.0, 8.0 * F * GG * (double)Cb);
+        if (launch_copy_cols(ctx->stream, z + 1024, Cx, d_det, Cb, (long long)F * GG, Cb))
+            return dt_fail(ctx, DT_ERR_DEVICE, "detection copy launch failed");
+    }
+    return DT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// TinyTracker
+// ---------------------------------------------------------------------------
+extern "C" int dt_tiny_load(dt_ctx *ctx, int D, int units, const float *h_kernel, const float *h_recurrent,
+                            const float *h_bias, const float *h_dense_kernel, const float *h_dense_bias)
+{
+    if (!ctx || !h_kernel || !h_recurrent || !h_bias || !h_dense_kernel || !h_dense_bias)
+        return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (units != 512) return dt_fail(ctx, DT_ERR_ARG, "LSTM units must be 512 (config.json:19)");
+    if (D < 8 || (D - 4) % 4) return dt_fail(ctx, DT_ERR_ARG, "feature width D-4 must be a multiple of 4");
+    const int U = units, Dp = round_up(D, 32), N4 = 4 * U;
+    // x.W as a 1x1 "convolution": kernel [D,4U] is HWIO with k=1
+    std::vector<float> wx((size_t)N4 * Dp), bx(h_bias, h_bias + N4);
+    pack_conv_weights(h_kernel, 1, D, N4, nullptr, Dp, nullptr, N4, nullptr, wx.data());
+    // recurrent [U,4U] (k, g*U+j) -> [j][g][k]
+    std::vector<float> ur((size_t)U * N4);
+    for (int j = 0; j < U; ++j)
+        for (int g = 0; g < 4; ++g)
+            for (int k = 0; k < U; ++k) ur[((size_t)j * 4 + g) * U + k] = h_recurrent[(size_t)k * N4 + g * U + j];
+    std::vector<float> wd(h_dense_kernel, h_dense_kernel + (size_t)U * 4), bd(h_dense_bias, h_dense_bias + 4);
+    int rc;
+    if ((rc = upload(ctx, &ctx->tiny_wx, wx))) return rc;
+    if ((rc = upload(ctx, &ctx->tiny_bx, bx))) return rc;
+    if ((rc = upload(ctx, &ctx->tiny_ur, ur))) return rc;
+    if ((rc = upload(ctx, &ctx->tiny_wd, wd))) return rc;
+    if ((rc = upload(ctx, &ctx->tiny_bd, bd))) return rc;
+    ctx->tiny_D = D; ctx->tiny_Dpad = Dp; ctx->tiny_U = U;
+    ctx->tiny_loaded = true;
+    return DT_OK;
+}
+
+extern "C" int dt_tiny_forward(dt_ctx *ctx, const float *d_feat, const float *d_det, int n_seq, int T, int fh, int fw,
+                               int fc, int pool, float *d_out)
+{
+    if (!ctx || !d_feat || !d_det || !d_out) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (!ctx->tiny_loaded) return dt_fail(ctx, DT_ERR_STATE, "TinyTracker weights not loaded");
+    const int U = ctx->tiny_U, D = ctx->tiny_D, Dp = ctx->tiny_Dpad, N4 = 4 * U;
+    const int fdim = pool == 0 ? fc : (fh / 4) * (fw / 4) * fc;
+    if (fdim + 4 != D) return dt_fail(ctx, DT_ERR_ARG, "pooled feature width %d + 4 != D %d", fdim, D);
+    const int R = n_seq * T;
+    float *x = ws_get(ctx, "tiny_x", (size_t)R * Dp * sizeof(float), /*zero_on_grow=*/true);
+    float *xproj = ws_get(ctx, "tiny_xproj", (size_t)R * N4 * sizeof(float));
+    float *hseq = ws_get(ctx, "tiny_h", (size_t)R * U * sizeof(float));
+    float *cst = ws_get(ctx, "tiny_c", (size_t)n_seq * U * sizeof(float));
+    if (!x || !xproj || !hseq || !cst) return DT_ERR_DEVICE;
+    {   // GlobalMaxPooling2D / MaxPooling2D(4,4)+Flatten, then concatenate([x, det]) (TinyTracker.py:29-34)
+        ProfScope ps(ctx, "pool", 0.0, 4.0 * R * ((double)fh * fw * fc + fdim));
+        int rc = pool == 0 ? launch_global_maxpool(ctx->stream, d_feat, R, fh * fw, fc, x, Dp)
+                           : launch_maxpool4_flatten(ctx->stream, d_feat, R, fh, fw, fc, x, Dp);
+        if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "pool launch failed");
+        if (launch_copy_cols(ctx->stream, d_det, 4, x + fdim, Dp, R, 4))
+            return dt_fail(ctx, DT_ERR_DEVICE, "det concat launch failed");
+    }
+    {   // x.W + b for every (sequence, t) at once on the matrix cores
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = x; a.in_ld = Dp; a.in_bs = Dp;
+        a.wt = ctx->tiny_wx; a.bias = ctx->tiny_bx;
+        a.out = xproj; a.out_ld = N4; a.out_bs = N4;
+        a.B = R; a.H = 1; a.W = 1; a.Cin = Dp; a.N = N4; a.M = R; a.K = Dp;
+        a.slope = 1.0f;
+        ProfScope ps(ctx, "conv_igemm", 2.0 * R * (double)D * N4, 4.0 * ((double)R * Dp + (double)Dp * N4 + (double)R * N4));
+        if (launch_conv_igemm(ctx->stream, a, 1, ORD_LINEAR, EPI_PLAIN, CFG_128x128))
+            return dt_fail(ctx, DT_ERR_DEVICE, "LSTM input projection launch failed");
+    }
+    const long long xp_bs = (long long)T * N4, h_bs = (long long)T * U;
+    for (int t = 0; t < T; ++t) {
+        ProfScope ps(ctx, "lstm_step", 2.0 * n_seq * (double)U * N4, 4.0 * ((double)U * N4 + n_seq * (6.0 * U + N4)));
+        int rc;
+        if (t == 0)
+            rc = launch_lstm_step0(ctx->stream, xproj, xp_bs, cst, hseq, h_bs, n_seq, U);
+        else
+            rc = launch_lstm_step(ctx->stream, xproj + (long long)t * N4, xp_bs, hseq + (long long)(t - 1) * U, h_bs,
+                                  cst, ctx->tiny_ur, hseq + (long long)t * U, h_bs, n_seq, U);
+        if (rc) return dt_fail(ctx, DT_ERR_DEVICE, "LSTM step launch failed");
+    }
+    {
+        ProfScope ps(ctx, "misc", 2.0 * R * U * 4.0, 4.0 * R * (U + 4.0));
+        if (launch_dense_sigmoid(ctx->stream, hseq, U, ctx->tiny_wd, ctx->tiny_bd, R, U, 4, d_out, 4))
+            return dt_fail(ctx, DT_ERR_DEVICE, "Dense launch failed");
+    }
+    return DT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// layer-level entry points for the parity tests
+// ---------------------------------------------------------------------------
+extern "C" int dt_conv2d(dt_ctx *ctx, const float *d_in, int B, int H, int W, int Cin, const float *h_kernel, int k,
+                         int Cout, const float *h_bias, float leaky_slope, int pool, float *d_out, float *d_out2)
+{
+    if (!ctx || !d_in || !h_kernel || !d_out) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (Cin % 32) return dt_fail(ctx, DT_ERR_ARG, "Cin must be a multiple of 32");
+    if (k != 1 && k != 3) return dt_fail(ctx, DT_ERR_ARG, "kernel size must be 1 or 3");
+    if (pool && ((H | W) & 1)) return dt_fail(ctx, DT_ERR_ARG, "pooling needs even H and W");
+    std::vector<float> zero(Cout, 0.0f);
+    int rc = load_conv_layer(ctx, 0, k, Cin, Cout, h_kernel, nullptr, h_bias ? h_bias : zero.data());
+    if (rc) return rc;
+    const ConvLayer &L = ctx->layers[0];
+    switch (pool) {
+    case 0: return run_conv(ctx, L, d_in, Cin, B, H, W, d_out, Cout, ORD_LINEAR, EPI_PLAIN, leaky_slope);
+    case 1: return run_conv(ctx, L, d_in, Cin, B, H, W, d_out, Cout, ORD_QUAD, EPI_POOL, leaky_slope);
+    case 2:
+        if (!d_out2 || k != 3) return dt_fail(ctx, DT_ERR_ARG, "pool=2 needs d_out2 and k=3");
+        return run_conv(ctx, L, d_in, Cin, B, H, W, d_out, Cout, ORD_QUAD, EPI_POOL_BOTH, leaky_slope, d_out2, Cout);
+    case 3:
+        if (k != 1) return dt_fail(ctx, DT_ERR_ARG, "space_to_depth epilogue needs k=1");
+        return run_conv(ctx, L, d_in, Cin, B, H, W, d_out, 4 * Cout, ORD_QUAD, EPI_S2D, leaky_slope);
+    default: return dt_fail(ctx, DT_ERR_ARG, "bad pool mode");
+    }
+}
+
+extern "C" int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int W, int Cx, const float *d_h,
+                                const float *d_c, int U, const float *h_kernel, const float *h_recurrent,
+                                const float *h_bias, float *d_h_out, float *d_c_out)
+{
+    if (!ctx || !d_x || !d_h || !d_c || !h_kernel || !h_recurrent || !h_bias || !d_h_out || !d_c_out)
+        return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (Cx % 32 || U % 32) return dt_fail(ctx, DT_ERR_ARG, "Cx and U must be multiples of 32");
+    const int N4 = 4 * U, GG = H * W;
+    std::vector<int> n_map;
+    gate_interleave_map(U, n_map);
+    std::vector<float> wx((size_t)N4 * 9 * Cx), wh((size_t)N4 * 9 * U), bx(N4);
+    pack_conv_weights(h_kernel, 3, Cx, N4, nullptr, Cx, n_map.data(), N4, nullptr, wx.data());
+    pack_conv_weights(h_recurrent, 3, U, N4, nullptr, U, n_map.data(), N4, nullptr, wh.data());
+    for (int np = 0; np < N4; ++np) bx[np] = h_bias[n_map[np]];
+    float *dwx = nullptr, *dwh = nullptr, *dbx = nullptr;
+    int rc;
+    if ((rc = upload(ctx, &dwx, wx)) || (rc = upload(ctx, &dwh, wh)) || (rc = upload(ctx, &dbx, bx))) return rc;
+    float *xproj = ws_get(ctx, "cl_xproj", (size_t)B * GG * N4 * sizeof(float));
+    if (!xproj) return DT_ERR_DEVICE;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = d_x; a.in_ld = Cx; a.in_bs = (long long)GG * Cx;
+    a.wt = dwx; a.bias = dbx;
+    a.out = xproj; a.out_ld = N4; a.out_bs = (long long)GG * N4;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cx; a.N = N4; a.M = B * GG; a.K = 9 * Cx; a.slope = 1.0f;
+    if (launch_conv_igemm(ctx->stream, a, 3, ORD_LINEAR, EPI_PLAIN, CFG_128x128))
+        return dt_fail(ctx, DT_ERR_DEVICE, "xproj launch failed");
+    HIP_TRY(ctx, hipMemcpyAsync(d_c_out, d_c, (size_t)B * GG * U * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    memset(&a, 0, sizeof(a));
+    a.in = d_h; a.in_ld = U; a.in_bs = (long long)GG * U;
+    a.wt = dwh;
+    a.out = d_h_out; a.out_ld = U; a.out_bs = (long long)GG * U;
+    a.xproj = xproj; a.xp_ld = N4; a.xp_bs = (long long)GG * N4;
+    a.cstate = d_c_out; a.c_ld = U; a.c_bs = (long long)GG * U;
+    a.B = B; a.H = H; a.W = W; a.Cin = U; a.N = N4; a.M = B * GG; a.K = 9 * U; a.slope = 1.0f;
+    if (launch_conv_igemm(ctx->stream, a, 3, ORD_LINEAR, EPI_GATES, CFG_128x128))
+        return dt_fail(ctx, DT_ERR_DEVICE, "gates launch failed");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(dwx); (void)hipFree(dwh); (void)hipFree(dbx);
+    return DT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------
+static void prof_drain(dt_ctx *ctx)
+{
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &e : ctx->pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) ctx->prof_tab[e.name].ms += ms;
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    ctx->pending.clear();
+}
+
+extern "C" int dt_profile_enable(dt_ctx *ctx, int on)
+{
+    if (!ctx) return DT_ERR_ARG;
+    prof_drain(ctx);
+    ctx->prof = on != 0;
+    return DT_OK;
+}
+
+extern "C" int dt_profile_reset(dt_ctx *ctx)
+{
+    if (!ctx) return DT_ERR_ARG;
+    prof_drain(ctx);
+    ctx->prof_tab.clear();
+    return DT_OK;
+}
+
+extern "C" int dt_profile_read(dt_ctx *ctx, const char *name, int64_t *launches, double *total_ms, double *flops,
+                               double *bytes)
+{
+    if (!ctx || !name) return DT_ERR_ARG;
+    prof_drain(ctx);
+    auto it = ctx->prof_tab.find(name);
+    ProfEntry e;
+    if (it != ctx->prof_tab.end()) e = it->second;
+    if (launches) *launches = e.launches;
+    if (total_ms) *total_ms = e.ms;
+    if (flops) *flops = e.flops;
+    if (bytes) *bytes = e.bytes;
+    return DT_OK;
+}

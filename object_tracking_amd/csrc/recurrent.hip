@@ -1,0 +1,292 @@
+// recurrent.hip -- the bandwidth/latency-bound pieces of the track-state update:
+//   * ConvLSTM2D cell update for t = 0 (h_{-1} = 0, so z = W*x + b only)
+//     models_tracking/MultiObjDetTracker.py:176
+//   * TinyTracker: GlobalMaxPooling2D / MaxPooling2D(4,4)+Flatten feature
+//     reduction, the per-track LSTM(512, implementation=2) recurrent GEMV with
+//     the cell update, and Dense(4, sigmoid)   models_tracking/TinyTracker.py:29-37
+// Keras 2.x defaults throughout: tanh / hard_sigmoid, gate order i,f,c,o.
+#include "dt_internal.h"
+
+__device__ __forceinline__ float hard_sigmoid_r(float x)
+{
+    float y = __fmaf_rn(0.2f, x, 0.5f);
+    return fminf(fmaxf(y, 0.0f), 1.0f);
+}
+
+// ---------------------------------------------------------------------------
+// ConvLSTM t = 0: xproj is gate-interleaved [.., (j/32)*128 + g*32 + j%32]
+// ---------------------------------------------------------------------------
+__global__ void convlstm_gates0_kernel(const float *xproj, long long xp_bs, int xp_ld, float *cstate, long long c_bs,
+                                       int c_ld, float *hout, long long h_bs, int h_ld, int B, int HW, int U)
+{
+    const long long total = (long long)B * HW * U;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(e % U);
+        const long long r = e / U;
+        const int pix = (int)(r % HW);
+        const int b = (int)(r / HW);
+        const float *xp = xproj + (long long)b * xp_bs + (long long)pix * xp_ld + (j >> 5) * 128 + (j & 31);
+        const float gi = hard_sigmoid_r(xp[0]);
+        const float gc = tanhf(xp[64]);
+        const float go = hard_sigmoid_r(xp[96]);
+        // c_{-1} = 0: the forget term vanishes
+        const float cn = gi * gc;
+        cstate[(long long)b * c_bs + (long long)pix * c_ld + j] = cn;
+        hout[(long long)b * h_bs + (long long)pix * h_ld + j] = go * tanhf(cn);
+    }
+}
+
+int launch_convlstm_gates_only(hipStream_t st, const float *xproj, long long xp_bs, int xp_ld, float *cstate,
+                               long long c_bs, int c_ld, float *hout, long long h_bs, int h_ld, int B, int HW, int U)
+{
+    const long long total = (long long)B * HW * U;
+    if (total <= 0) return 0;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(convlstm_gates0_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xproj, xp_bs, xp_ld, cstate,
+                       c_bs, c_ld, hout, h_bs, h_ld, B, HW, U);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------
+// GlobalMaxPooling2D: in [n][HW][C] -> out[n*out_ld + c].  HBM-bound: every
+// wavefront reads 1 KiB contiguous (64 lanes x float4) per pixel; the four
+// wavefronts of a block split the pixels and combine through LDS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void global_maxpool_kernel(const float *in, int HW, int C, float *out, int out_ld)
+{
+    __shared__ f32x4 s_part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = (blockIdx.y * 64 + lane) * 4;
+    const long long n = blockIdx.x;
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (c4 < C) {
+        const float *p = in + n * HW * C + c4;
+        for (int i = wave; i < HW; i += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(p + (long long)i * C);
+            m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]);
+            m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+        }
+    }
+    s_part[wave][lane] = m;
+    __syncthreads();
+    if (wave == 0 && c4 < C) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f32x4 o = s_part[w][lane];
+            m[0] = fmaxf(m[0], o[0]); m[1] = fmaxf(m[1], o[1]);
+            m[2] = fmaxf(m[2], o[2]); m[3] = fmaxf(m[3], o[3]);
+        }
+        float *o = out + n * out_ld + c4;
+        o[0] = m[0]; o[1] = m[1]; o[2] = m[2]; o[3] = m[3];
+    }
+}
+
+int launch_global_maxpool(hipStream_t st, const float *in, int n, int HW, int C, float *out, int out_ld)
+{
+    if (n <= 0) return 0;
+    if (C % 4 != 0) return 2;
+    dim3 grid((unsigned)n, (unsigned)((C / 4 + 63) / 64));
+    hipLaunchKernelGGL(global_maxpool_kernel, grid, dim3(256), 0, st, in, HW, C, out, out_ld);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// MaxPooling2D((4,4),strides=(4,4)) + Flatten: out[n*out_ld + ((h4*W4)+w4)*C + c]
+__global__ void maxpool4_flatten_kernel(const float *in, int n, int H, int W, int C, float *out, int out_ld)
+{
+    const int H4 = H / 4, W4 = W / 4;
+    const long long total = (long long)n * H4 * W4 * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long long r = e / C;
+        const int w4 = (int)(r % W4); r /= W4;
+        const int h4 = (int)(r % H4);
+        const long long b = r / H4;
+        float m = -INFINITY;
+        for (int dy = 0; dy < 4; ++dy)
+            for (int dx = 0; dx < 4; ++dx)
+                m = fmaxf(m, in[((b * H + 4 * h4 + dy) * W + 4 * w4 + dx) * C + c]);
+        out[b * out_ld + ((long long)h4 * W4 + w4) * C + c] = m;
+    }
+}
+
+int launch_maxpool4_flatten(hipStream_t st, const float *in, int n, int H, int W, int C, float *out, int out_ld)
+{
+    const long long total = (long long)n * (H / 4) * (W / 4) * C;
+    if (total <= 0) return 0;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(maxpool4_flatten_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, n, H, W, C, out, out_ld);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// strided column-block copy: dst[r*dst_ld + c] = src[r*src_ld + c], c < cols
+__global__ void copy_cols_kernel(const float *src, int src_ld, float *dst, int dst_ld, long long rows, int cols)
+{
+    const long long total = rows * cols;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / cols;
+        const int c = (int)(e - r * cols);
+        dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+}
+
+int launch_copy_cols(hipStream_t st, const float *src, int src_ld, float *dst, int dst_ld, long long rows, int cols)
+{
+    const long long total = rows * cols;
+    if (total <= 0) return 0;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, src_ld, dst, dst_ld, rows, cols);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------
+// Per-track LSTM step (TinyTracker.py:36, implementation=2):
+//   z[b] = xproj[b] (= x.W + bias, precomputed for all t by the MFMA GEMM)
+//          + h_prev[b] . Ur          <- this kernel: recurrent gate GEMV
+//   i,f,o = hard_sigmoid, g = tanh;  c' = f*c + i*g;  h' = o*tanh(c')
+// One wavefront per hidden unit j.  Its four gate columns of Ur (packed
+// [j][gate][k], k contiguous, 8 KiB) are read ONCE, coalesced, into registers
+// (lane l holds k = 8l..8l+7 of each gate); then for every track the wavefront
+// reads the 2 KiB h_prev row coalesced, forms four partial dot products per lane
+// and reduces them with wavefront shuffles.  Lane (b mod 64) keeps track b's
+// four sums, so the cell update and the stores run on all lanes at the end.
+// 512 wavefronts in 256 workgroups of 2: every CU streams a 16 KiB weight slice.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(128) void lstm_step_kernel(const float *xproj, long long xp_bs, const float *h_prev,
+                                                        long long h_bs, float *cstate, const float *ur, float *h_out,
+                                                        long long ho_bs, int B, int U)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 2 + (threadIdx.x >> 6);
+    if (j >= U) return;
+    const int KP = U / 64;                  // k per lane (8 for U = 512)
+    // weights: [j][gate][k]
+    float w[4][8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float *wp = ur + ((long long)j * 4 + g) * U + lane * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(wp);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(wp + 4);
+        w[g][0] = a[0]; w[g][1] = a[1]; w[g][2] = a[2]; w[g][3] = a[3];
+        w[g][4] = b[0]; w[g][5] = b[1]; w[g][6] = b[2]; w[g][7] = b[3];
+    }
+    (void)KP;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        float keep[4] = {0.f, 0.f, 0.f, 0.f};
+        const int bn = min(64, B - b0);
+        for (int bb = 0; bb < bn; ++bb) {
+            const float *hp = h_prev + (long long)(b0 + bb) * h_bs + lane * 8;
+            const f32x4 x0 = *reinterpret_cast<const f32x4 *>(hp);
+            const f32x4 x1 = *reinterpret_cast<const f32x4 *>(hp + 4);
+            float s[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float a = x0[0] * w[g][0];
+                a = __fmaf_rn(x0[1], w[g][1], a);
+                a = __fmaf_rn(x0[2], w[g][2], a);
+                a = __fmaf_rn(x0[3], w[g][3], a);
+                a = __fmaf_rn(x1[0], w[g][4], a);
+                a = __fmaf_rn(x1[1], w[g][5], a);
+                a = __fmaf_rn(x1[2], w[g][6], a);
+                a = __fmaf_rn(x1[3], w[g][7], a);
+                s[g] = wave_sum(a);
+            }
+            if (lane == bb) { keep[0] = s[0]; keep[1] = s[1]; keep[2] = s[2]; keep[3] = s[3]; }
+        }
+        if (lane < bn) {
+            const int b = b0 + lane;
+            const float *xp = xproj + (long long)b * xp_bs;
+            const float zi = keep[0] + xp[j];
+            const float zf = keep[1] + xp[U + j];
+            const float zc = keep[2] + xp[2 * U + j];
+            const float zo = keep[3] + xp[3 * U + j];
+            float *cp = cstate + (long long)b * U + j;
+            const float cn = hard_sigmoid_r(zf) * (*cp) + hard_sigmoid_r(zi) * tanhf(zc);
+            *cp = cn;
+            h_out[(long long)b * ho_bs + j] = hard_sigmoid_r(zo) * tanhf(cn);
+        }
+    }
+}
+
+int launch_lstm_step(hipStream_t st, const float *xproj, long long xp_bs, const float *h_prev, long long h_bs,
+                     float *cstate, const float *Ur_packed, float *h_out, long long ho_bs, int B, int U)
+{
+    if (U != 512) return 2;   // lane k-slice of 8 is compiled in (LSTM_UNITS = 512, config.json:19)
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(lstm_step_kernel, dim3((unsigned)((U + 1) / 2)), dim3(128), 0, st, xproj, xp_bs, h_prev, h_bs,
+                       cstate, Ur_packed, h_out, ho_bs, B, U);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// LSTM step for t = 0 (h_{-1} = c_{-1} = 0): elementwise on xproj
+__global__ void lstm_step0_kernel(const float *xproj, long long xp_bs, float *cstate, float *h_out, long long ho_bs,
+                                  int B, int U)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * U) return;
+    const int b = e / U, j = e - b * U;
+    const float *xp = xproj + (long long)b * xp_bs;
+    const float cn = hard_sigmoid_r(xp[j]) * tanhf(xp[2 * U + j]);
+    cstate[(long long)b * U + j] = cn;
+    h_out[(long long)b * ho_bs + j] = hard_sigmoid_r(xp[3 * U + j]) * tanhf(cn);
+}
+
+int launch_lstm_step0(hipStream_t st, const float *xproj, long long xp_bs, float *cstate, float *h_out,
+                      long long ho_bs, int B, int U)
+{
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(lstm_step0_kernel, dim3((unsigned)((B * U + 255) / 256)), dim3(256), 0, st, xproj, xp_bs,
+                       cstate, h_out, ho_bs, B, U);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------
+// Dense(O, sigmoid) over rows of h (TinyTracker.py:37): one wavefront per row,
+// lanes split U, wavefront-shuffle reduction per output.  O <= 8.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dense_sigmoid_kernel(const float *h, long long h_bs, const float *Wd,
+                                                            const float *bd, int B, int U, int O, float *out,
+                                                            long long out_bs)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.0f;
+    const float *hp = h + (long long)row * h_bs;
+    for (int k = lane; k < U; k += 64) {
+        const float x = hp[k];
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+            if (o < O) acc[o] = __fmaf_rn(x, Wd[(long long)k * O + o], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+        if (o < O) {
+            const float s = wave_sum(acc[o]) + bd[o];
+            if (lane == 0) out[(long long)row * out_bs + o] = 1.0f / (1.0f + expf(-s));
+        }
+}
+
+int launch_dense_sigmoid(hipStream_t st, const float *h, long long h_bs, const float *Wd, const float *bd, int B,
+                         int U, int O, float *out, long long out_bs)
+{
+    if (B <= 0) return 0;
+    if (O > 8) return 2;
+    hipLaunchKernelGGL(dense_sigmoid_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, h, h_bs, Wd, bd, B, U, O,
+                       out, out_bs);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}

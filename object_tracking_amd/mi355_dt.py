@@ -1,0 +1,321 @@
+"""ctypes binding of libmi355_dt.so (include/mi355_dt.h) for the Python host.
+
+PyTorch-ROCm is used only as plumbing: device buffers (`tensor.data_ptr()`),
+the current HIP stream and `torch.distributed`.  All compute goes through the
+C ABI.  There is NO CPU fallback: if the shared library is missing, or no gfx950
+device is visible, this module raises -- it never routes around the HIP path.
+
+The binding style follows the reference's own ctypes precedent,
+models_detection/YOLO.py:6-37,58-119 (libdarknet.so), with status codes added.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355_dt.so")
+
+DT_FRAMES_U8 = 0
+DT_FRAMES_F32 = 1
+DT_BOX_FLOATS = 8
+
+SYMBOLS = [
+    "dt_create", "dt_destroy", "dt_last_error", "dt_set_stream", "dt_abi_version",
+    "dt_detector_config", "dt_load_darknet_weights", "dt_detect_forward", "dt_detector_tap",
+    "dt_decode", "dt_bbox_iou", "dt_tracker_load", "dt_track_forward", "dt_associate",
+    "dt_tiny_load", "dt_tiny_forward", "dt_conv2d", "dt_convlstm_step",
+    "dt_profile_enable", "dt_profile_reset", "dt_profile_read",
+]
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libmi355_dt.so and declare the prototypes.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            "libmi355_dt.so not found at %s -- build it with `python -m object_tracking_amd.build` "
+            "(hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cf, csz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    L.dt_create.argtypes = [ctypes.POINTER(vp)]
+    L.dt_destroy.argtypes = [vp]
+    L.dt_destroy.restype = None
+    L.dt_last_error.argtypes = [vp]
+    L.dt_last_error.restype = ctypes.c_char_p
+    L.dt_set_stream.argtypes = [vp, vp]
+    L.dt_abi_version.argtypes = []
+    L.dt_detector_config.argtypes = [vp, ci, ci, ci, ci, vp]
+    L.dt_load_darknet_weights.argtypes = [vp, vp, csz, ctypes.POINTER(csz)]
+    L.dt_detect_forward.argtypes = [vp, vp, ci, ci, vp, vp]
+    L.dt_detector_tap.argtypes = [vp, ctypes.c_char_p, ci, vp]
+    L.dt_decode.argtypes = [vp, vp, ci, ci, ci, ci, ci, cf, cf, vp, ci, vp, vp, vp, vp]
+    L.dt_bbox_iou.argtypes = [vp, vp, ci, vp]
+    L.dt_tracker_load.argtypes = [vp, ci, vp, vp, vp, vp, vp]
+    L.dt_track_forward.argtypes = [vp, vp, ci, ci, ci, vp, vp]
+    L.dt_associate.argtypes = [vp, vp, vp, ci, ci, ci, cf, vp, vp]
+    L.dt_tiny_load.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp]
+    L.dt_tiny_forward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    L.dt_conv2d.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, vp, cf, ci, vp, vp]
+    L.dt_convlstm_step.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]
+    L.dt_profile_enable.argtypes = [vp, ci]
+    L.dt_profile_reset.argtypes = [vp]
+    L.dt_profile_read.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64),
+                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                  ctypes.POINTER(ctypes.c_double)]
+    for s in SYMBOLS:
+        if s not in ("dt_destroy", "dt_last_error"):
+            getattr(L, s).restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def _hptr(a):
+    """host float32 array -> (keepalive, void*)"""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _dptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Context(object):
+    """One dt_ctx (one GPU, one process)."""
+
+    def __init__(self, device=None):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise NativeError("no HIP device visible to PyTorch-ROCm; the MI355X path has no CPU fallback")
+        if device is not None:
+            torch.cuda.set_device(device)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        h = ctypes.c_void_p()
+        rc = self.lib.dt_create(ctypes.byref(h))
+        if rc != 0:
+            raise NativeError("dt_create failed (%d): %s" % (rc, self.lib.dt_last_error(None).decode()))
+        self.h = h
+        self.cb = None
+        self.grid = None
+        self.nb_box = None
+        self.nb_class = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise NativeError("%s failed (%d): %s" % (what, rc, self.lib.dt_last_error(self.h).decode()))
+
+    def _sync_stream(self):
+        st = self.torch.cuda.current_stream(self.device).cuda_stream
+        self.lib.dt_set_stream(self.h, ctypes.c_void_p(st))
+
+    def _f32(self, *shape):
+        return self.torch.empty(shape, dtype=self.torch.float32, device=self.device)
+
+    # ---- detector -----------------------------------------------------
+    def detector_config(self, image_h, image_w, nb_box, nb_class, anchors):
+        keep, p = _hptr(anchors)
+        self._check(self.lib.dt_detector_config(self.h, image_h, image_w, nb_box, nb_class, p), "dt_detector_config")
+        self.image_h, self.image_w = image_h, image_w
+        self.nb_box, self.nb_class = nb_box, nb_class
+        self.cb = nb_box * (5 + nb_class)
+        self.grid = (image_h // 32, image_w // 32)
+
+    def load_darknet_weights(self, blob):
+        keep, p = _hptr(blob)
+        used = ctypes.c_size_t(0)
+        self._check(self.lib.dt_load_darknet_weights(self.h, p, keep.size, ctypes.byref(used)), "dt_load_darknet_weights")
+        return used.value
+
+    def _frames_dtype(self, frames):
+        t = self.torch
+        if frames.dtype == t.uint8:
+            return DT_FRAMES_U8
+        if frames.dtype == t.float32:
+            return DT_FRAMES_F32
+        raise NativeError("frames must be uint8 or float32, got %s" % frames.dtype)
+
+    def detect_forward(self, frames, want_feat=False):
+        """frames [B,H,W,3] device tensor -> netout [B,G,G,nb_box,5+C] (+ feat [B,G,G,1024])."""
+        assert frames.is_cuda and frames.is_contiguous() and frames.dim() == 4
+        B = frames.shape[0]
+        gh, gw = self.grid
+        netout = self._f32(B, gh, gw, self.nb_box, 5 + self.nb_class)
+        feat = self._f32(B, gh, gw, 1024) if want_feat else None
+        self._sync_stream()
+        self._check(self.lib.dt_detect_forward(self.h, _dptr(frames), self._frames_dtype(frames), B,
+                                               _dptr(netout), _dptr(feat)), "dt_detect_forward")
+        return (netout, feat) if want_feat else netout
+
+    def detect_forward_internal(self, frames):
+        """Forward into the context's own workspaces (for dt_detector_tap)."""
+        assert frames.is_cuda and frames.is_contiguous() and frames.dim() == 4
+        self._sync_stream()
+        self._check(self.lib.dt_detect_forward(self.h, _dptr(frames), self._frames_dtype(frames), frames.shape[0],
+                                               None, None), "dt_detect_forward")
+
+    def detector_tap(self, name, batch):
+        H, W = self.image_h, self.image_w
+        shape = {"act_13": (batch, H // 16, W // 16, 512), "conv_feat": (batch, H // 32, W // 32, 1024),
+                 "conv_23": (batch, H // 32, W // 32, self.cb)}[name]
+        out = self._f32(*shape)
+        self._sync_stream()
+        self._check(self.lib.dt_detector_tap(self.h, name.encode(), batch, _dptr(out)), "dt_detector_tap")
+        return out
+
+    # ---- decode -------------------------------------------------------
+    def decode(self, netout, obj_threshold, nms_threshold, anchors, nb_class, cap=None,
+               want_classes=False, want_post=False):
+        """netout [B,GH,GW,NB,5+C] device float32 (not modified).  Returns dict of
+        device tensors: boxes [B,cap,8], counts [B] (+ classes, post)."""
+        t = self.torch
+        assert netout.is_cuda and netout.dtype == t.float32 and netout.is_contiguous() and netout.dim() == 5
+        B, GH, GW, NB, S = netout.shape
+        assert S == 5 + nb_class
+        if cap is None:
+            cap = GH * GW * NB
+        boxes = t.zeros((B, cap, DT_BOX_FLOATS), dtype=t.float32, device=self.device)
+        counts = t.zeros((B,), dtype=t.int32, device=self.device)
+        classes = t.zeros((B, cap, nb_class), dtype=t.float32, device=self.device) if want_classes else None
+        post = t.empty_like(netout) if want_post else None
+        keep, ap = _hptr(anchors)
+        self._sync_stream()
+        self._check(self.lib.dt_decode(self.h, _dptr(netout), B, GH, GW, NB, nb_class, float(obj_threshold),
+                                       float(nms_threshold), ap, cap, _dptr(boxes), _dptr(counts),
+                                       _dptr(classes), _dptr(post)), "dt_decode")
+        return dict(boxes=boxes, counts=counts, classes=classes, post=post)
+
+    def bbox_iou(self, pairs):
+        t = self.torch
+        assert pairs.is_cuda and pairs.dtype == t.float32 and pairs.is_contiguous()
+        n = pairs.shape[0]
+        out = self._f32(n)
+        self._sync_stream()
+        self._check(self.lib.dt_bbox_iou(self.h, _dptr(pairs), n, _dptr(out)), "dt_bbox_iou")
+        return out
+
+    def associate(self, boxes, counts, assoc_threshold):
+        """boxes [n_clips,T,cap,8], counts [n_clips,T] int32 -> ids [n_clips,T,cap], nids [n_clips]."""
+        t = self.torch
+        assert boxes.is_cuda and boxes.is_contiguous() and counts.is_contiguous() and counts.dtype == t.int32
+        n_clips, T, cap, _ = boxes.shape
+        ids = t.empty((n_clips, T, cap), dtype=t.int32, device=self.device)
+        nids = t.empty((n_clips,), dtype=t.int32, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.dt_associate(self.h, _dptr(boxes), _dptr(counts), n_clips, T, cap,
+                                          float(assoc_threshold), _dptr(ids), _dptr(nids)), "dt_associate")
+        return ids, nids
+
+    # ---- tracker ------------------------------------------------------
+    def tracker_load(self, units, kernel, recurrent, bias, out_kernel, out_bias):
+        ks = [_hptr(a) for a in (kernel, recurrent, bias, out_kernel, out_bias)]
+        self._check(self.lib.dt_tracker_load(self.h, units, *[k[1] for k in ks]), "dt_tracker_load")
+        self.trk_units = units
+
+    def track_forward(self, frames, want_det=True):
+        """frames [n_clips,T,H,W,3] -> tracking grid [n_clips,T,G,G,NB,5+C] (+ detection grid)."""
+        assert frames.is_cuda and frames.is_contiguous() and frames.dim() == 5
+        n_clips, T = frames.shape[:2]
+        gh, gw = self.grid
+        trk = self._f32(n_clips, T, gh, gw, self.nb_box, 5 + self.nb_class)
+        det = self._f32(n_clips, T, gh, gw, self.nb_box, 5 + self.nb_class) if want_det else None
+        self._sync_stream()
+        self._check(self.lib.dt_track_forward(self.h, _dptr(frames), self._frames_dtype(frames), n_clips, T,
+                                              _dptr(trk), _dptr(det)), "dt_track_forward")
+        return (trk, det) if want_det else trk
+
+    # ---- tiny tracker ---------------------------------------------------
+    def tiny_load(self, D, units, kernel, recurrent, bias, dense_kernel, dense_bias):
+        ks = [_hptr(a) for a in (kernel, recurrent, bias, dense_kernel, dense_bias)]
+        self._check(self.lib.dt_tiny_load(self.h, D, units, *[k[1] for k in ks]), "dt_tiny_load")
+
+    def tiny_forward(self, feat, det, pool="Global"):
+        """feat [n_seq,T,fh,fw,fc], det [n_seq,T,4] -> [n_seq,T,4]."""
+        t = self.torch
+        assert feat.is_cuda and feat.is_contiguous() and feat.dtype == t.float32
+        assert det.is_cuda and det.is_contiguous() and det.dtype == t.float32
+        n_seq, T, fh, fw, fc = feat.shape
+        out = self._f32(n_seq, T, 4)
+        self._sync_stream()
+        self._check(self.lib.dt_tiny_forward(self.h, _dptr(feat), _dptr(det), n_seq, T, fh, fw, fc,
+                                             0 if pool == "Global" else 1, _dptr(out)), "dt_tiny_forward")
+        return out
+
+    # ---- layer-level (parity tests) -----------------------------------
+    def conv2d(self, x, kernel_hwio, bias=None, leaky_slope=1.0, pool=0):
+        t = self.torch
+        assert x.is_cuda and x.is_contiguous() and x.dtype == t.float32
+        B, H, W, Cin = x.shape
+        k, _, ci, Cout = kernel_hwio.shape
+        assert ci == Cin
+        kk, kp = _hptr(kernel_hwio)
+        bb, bp = _hptr(bias) if bias is not None else (None, None)
+        if pool == 0:
+            out, out2 = self._f32(B, H, W, Cout), None
+        elif pool == 1:
+            out, out2 = self._f32(B, H // 2, W // 2, Cout), None
+        elif pool == 2:
+            out, out2 = self._f32(B, H, W, Cout), self._f32(B, H // 2, W // 2, Cout)
+        else:
+            out, out2 = self._f32(B, H // 2, W // 2, 4 * Cout), None
+        self._sync_stream()
+        self._check(self.lib.dt_conv2d(self.h, _dptr(x), B, H, W, Cin, kp, k, Cout, bp, float(leaky_slope), pool,
+                                       _dptr(out), _dptr(out2)), "dt_conv2d")
+        return (out, out2) if pool == 2 else out
+
+    def convlstm_step(self, x, h, c, kernel, recurrent, bias):
+        t = self.torch
+        B, H, W, Cx = x.shape
+        U = h.shape[-1]
+        ho, co = t.empty_like(h), t.empty_like(c)
+        ks = [_hptr(a) for a in (kernel, recurrent, bias)]
+        self._sync_stream()
+        self._check(self.lib.dt_convlstm_step(self.h, _dptr(x), B, H, W, Cx, _dptr(h), _dptr(c), U,
+                                              ks[0][1], ks[1][1], ks[2][1], _dptr(ho), _dptr(co)), "dt_convlstm_step")
+        return ho, co
+
+    # ---- profiling ------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._sync_stream()
+        self._check(self.lib.dt_profile_enable(self.h, 1 if on else 0), "dt_profile_enable")
+
+    def profile_reset(self):
+        self._check(self.lib.dt_profile_reset(self.h), "dt_profile_reset")
+
+    def profile_read(self, name):
+        n = ctypes.c_int64(0)
+        ms, fl, by = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self.lib.dt_profile_read(self.h, name.encode(), ctypes.byref(n), ctypes.byref(ms),
+                                             ctypes.byref(fl), ctypes.byref(by)), "dt_profile_read")
+        return dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on the current device (created on first use)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx

@@ -1,0 +1,353 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against
+ (a) the golden vectors generated from the reference's numpy code,
+ (b) the CPU oracle on the same seeded inputs (sizes the oracle finishes in seconds),
+ (c) size-independent properties at full size.
+Bars: exact box set / order / labels / track ids; coordinates and scores within
+2e-6 relative (float32 exp / summation-order ulps); conv stacks within 1e-3 of
+the activation scale (north_star: box coords within 1e-3 fp32)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from utility import synth
+
+pytestmark = pytest.mark.gpu
+
+ANCHORS = [0.57273, 0.677385, 1.87446, 2.06253, 3.33843, 5.47434, 7.88282, 3.52778, 9.77052, 9.16828]
+
+
+def dev(a, ctx):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)
+
+
+def relerr(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+# ------------------------------------------------------------------ decode / NMS
+def _check_decode_rows(rows, g_rows):
+    assert len(rows) == len(g_rows), "box count differs"
+    if len(g_rows):
+        assert np.array_equal(rows[:, 5], g_rows[:, 5]), "labels / order differ"
+        np.testing.assert_allclose(rows[:, :5], g_rows[:, :5], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(rows[:, 6], g_rows[:, 6], rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", [
+    "g13_c80_n24", "g13_c12_n32", "g19_c12_n128", "g3_background", "g5_rescale", "g3_relabel",
+    "g7_c5_lowthr", "g7_c12_nms09", "g7_c12_nms01", "g5_c1", "g4_dense"])
+def test_decode_matches_reference_golden(ctx, golden_dir, name):
+    d = np.load(os.path.join(golden_dir, "decode_%s.npz" % name))
+    C = int(d["nb_class"])
+    r = ctx.decode(dev(d["netout"][None], ctx), float(d["obj_threshold"]), float(d["nms_threshold"]), d["anchors"],
+                   C, want_classes=True, want_post=True)
+    n = int(r["counts"][0])
+    rows = r["boxes"][0, :n].cpu().numpy()
+    _check_decode_rows(rows, d["boxes"])
+    if n:
+        np.testing.assert_allclose(r["classes"][0, :n].cpu().numpy(), d["classes"], rtol=2e-6, atol=1e-7)
+    if "netout_post" in d:
+        np.testing.assert_allclose(r["post"][0].cpu().numpy(), d["netout_post"], rtol=2e-6, atol=1e-7)
+
+
+def test_decode_drop_in_function_mutates_like_reference(golden_dir):
+    from utility.utils import decode_netout
+    d = np.load(os.path.join(golden_dir, "decode_g5_rescale.npz"))
+    net = d["netout"].copy()
+    boxes = decode_netout(net, float(d["obj_threshold"]), float(d["nms_threshold"]), list(d["anchors"]), int(d["nb_class"]))
+    assert len(boxes) == len(d["boxes"])
+    np.testing.assert_allclose(net, d["netout_post"], rtol=2e-6, atol=1e-7)      # in-place, like utils.py:214-216
+    for b, g in zip(boxes, d["boxes"]):
+        assert b.get_label() == int(g[5])
+        assert abs(b.get_score() - g[6]) < 1e-6 and abs(b.x - g[0]) < 1e-6
+        assert np.shares_memory(b.classes, net)                                   # views, like the reference
+
+
+def _planted(seed, G, C, n_obj):
+    rs = np.random.RandomState(seed)
+    g = rs.randn(G, G, 5, 5 + C).astype(np.float32)
+    g[..., 4] -= 4.0
+    for k, cell in enumerate(rs.permutation(G * (G - 1))[:n_obj]):
+        row, col = divmod(int(cell), G - 1)
+        b = int(rs.randint(0, 5)); cls = int(rs.randint(0, C))
+        g[row, col, b, 4] = 4.0 + rs.rand()
+        g[row, col, b, 5 + cls] += 12.0 + rs.rand()
+        if k % 3 == 0:
+            g[row, col + 1, b, :] = g[row, col, b, :]
+            g[row, col + 1, b, 0] -= 3.0
+            g[row, col + 1, b, 4] -= 0.25 + 0.5 * rs.rand()
+    return g
+
+
+@pytest.mark.parametrize("G,C,n_obj,B", [(13, 80, 24, 6), (13, 12, 32, 16), (19, 12, 128, 5), (7, 3, 40, 9)])
+def test_decode_batch_vs_oracle(ctx, G, C, n_obj, B):
+    grids = np.stack([_planted(1000 + 17 * i + G, G, C, n_obj) for i in range(B)])
+    r = ctx.decode(dev(grids, ctx), 0.5, 0.45, ANCHORS, C)
+    counts = r["counts"].cpu().numpy()
+    boxes = r["boxes"].cpu().numpy()
+    for i in range(B):
+        rows, _ = orc.decode_netout(grids[i], 0.5, 0.45, ANCHORS, C)
+        assert counts[i] == len(rows)
+        got = boxes[i, :counts[i]]
+        assert np.array_equal(got[:, 5], rows[:, 5]) and np.array_equal(got[:, 7], rows[:, 7])
+        np.testing.assert_allclose(got[:, :7], rows[:, :7], rtol=2e-6, atol=1e-6)
+        assert np.all(np.diff(got[:, 7]) > 0), "creation (row,col,b) order"
+
+
+def test_decode_properties_full_size(ctx):
+    """Size-independent properties on 64 frames of the 19x19 / 128-object case:
+    batch invariance, cap truncation keeps a prefix, survivors are above threshold,
+    no two same-label survivors overlap at IoU >= nms threshold."""
+    B, G, C = 64, 19, 12
+    grids = np.stack([_planted(5000 + i, G, C, 128) for i in range(B)])
+    d = dev(grids, ctx)
+    full = ctx.decode(d, 0.5, 0.45, ANCHORS, C)
+    one = ctx.decode(d[7:8].contiguous(), 0.5, 0.45, ANCHORS, C)
+    n7 = int(full["counts"][7])
+    assert int(one["counts"][0]) == n7
+    assert torch.equal(one["boxes"][0, :n7], full["boxes"][7, :n7])
+    capped = ctx.decode(d, 0.5, 0.45, ANCHORS, C, cap=50)
+    assert torch.equal(capped["counts"], full["counts"])
+    assert torch.equal(capped["boxes"][:, :50], full["boxes"][:, :50])
+    bx = full["boxes"].cpu().numpy(); cn = full["counts"].cpu().numpy()
+    for i in range(0, B, 9):
+        r = bx[i, :cn[i]]
+        assert np.all(r[:, 6] > 0.5)
+        pairs = [(a, b) for a in range(len(r)) for b in range(a + 1, len(r)) if r[a, 5] == r[b, 5]]
+        if pairs:
+            pr = np.array([np.concatenate([r[a, :4], r[b, :4]]) for a, b in pairs], dtype=np.float32)
+            iou = ctx.bbox_iou(dev(pr, ctx)).cpu().numpy()
+            assert np.all(iou < 0.45)
+
+
+def test_bbox_iou_bit_exact_vs_reference(ctx, golden_dir):
+    d = np.load(os.path.join(golden_dir, "bbox_iou.npz"))
+    got = ctx.bbox_iou(dev(d["pairs"], ctx)).cpu().numpy()
+    assert np.array_equal(got, d["iou"].astype(np.float32))
+
+
+# ------------------------------------------------------------------ conv kernel
+@pytest.mark.parametrize("B,H,W,Cin,k,Cout,pool", [
+    (2, 10, 12, 32, 3, 64, 0),     # N<=64 tile config, M edge
+    (1, 13, 13, 64, 3, 128, 0),    # 128x128 config, M=169 (one partial tile)
+    (3, 13, 13, 96, 1, 85, 0),     # 1x1, N edge (85), Cin = 3 chunks
+    (2, 8, 8, 32, 3, 32, 1),       # fused 2x2 max-pool
+    (1, 26, 26, 64, 3, 160, 1),    # pool, two N tiles with edge
+    (2, 12, 8, 64, 3, 128, 2),     # pool + unpooled (skip tap of conv_13)
+    (2, 6, 10, 64, 1, 64, 3),      # 1x1 + tf.space_to_depth(2) (conv_21)
+    (1, 13, 13, 1280, 3, 256, 0),  # long K (conv_22's Cin)
+])
+def test_conv2d_vs_oracle(ctx, B, H, W, Cin, k, Cout, pool):
+    rs = np.random.RandomState(B * 1000 + H + Cin + Cout)
+    x = rs.randn(B, H, W, Cin).astype(np.float32)
+    w = (rs.randn(k, k, Cin, Cout) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32)
+    ref = orc.conv2d(x, w, b)
+    orc.lib().orc_leaky(ref.ctypes.data_as(__import__("ctypes").c_void_p), __import__("ctypes").c_int64(ref.size),
+                        __import__("ctypes").c_float(0.1))
+    got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=pool)
+    tol = 2e-5
+    if pool == 0:
+        assert relerr(got.cpu().numpy(), ref) < tol
+    elif pool == 1:
+        assert relerr(got.cpu().numpy(), orc.maxpool2(ref)) < tol
+    elif pool == 2:
+        assert relerr(got[0].cpu().numpy(), ref) < tol
+        assert relerr(got[1].cpu().numpy(), orc.maxpool2(ref)) < tol
+    else:
+        assert relerr(got.cpu().numpy(), orc.space_to_depth2(ref)) < tol
+
+
+def test_conv2d_detects_transpose(ctx):
+    """asymmetric one-hot kernel: output channel n copies input channel (n*7)%Cin
+    shifted by the tap -- a swapped A/B fragment or C/D row/col map fails this."""
+    B, H, W, Cin, Cout = 1, 9, 11, 32, 96
+    x = np.arange(B * H * W * Cin, dtype=np.float32).reshape(B, H, W, Cin) % 251
+    w = np.zeros((3, 3, Cin, Cout), dtype=np.float32)
+    for n in range(Cout):
+        w[n % 3, (n // 3) % 3, (n * 7) % Cin, n] = 1.0
+    got = ctx.conv2d(dev(x, ctx), w, None, leaky_slope=1.0, pool=0).cpu().numpy()
+    assert np.array_equal(got, orc.conv2d(x, w))
+
+
+# ------------------------------------------------------------------ detector
+def _detector(ctx_unused, H, W, C, seed=1234):
+    from models_detection.KerasYOLO import KerasYOLO
+    labels = [str(i) for i in range(C)]
+    blob = synth.synth_darknet_blob(C, seed=seed)
+    det = KerasYOLO({'LABELS': labels, 'BATCH_SIZE': 4, 'IMAGE_H': H, 'IMAGE_W': W, 'GRID_H': H // 32,
+                     'GRID_W': W // 32}, weights=blob)
+    layers, used = orc.parse_darknet_blob(blob, C)
+    assert used == blob.size
+    return det, layers, blob
+
+
+@pytest.mark.parametrize("H,W,C,B", [(64, 64, 12, 3), (96, 64, 80, 2)])
+def test_detector_forward_vs_oracle_small(ctx, H, W, C, B):
+    det, layers, _ = _detector(ctx, H, W, C)
+    rs = np.random.RandomState(42)
+    frames = rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
+    ref_net, ref_feat, taps = orc.yolov2_forward(orc.normalize_u8(frames), layers, taps=("act_13",))
+    net, feat = det.model.ctx.detect_forward(dev(frames, det.model.ctx), want_feat=True)
+    assert relerr(net.cpu().numpy(), ref_net) < 1e-3
+    assert relerr(feat.cpu().numpy(), ref_feat) < 1e-3
+    # float32 frames (already normalised) take the same path
+    net32 = det.model.ctx.detect_forward(dev(orc.normalize_u8(frames), det.model.ctx))
+    assert torch.equal(net32, net)
+    # named taps (KerasYOLO.extract)
+    det.model.ctx.detect_forward_internal(dev(frames, det.model.ctx))
+    a13 = det.model.ctx.detector_tap("act_13", B).cpu().numpy()
+    assert relerr(a13, taps["act_13"]) < 1e-3
+    assert torch.equal(det.model.ctx.detector_tap("conv_23", B).reshape(net.shape), net)
+
+
+def test_detector_full_size_one_frame_vs_oracle(ctx):
+    """configs[0]-shaped case: one 416x416 frame through the full YOLOv2 (C=80)."""
+    det, layers, _ = _detector(ctx, 416, 416, 80)
+    frame = synth.synth_clip(1, 416, 416, 3, seed=7)
+    ref_net, _, _ = orc.yolov2_forward(orc.normalize_u8(frame), layers)
+    net = det.model.ctx.detect_forward(dev(frame, det.model.ctx)).cpu().numpy()
+    assert net.shape == (1, 13, 13, 5, 85)
+    assert relerr(net, ref_net) < 1e-3
+    # box parity on the decoded output (boost objectness so boxes exist)
+    boost = net.copy(); boost[..., 4] += 2.0; boost[..., 5:] *= 4.0
+    rboost = ref_net.copy(); rboost[..., 4] += 2.0; rboost[..., 5:] *= 4.0
+    rows, _ = orc.decode_netout(rboost[0], 0.3, 0.45, ANCHORS, 80)
+    r = det.model.ctx.decode(dev(boost, det.model.ctx), 0.3, 0.45, ANCHORS, 80)
+    n = int(r["counts"][0])
+    got = r["boxes"][0, :n].cpu().numpy()
+    if len(rows) == n and n > 0 and np.array_equal(got[:, 7], rows[:, 7]):
+        assert np.abs(got[:, :4] - rows[:, :4]).max() < 1e-3
+
+
+def test_detector_batch_invariance_full_size(ctx):
+    """A frame's output must not depend on its position in the batch (bit-exact)."""
+    det, _, _ = _detector(ctx, 416, 416, 12)
+    frames = np.concatenate([synth.synth_clip(3, 416, 416, 2, seed=s) for s in (1, 2)])
+    d = dev(frames, det.model.ctx)
+    full = det.model.ctx.detect_forward(d)
+    single = det.model.ctx.detect_forward(d[4:5].contiguous())
+    assert torch.equal(single[0], full[4])
+    again = det.model.ctx.detect_forward(d)
+    assert torch.equal(again, full), "run-to-run determinism"
+
+
+# ------------------------------------------------------------------ ConvLSTM / tracker
+def test_convlstm_step_vs_oracle(ctx):
+    rs = np.random.RandomState(9)
+    B, H, W, Cx, U = 3, 5, 7, 96, 64
+    x = rs.randn(B, H, W, Cx).astype(np.float32)
+    h = (rs.randn(B, H, W, U) * .5).astype(np.float32); c = rs.randn(B, H, W, U).astype(np.float32)
+    Wk = (rs.randn(3, 3, Cx, 4 * U) * .05).astype(np.float32); Uk = (rs.randn(3, 3, U, 4 * U) * .05).astype(np.float32)
+    b = rs.randn(4 * U).astype(np.float32) * .1
+    rh, rc = orc.convlstm_step(x, h, c, Wk, Uk, b)
+    gh, gc = ctx.convlstm_step(dev(x, ctx), dev(h, ctx), dev(c, ctx), Wk, Uk, b)
+    np.testing.assert_allclose(gh.cpu().numpy(), rh, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(gc.cpu().numpy(), rc, rtol=1e-4, atol=2e-5)
+
+
+def _tracker(H, W, T, C=12, seed=1235):
+    from models_tracking.MultiObjDetTracker import MultiObjDetTracker
+
+    class Trk(MultiObjDetTracker):
+        IMAGE_H, IMAGE_W = H, W
+        GRID_H, GRID_W = H // 32, W // 32
+        SEQUENCE_LENGTH = T
+        LABELS = [str(i) for i in range(C)]
+        LOAD_MODEL = False
+    blob = synth.synth_darknet_blob(C)
+    tw = synth.synth_tracker_weights(C, seed=seed)
+    return Trk(detector_weights=blob, tracker_weights=tw), blob, tw
+
+
+def test_track_forward_vs_oracle_small(ctx):
+    H, W, T, n_clips, C = 64, 96, 4, 3, 12
+    trk, blob, tw = _tracker(H, W, T, C)
+    layers, _ = orc.parse_darknet_blob(blob, C)
+    frames = np.stack([synth.synth_clip(T, H, W, 2, seed=20 + i) for i in range(n_clips)])
+    got_trk, got_det = trk.model.predict([frames, None])
+    for i in range(n_clips):
+        ref_trk, ref_det = orc.tracker_forward(orc.normalize_u8(frames[i]), layers, tw)
+        assert relerr(got_det[i], ref_det) < 1e-3
+        assert relerr(got_trk[i], ref_trk) < 1e-3
+
+
+def test_track_clips_boxes_and_ids_vs_oracle(ctx):
+    """End to end on device (forward -> decode -> associate) vs the oracle chain;
+    the tracker head is scaled so that boxes exist.  Track ids bit-exact."""
+    H, W, T, n_clips, C = 64, 64, 6, 4, 12
+    trk, blob, tw = _tracker(H, W, T, C)
+    tw = dict(tw)
+    tw["out_kernel"] = tw["out_kernel"] * 40.0
+    ob = tw["out_bias"].copy(); ob[4::17] = 1.5; tw["out_bias"] = ob
+    trk.model.set_weights(tw)
+    trk.OBJ_THRESHOLD, trk.NMS_THRESHOLD, trk.ASSOC_THRESHOLD = 0.3, 0.45, 0.3
+    layers, _ = orc.parse_darknet_blob(blob, C)
+    frames = np.stack([synth.synth_clip(T, H, W, 2, seed=40 + i) for i in range(n_clips)])
+    res = trk.track_clips(frames)
+    cap = res["boxes"].shape[2]
+    total = 0
+    for i in range(n_clips):
+        ref_trk, _ = orc.tracker_forward(orc.normalize_u8(frames[i]), layers, tw)
+        rb = np.zeros((T, cap, 8), dtype=np.float32); rc = np.zeros(T, dtype=np.int32)
+        for t in range(T):
+            rows, _ = orc.decode_netout(ref_trk[t], 0.3, 0.45, ANCHORS, C)
+            rb[t, :len(rows)] = rows; rc[t] = len(rows)
+        assert np.array_equal(res["counts"][i].cpu().numpy(), rc)
+        gb = res["boxes"][i].cpu().numpy()
+        for t in range(T):
+            assert np.array_equal(gb[t, :rc[t], 5], rb[t, :rc[t], 5])
+            assert np.array_equal(gb[t, :rc[t], 7], rb[t, :rc[t], 7])
+            assert np.abs(gb[t, :rc[t], :4] - rb[t, :rc[t], :4]).max(initial=0) < 1e-3
+        rid, rn = orc.associate_clip(rb, rc, 0.3)
+        assert np.array_equal(res["ids"][i].cpu().numpy(), rid), "track ids must be bit-exact"
+        assert int(res["nids"][i]) == rn
+        total += int(rc.sum())
+    assert total > 0, "test is vacuous without boxes"
+
+
+def test_associate_vs_oracle_synthetic(ctx):
+    """Moving boxes with births, deaths, label changes and ties."""
+    rs = np.random.RandomState(3)
+    n_clips, T, cap = 7, 12, 40
+    boxes = np.zeros((n_clips, T, cap, 8), dtype=np.float32)
+    counts = np.zeros((n_clips, T), dtype=np.int32)
+    for c in range(n_clips):
+        n_obj = 5 + 4 * c
+        pos = rs.rand(n_obj, 2); vel = (rs.rand(n_obj, 2) - .5) * .06; wh = rs.rand(n_obj, 2) * .2 + .05
+        lab = rs.randint(0, 3, n_obj)
+        for t in range(T):
+            alive = [k for k in range(n_obj) if rs.rand() > 0.15]
+            rs.shuffle(alive)
+            for i, k in enumerate(alive[:cap]):
+                p = pos[k] + vel[k] * t
+                boxes[c, t, i] = [p[0], p[1], wh[k, 0], wh[k, 1], .9, lab[k] if rs.rand() > .05 else (lab[k] + 1) % 3, .8, i]
+            counts[c, t] = min(len(alive), cap)
+        boxes[c, 3, 1, :4] = boxes[c, 3, 0, :4]      # exact duplicate -> tie on IoU
+    ids, nids = ctx.associate(dev(boxes, ctx), dev(counts, ctx), 0.3)
+    for c in range(n_clips):
+        rid, rn = orc.associate_clip(boxes[c], counts[c], 0.3)
+        assert np.array_equal(ids[c].cpu().numpy(), rid)
+        assert int(nids[c]) == rn
+
+
+# ------------------------------------------------------------------ TinyTracker
+@pytest.mark.parametrize("pool,fh,fw,fc,n_seq,T", [("Global", 26, 26, 512, 5, 6), ("Global", 13, 13, 512, 70, 3),
+                                                    ("Max", 8, 8, 32, 3, 4)])
+def test_tiny_forward_vs_oracle(ctx, pool, fh, fw, fc, n_seq, T):
+    from models_tracking.TinyTracker import TinyTracker
+    feat_dim = fc if pool == "Global" else (fh // 4) * (fw // 4) * fc
+    tw = synth.synth_tiny_weights(feat_dim)
+    cfg = {"model_tracker": {"name": "TinyTracker", "lstm_units": 512, "sequence_length": T},
+           "train": {"pool": pool, "batch_size": 4}}
+    tt = TinyTracker(cfg, feature_dims=(fh, fw, fc), weights=tw, ctx=ctx)
+    rs = np.random.RandomState(11)
+    feat = rs.randn(n_seq, T, fh, fw, fc).astype(np.float32)
+    det = rs.rand(n_seq, T, 4).astype(np.float32)
+    got = tt.model_tracker.predict([feat, det])
+    ref = orc.tinytracker_forward(feat, det, tw, pool=pool)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5)
