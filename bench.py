@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the detect-and-track hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (default `--workload track`, BASELINE.json configs[2], the 1-GPU
+configuration the metric "frames/sec detect+track @416x416" is quoted on):
+per GPU `--clips` MOT17-shaped synthetic clips of T=30 frames, 416x416x3 uint8,
+already resident in HBM; one STEP = one pass of the whole path over that batch:
+  x/255 + YOLOv2 (23 conv, C=12)  ->  ConvLSTM2D(512,3x3) recurrence over T
+  -> 1x1 conv -> decode_netout + NMS for every frame -> track-id association
+  (+ for N>1 the cross-stream all-gather of the detection records).
+`--workload detect` runs BASELINE.json configs[1] instead (YOLOv2 C=80 forward
++ decode, batch 8) -- reported as an extra line item, never as `value`.
+
+Synthetic data: darknet-format random weights (utility/synth.py, seeds
+1234/1235); the tracker's 1x1 head is calibrated once, outside the timed region,
+so that ~32 boxes/frame survive (the "32 tracks" of configs[2]); frames are
+low-frequency backgrounds with moving rectangles.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     -- the fp32 MFMA implicit-GEMM conv kernel family: algorithmic
+                  FLOP / HIP-event time of its launches inside the timed region,
+                  against the 157.3 TFLOP/s fp32 matrix peak of MI355X
+  cpu_baseline -- the CPU oracle ("port") timed on a bounded sample on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import object_tracking_amd  # noqa: F401
+from models_detection.KerasYOLO import KerasYOLO
+from models_tracking.MultiObjDetTracker import MultiObjDetTracker
+from parallel import gather_detections, init_from_env
+from utility import synth
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+GFLOP_TRACK_416 = 39.460          # 29.346 detect (C=12) + 10.099 ConvLSTM + 0.015 1x1
+GFLOP_DETECT_416_C80 = 29.464
+
+
+def make_frames(n_clips, T, H, W, device, seed0):
+    """uint8 [n_clips,T,H,W,3] on the device.  Up to 8 distinct clips are rendered
+    on the host (utility/synth.synth_clip); further clips are spatial rolls of them."""
+    base = [torch.from_numpy(synth.synth_clip(T, H, W, 32, seed=seed0 + i)) for i in range(min(n_clips, 8))]
+    out = torch.empty((n_clips, T, H, W, 3), dtype=torch.uint8, device=device)
+    for i in range(n_clips):
+        src = base[i % len(base)].to(device)
+        if i >= len(base):
+            src = torch.roll(src, shifts=(17 * (i // len(base)), 29 * (i // len(base))), dims=(1, 2))
+        out[i] = src
+    return out
+
+
+def build_tracker(H, W, T, target_boxes, frames_for_calib):
+    class Trk(MultiObjDetTracker):
+        IMAGE_H, IMAGE_W = H, W
+        GRID_H, GRID_W = H // 32, W // 32
+        SEQUENCE_LENGTH = T
+        LOAD_MODEL = False
+
+    C = len(Trk.LABELS)
+    blob = synth.synth_darknet_blob(C, seed=1234)
+    tw = synth.synth_tracker_weights(C, seed=1235)
+    S = 5 + C
+    cls_ch = [b * S + 5 + c for b in range(5) for c in range(C)]
+    obj_ch = [b * S + 4 for b in range(5)]
+    tw["out_kernel"][..., cls_ch] *= 200.0          # peaky class softmax: score ~ objectness
+    tw["out_bias"][obj_ch] = 0.0
+    trk = Trk(detector_weights=blob, tracker_weights=tw)
+    # calibration (untimed): shift the objectness bias so that ~target_boxes cells/frame have t_o > 0
+    netout = trk.model.forward(frames_for_calib, want_det=False)
+    to = netout[..., 4].reshape(netout.shape[0] * netout.shape[1], -1).float()
+    k = max(1, min(to.shape[1] - 1, to.shape[1] - target_boxes))
+    q = torch.kthvalue(to, k, dim=1).values.mean().item()
+    tw["out_bias"][obj_ch] = -q
+    trk.model.set_weights(tw)
+    return trk, blob, tw
+
+
+def cpu_baseline_track(blob, tw, H, W, n_frames):
+    """The CPU oracle ("port" of the Keras graph, not Keras itself -- SURVEY.md
+    section 0.1) on a bounded sample: one clip of n_frames frames through the
+    detector, ConvLSTM, 1x1, decode and association."""
+    from oracle import oracle as orc
+    C = 12
+    layers, _ = orc.parse_darknet_blob(blob, C)
+    frames = synth.synth_clip(n_frames, H, W, 32, seed=999)
+    t0 = time.perf_counter()
+    trk, _ = orc.tracker_forward(orc.normalize_u8(frames), layers, tw)
+    cap = trk.shape[1] * trk.shape[2] * 5
+    rb = np.zeros((n_frames, cap, 8), dtype=np.float32)
+    rc = np.zeros(n_frames, dtype=np.int32)
+    for t in range(n_frames):
+        rows, _ = orc.decode_netout(trk[t], 0.5, 0.45, MultiObjDetTracker.ANCHORS, C)
+        rb[t, :len(rows)] = rows
+        rc[t] = len(rows)
+    orc.associate_clip(rb, rc, 0.3)
+    dt = time.perf_counter() - t0
+    return n_frames / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["track", "detect"], default="track")
+    ap.add_argument("--clips", type=int, default=32, help="clips per GPU per step (track)")
+    ap.add_argument("--T", type=int, default=30)
+    ap.add_argument("--size", type=int, default=416)
+    ap.add_argument("--batch", type=int, default=8, help="frames per step (detect)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=4)
+    args = ap.parse_args()
+
+    rank, world, local = init_from_env()
+    assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    device = torch.device("cuda", torch.cuda.current_device())
+    H = W = args.size
+
+    if args.workload == "track":
+        frames = make_frames(args.clips, args.T, H, W, device, seed0=42 + 100 * rank)
+        trk, blob, tw = build_tracker(H, W, args.T, 32, frames[:min(4, args.clips)].contiguous())
+        ctx = trk.model.ctx
+        frames_per_step = args.clips * args.T
+        gflop_per_frame = GFLOP_TRACK_416 * (H * W) / (416.0 * 416.0)
+
+        def step():
+            res = trk.track_clips(frames, cap=128)
+            if world > 1:
+                res = gather_detections(res)
+            return res
+    else:
+        C = 80
+        blob = synth.synth_darknet_blob(C, seed=1234)
+        det = KerasYOLO({'LABELS': KerasYOLO.LABELS_COCO, 'BATCH_SIZE': args.batch, 'IMAGE_H': H, 'IMAGE_W': W,
+                         'GRID_H': H // 32, 'GRID_W': W // 32}, weights=blob)
+        ctx = det.model.ctx
+        frames = make_frames(1, args.batch, H, W, device, seed0=42 + 100 * rank)[0].contiguous()
+        frames_per_step = args.batch
+        gflop_per_frame = GFLOP_DETECT_416_C80 * (H * W) / (416.0 * 416.0)
+        tw = None
+
+        def step():
+            return det.detect(frames)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    sync_all()
+    ctx.profile_reset()
+    ctx.profile_enable(True)          # HIP events around every launch, on the launch stream
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kern = {}
+    for name in ("conv_igemm", "conv1_direct", "convlstm_gates", "decode_nms", "associate", "misc"):
+        p = ctx.profile_read(name)
+        if p["launches"]:
+            kern[name] = dict(launches=p["launches"], ms_per_step=p["ms"] / args.steps,
+                              tflops=(p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["ms"] > 0 else None,
+                              gbs=(p["bytes"] / (p["ms"] * 1e-3) / 1e9) if p["ms"] > 0 else None)
+    ig = ctx.profile_read("conv_igemm")
+    achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+    boxes_per_frame = None
+    if args.workload == "track" and res is not None:
+        boxes_per_frame = float(res["counts"].float().mean().item())
+
+    if rank == 0:
+        total_frames = frames_per_step * world * args.steps
+        fps = total_frames / elapsed
+        out = {
+            "metric": "frames/sec detect+track @416x416" if args.workload == "track" else "frames/sec detect @416x416",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("BASELINE.json configs[2]: MultiObjDetTracker (YOLOv2 C=12 + ConvLSTM2D(512) + 1x1 "
+                                    "+ decode/NMS + track ids), %d clips x %d frames per GPU per step, %dx%d uint8"
+                                    % (args.clips, args.T, H, W)) if args.workload == "track" else
+                       ("BASELINE.json configs[1]: YOLOv2 C=80 forward + decode/NMS, batch %d, %dx%d uint8"
+                        % (args.batch, H, W)),
+                       "frames_per_step_per_gpu": frames_per_step, "parallelism": "clip-shard x%d" % world,
+                       "gflop_per_frame": gflop_per_frame, "boxes_per_frame": boxes_per_frame},
+            "whole_path_tflops": fps * gflop_per_frame / 1e3,
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32 implicit GEMM)",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "launches_per_step": ig["launches"] / max(1, args.steps),
+                         "avg_launch_ms": ig["ms"] / max(1, ig["launches"])},
+            "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline and args.workload == "track":
+            from oracle import oracle as orc
+            orc.lib()
+            cpu_fps, cpu_s = cpu_baseline_track(blob, tw, H, W, args.cpu_frames)
+            out["cpu_baseline"] = {"value": cpu_fps, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": "CPU restatement (oracle/, C + OpenMP; NOT Keras/TF, which cannot run "
+                                             "here): 1 clip x %d frames %dx%d through detector+ConvLSTM+1x1+decode+"
+                                             "association, %.1f s" % (args.cpu_frames, H, W, cpu_s)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -220,8 +220,11 @@ def test_detector_full_size_one_frame_vs_oracle(ctx):
     r = det.model.ctx.decode(dev(boost, det.model.ctx), 0.3, 0.45, ANCHORS, 80)
     n = int(r["counts"][0])
     got = r["boxes"][0, :n].cpu().numpy()
-    if len(rows) == n and n > 0 and np.array_equal(got[:, 7], rows[:, 7]):
-        assert np.abs(got[:, :4] - rows[:, :4]).max() < 1e-3
+    assert n > 0
+    if len(rows) == n and np.array_equal(got[:, 7], rows[:, 7]):
+        # x,y in [0,1]; w,h = anchor*exp(t)/G are unbounded -> relative bar for those
+        assert np.abs(got[:, :2] - rows[:, :2]).max() < 1e-3
+        assert (np.abs(got[:, 2:4] - rows[:, 2:4]) / np.maximum(1.0, np.abs(rows[:, 2:4]))).max() < 1e-3
 
 
 def test_detector_batch_invariance_full_size(ctx):
