@@ -124,7 +124,8 @@ def main():
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--batch", type=int, default=8, help="frames per step (detect)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--cpu-frames", type=int, default=30)
+    ap.add_argument("--layer-report", default=None, help="write a per-layer table (HIP-event times) to this file")
     args = ap.parse_args()
 
     rank, world, local = init_from_env()
@@ -135,7 +136,7 @@ def main():
 
     if args.workload == "track":
         frames = make_frames(args.clips, args.T, H, W, device, seed0=42 + 100 * rank)
-        trk, blob, tw = build_tracker(H, W, args.T, 32, frames[:min(4, args.clips)].contiguous())
+        trk, blob, tw = build_tracker(H, W, args.T, 32, frames)
         ctx = trk.model.ctx
         frames_per_step = args.clips * args.T
         gflop_per_frame = GFLOP_TRACK_416 * (H * W) / (416.0 * 416.0)
@@ -196,6 +197,17 @@ def main():
     if args.workload == "track" and res is not None:
         boxes_per_frame = float(res["counts"].float().mean().item())
 
+    if rank == 0 and args.layer_report:
+        with open(args.layer_report, "w") as f:
+            f.write("# per-layer HIP-event times inside the timed region (%d steps); algorithmic FLOP / bytes\n" % args.steps)
+            f.write("%-32s %8s %12s %10s %10s\n" % ("name", "launches", "ms/step", "TFLOP/s", "GB/s(alg)"))
+            for name in sorted(ctx.profile_names()):
+                p = ctx.profile_read(name)
+                if p["ms"] <= 0:
+                    continue
+                f.write("%-32s %8d %12.4f %10.2f %10.1f\n" % (name, p["launches"], p["ms"] / args.steps,
+                                                            p["flops"] / (p["ms"] * 1e-3) / 1e12,
+                                                            p["bytes"] / (p["ms"] * 1e-3) / 1e9))
     if rank == 0:
         total_frames = frames_per_step * world * args.steps
         fps = total_frames / elapsed

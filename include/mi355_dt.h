@@ -156,9 +156,12 @@ DT_API int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int W, 
  * stream.  dt_profile_read synchronises the stream and returns, per kernel
  * family, launches / total ms / algorithmic flops / algorithmic bytes since the
  * last reset.  names: "conv_igemm", "conv1_direct", "convlstm_gates",
- * "decode_nms", "associate", "lstm_step", "pool", "misc". */
+ * "decode_nms", "associate", "lstm_step", "pool", "misc"; per-layer tags such as
+ * "conv_igemm:conv_19", "conv_igemm:convlstm_step" are listed by dt_profile_names. */
 DT_API int dt_profile_enable(dt_ctx *ctx, int on);
 DT_API int dt_profile_reset(dt_ctx *ctx);
+/* newline-separated list of every name with data (families and "family:layer" tags) */
+DT_API int dt_profile_names(dt_ctx *ctx, char *buf, size_t buflen);
 DT_API int dt_profile_read(dt_ctx *ctx, const char *name, int64_t *launches,
                     double *total_ms, double *flops, double *bytes);
 

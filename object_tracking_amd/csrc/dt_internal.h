@@ -100,7 +100,7 @@ struct ProfEntry {
 
 struct PendingEvent {
     hipEvent_t a, b;
-    std::string name;
+    std::string name, tag;
 };
 
 struct DevBuf {
@@ -161,6 +161,6 @@ struct ProfScope {
     dt_ctx *ctx;
     PendingEvent ev;
     bool on;
-    ProfScope(dt_ctx *c, const char *name, double flops, double bytes);
+    ProfScope(dt_ctx *c, const char *name, double flops, double bytes, const char *tag = nullptr);
     ~ProfScope();
 };

@@ -56,16 +56,24 @@ float *ws_get(dt_ctx *ctx, const char *name, size_t bytes, bool zero_on_grow)
     return static_cast<float *>(b.p);
 }
 
-ProfScope::ProfScope(dt_ctx *c, const char *name, double flops, double bytes) : ctx(c), on(c->prof)
+ProfScope::ProfScope(dt_ctx *c, const char *name, double flops, double bytes, const char *tag)
+    : ctx(c), on(c->prof)
 {
     if (!on) return;
     ev.name = name;
+    if (tag) ev.tag = std::string(name) + ":" + tag;
     (void)hipEventCreate(&ev.a);
     (void)hipEventCreate(&ev.b);
     ProfEntry &e = ctx->prof_tab[name];
     e.launches += 1;
     e.flops += flops;
     e.bytes += bytes;
+    if (tag) {
+        ProfEntry &t = ctx->prof_tab[ev.tag];
+        t.launches += 1;
+        t.flops += flops;
+        t.bytes += bytes;
+    }
     (void)hipEventRecord(ev.a, ctx->stream);
 }
 ProfScope::~ProfScope()
@@ -261,7 +269,9 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
     const double flops = 2.0 * a.M * (double)a.K * L.cout;
     const double bytes = 4.0 * ((double)a.M * L.cin + (double)a.K * L.cout +
                                 (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0));
-    ProfScope ps(ctx, "conv_igemm", flops, bytes);
+    char tag[32];
+    snprintf(tag, sizeof(tag), L.idx == 102 ? "tconv_2" : "conv_%d", L.idx);
+    ProfScope ps(ctx, "conv_igemm", flops, bytes, tag);
     const int rc = launch_conv_igemm(ctx->stream, a, L.ks, order, epi, cfg);
     if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "conv_%d launch failed (rc=%d)", L.idx, rc);
     return DT_OK;
@@ -462,7 +472,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
         a.B = F; a.H = gh; a.W = gw; a.Cin = Cx; a.N = N4; a.M = F * GG; a.K = 9 * Cx;
         a.slope = 1.0f;
         ProfScope ps(ctx, "conv_igemm", 2.0 * a.M * 9.0 * (ctx->cb + 1024) * N4,
-                     4.0 * ((double)a.M * Cx + (double)a.K * N4 + (double)a.M * N4));
+                     4.0 * ((double)a.M * Cx + (double)a.K * N4 + (double)a.M * N4), "convlstm_xproj");
         if (launch_conv_igemm(ctx->stream, a, 3, ORD_LINEAR, EPI_PLAIN, CFG_128x128))
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM input projection launch failed");
     }
@@ -483,7 +493,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
         a.B = n_clips; a.H = gh; a.W = gw; a.Cin = U; a.N = N4; a.M = n_clips * GG; a.K = 9 * U;
         a.slope = 1.0f;
         ProfScope ps(ctx, "conv_igemm", 2.0 * a.M * (double)a.K * N4,
-                     4.0 * ((double)a.M * U + (double)a.K * N4 + (double)a.M * N4 + 3.0 * a.M * U));
+                     4.0 * ((double)a.M * U + (double)a.K * N4 + (double)a.M * N4 + 3.0 * a.M * U), "convlstm_step");
         if (launch_conv_igemm(ctx->stream, a, 3, ORD_LINEAR, EPI_GATES, CFG_128x128))
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM step launch failed");
     }
@@ -585,7 +595,8 @@ extern "C" int dt_tiny_forward(dt_ctx *ctx, const float *d_feat, const float *d_
         a.out = xproj; a.out_ld = N4; a.out_bs = N4;
         a.B = R; a.H = 1; a.W = 1; a.Cin = Dp; a.N = N4; a.M = R; a.K = Dp;
         a.slope = 1.0f;
-        ProfScope ps(ctx, "conv_igemm", 2.0 * R * (double)D * N4, 4.0 * ((double)R * Dp + (double)Dp * N4 + (double)R * N4));
+        ProfScope ps(ctx, "conv_igemm", 2.0 * R * (double)D * N4, 4.0 * ((double)R * Dp + (double)Dp * N4 + (double)R * N4),
+                     "lstm_xproj");
         if (launch_conv_igemm(ctx->stream, a, 1, ORD_LINEAR, EPI_PLAIN, CFG_128x128))
             return dt_fail(ctx, DT_ERR_DEVICE, "LSTM input projection launch failed");
     }
@@ -685,7 +696,10 @@ static void prof_drain(dt_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &e : ctx->pending) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) ctx->prof_tab[e.name].ms += ms;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            ctx->prof_tab[e.name].ms += ms;
+            if (!e.tag.empty()) ctx->prof_tab[e.tag].ms += ms;
+        }
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
@@ -705,6 +719,17 @@ extern "C" int dt_profile_reset(dt_ctx *ctx)
     if (!ctx) return DT_ERR_ARG;
     prof_drain(ctx);
     ctx->prof_tab.clear();
+    return DT_OK;
+}
+
+extern "C" int dt_profile_names(dt_ctx *ctx, char *buf, size_t buflen)
+{
+    if (!ctx || !buf || !buflen) return DT_ERR_ARG;
+    prof_drain(ctx);
+    std::string all;
+    for (auto &kv : ctx->prof_tab) { all += kv.first; all += "\n"; }
+    if (all.size() + 1 > buflen) return dt_fail(ctx, DT_ERR_ARG, "dt_profile_names: buffer too small (%zu needed)", all.size() + 1);
+    memcpy(buf, all.c_str(), all.size() + 1);
     return DT_OK;
 }
 

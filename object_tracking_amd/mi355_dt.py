@@ -25,7 +25,7 @@ SYMBOLS = [
     "dt_detector_config", "dt_load_darknet_weights", "dt_detect_forward", "dt_detector_tap",
     "dt_decode", "dt_bbox_iou", "dt_tracker_load", "dt_track_forward", "dt_associate",
     "dt_tiny_load", "dt_tiny_forward", "dt_conv2d", "dt_convlstm_step",
-    "dt_profile_enable", "dt_profile_reset", "dt_profile_read",
+    "dt_profile_enable", "dt_profile_reset", "dt_profile_read", "dt_profile_names",
 ]
 
 _lib = None
@@ -68,6 +68,7 @@ def load_library():
     L.dt_convlstm_step.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]
     L.dt_profile_enable.argtypes = [vp, ci]
     L.dt_profile_reset.argtypes = [vp]
+    L.dt_profile_names.argtypes = [vp, ctypes.c_char_p, csz]
     L.dt_profile_read.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64),
                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                   ctypes.POINTER(ctypes.c_double)]
@@ -301,6 +302,11 @@ class Context(object):
 
     def profile_reset(self):
         self._check(self.lib.dt_profile_reset(self.h), "dt_profile_reset")
+
+    def profile_names(self):
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._check(self.lib.dt_profile_names(self.h, buf, len(buf)), "dt_profile_names")
+        return [n for n in buf.value.decode().split("\n") if n]
 
     def profile_read(self, name):
         n = ctypes.c_int64(0)

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): GPU test suite, default bench line + per-layer
+# table, rocprofv3 kernel stats of the same bench command, PMC passes (FETCH_SIZE,
+# WRITE_SIZE separately; --kernel-trace only).  Outputs land in gpurun_out/<tag>/.
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r01}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+if [ "${SKIP_TESTS:-0}" != "1" ]; then
+  timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/pytest_gpu.txt
+fi
+timeout 600 python bench.py --layer-report $O/bench_layers.txt 2>$O/bench.err | tail -1 | tee $O/bench.json
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_stats.log 2>&1
+tail -1 $O/prof_stats.log
+python $R/tools/rocprof_summary.py stats $O/prof_stats > $O/rocprof_kernel_stats.txt 2>&1
+head -12 $O/rocprof_kernel_stats.txt
+if [ "${SKIP_PMC:-0}" != "1" ]; then
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_$C -o pmc -- python $R/tools/pmc_probe.py 32 > $O/pmc_$C.log 2>&1
+    tail -1 $O/pmc_$C.log
+    python $R/tools/rocprof_summary.py pmc $O/pmc_$C $C > $O/rocprof_pmc_$C.txt 2>&1
+    head -8 $O/rocprof_pmc_$C.txt
+  done
+fi
+# keep the merged payload small: drop raw per-dispatch CSVs above 20 MB
+find $O -name "*.csv" -size +20M -delete
+du -sh $O
