@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["track", "detect"], default="track")
-    ap.add_argument("--clips", type=int, default=32, help="clips per GPU per step (track)")
+    ap.add_argument("--clips", type=int, default=48, help="clips per GPU per step (track)")
     ap.add_argument("--T", type=int, default=30)
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--batch", type=int, default=8, help="frames per step (detect)")

@@ -29,6 +29,8 @@
 //   * EPI_GATES: the N axis is packed [j/32][gate][j%32]; a wave's four 32-wide
 //     column tiles are the i,f,c,o pre-activations of the same 32 hidden
 //     channels, so the LSTM cell update happens in registers.
+#include <cstdlib>
+
 #include "dt_internal.h"
 
 #define LDK 36  // LDS row stride in floats (32 + 4 pad)
@@ -80,12 +82,20 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
     const int wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
-    // XCD-aware tile order: blocks that share an A row-panel (same m-tile) are
-    // consecutive in blockIdx.x, i.e. spread over the 8 XCDs; weights (B) are
-    // small enough to live in every L2.  Grid: x = n-tiles fastest.
+    // XCD-aware tile order.  Workgroup b is dispatched to XCD b % 8 (observed; used
+    // for speed only).  Tiles are numbered n-fastest, and each XCD is given one
+    // CONTIGUOUS range of tile numbers, so the ntn column tiles that re-read the
+    // same activation rows (and neighbouring row panels that share the 3x3 halo)
+    // hit the same 4 MiB L2 instead of being fetched by all eight.
     const int ntn = (p.N + BN - 1) / BN;
-    const int tile_n = blockIdx.x % ntn;
-    const int tile_m = blockIdx.x / ntn;
+    int bid = blockIdx.x;
+    if (p.xcd_remap) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;   // bijective for any nwg
+    }
+    const int tile_n = bid % ntn;
+    const int tile_m = bid / ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- loader set-up ----------------------------------------------------
@@ -131,9 +141,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
             aoff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.in_ld + cc * 32;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((a_mask[i] >> tap) & 1u) v = *reinterpret_cast<const f32x4 *>(a_ptr[i] + aoff);
-            ra[i] = v;
+            // branch-free 'same' padding: out-of-image taps read a 16-byte block of zeros
+            const bool ok = (a_mask[i] >> tap) & 1u;
+            const float *src = ok ? a_ptr[i] + aoff : p.zeros;
+            ra[i] = *reinterpret_cast<const f32x4 *>(src);
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(b_ptr[i] + kc * 32);
@@ -156,41 +167,71 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // ---- main loop ----------------------------------------------------------
-    gload(0, 0, 0);
-    lstore(0);
-    __syncthreads();
-
+    // Rotated software pipeline, one barrier per 32-deep K chunk:
+    //   MFMA(kk=0) || read frags kk=1, write chunk t+1 to the other LDS buffer
+    //   MFMA(kk=1) || read frags kk=2, issue global loads of chunk t+2
+    //   MFMA(kk=2) || read frags kk=3
+    //   barrier
+    //   MFMA(kk=3) || read frags kk=0 of chunk t+1
+    // so LDS/global instructions always issue under a queue of 16 independent
+    // 64-cycle MFMAs and the matrix pipe only idles for barrier skew.
     const int fr = lane & 31;          // fragment row within a 32-row tile
     const int fk = (lane >> 5) * 4;    // k sub-slot: lanes 0-31 -> 0..3, 32-63 -> 4..7
-    int tap = 0, cc = 0;
+    struct Frag {
+        f32x4 a[TM], b[TN];
+    };
+    auto lfrag = [&](Frag &f, int buf, int kk) {
+        const float *cA = sA + (buf * BM + wm * WTM + fr) * LDK + fk + kk * 8;
+        const float *cB = sB + (buf * BN + wn * WTN + fr) * LDK + fk + kk * 8;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const f32x4 *>(cA + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const f32x4 *>(cB + j * 32 * LDK);
+    };
+    auto mma = [&](const Frag &f) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
+    };
+
+    int gtap = 0, gcc = 0;             // (tap, chunk) of the NEXT tile to fetch from global memory
+    auto gadvance = [&]() {
+        if (++gcc == cpt) { gcc = 0; ++gtap; }
+    };
+    gload(0, 0, 0);
+    gadvance();
+    lstore(0);
+    if (nk > 1) { gload(gtap, gcc, 1); gadvance(); }
+    __syncthreads();
+    Frag f0, f1;
+    lfrag(f0, 0, 0);
+    // The body is branch-free so that the scheduler can interleave it with the MFMAs:
+    // past the end of K the loads re-read the last chunk and the LDS traffic goes to
+    // the buffer nobody reads again.
+    const int last_tap = TAPS - 1, last_cc = cpt - 1;
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
-        int ntap = tap, ncc = cc + 1;
-        if (ncc == cpt) { ncc = 0; ntap = tap + 1; }
-        const bool more = (kc + 1) < nk;
-        if (more) gload(ntap, ncc, kc + 1);
-
-        const float *cA = sA + (cur * BM + wm * WTM + fr) * LDK + fk;
-        const float *cB = sB + (cur * BN + wn * WTN + fr) * LDK + fk;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            f32x4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(cA + i * 32 * LDK + kk * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(cB + j * 32 * LDK + kk * 8);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        lfrag(f1, cur, 1);
+        lstore(cur ^ 1);                                // chunk kc+1 (in registers since last iteration)
+        mma(f0);
+        lfrag(f0, cur, 2);
+        {
+            const bool in = gtap < TAPS;
+            gload(in ? gtap : last_tap, in ? gcc : last_cc, in ? kc + 2 : nk - 1);
+            gadvance();
         }
-        if (more) lstore(cur ^ 1);
+        mma(f1);
+        lfrag(f1, cur, 3);
+        mma(f0);
         __syncthreads();
-        tap = ntap;
-        cc = ncc;
+        __builtin_amdgcn_sched_barrier(0);   // keep the kk=3 MFMAs BELOW the barrier: they cover the reads that follow it
+        lfrag(f0, cur ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);   // ...and keep those reads ABOVE them
+        mma(f1);
     }
 
     // ---- epilogue -----------------------------------------------------------
@@ -287,11 +328,23 @@ template <int KS, int ORDER, int EPI>
 static int launch_cfg(hipStream_t st, const ConvArgs &a, int cfg)
 {
     if (cfg == CFG_128x64) return launch_one<KS, 128, 64, 4, 1, ORDER, EPI>(st, a);
+    if (cfg == CFG_256x128) return launch_one<KS, 256, 128, 4, 1, ORDER, EPI>(st, a);
     return launch_one<KS, 128, 128, 2, 2, ORDER, EPI>(st, a);
 }
 
-int launch_conv_igemm(hipStream_t st, const ConvArgs &a, int ks, int order, int epi, int cfg)
+int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, int epi, int cfg)
 {
+    ConvArgs a = a_in;
+    static const int remap_env = [] { const char *e = getenv("DT_XCD_REMAP"); return e ? atoi(e) : 1; }();
+    a.xcd_remap = remap_env;
+    static const int cfg_env = [] { const char *e = getenv("DT_CONV_CFG"); return e ? atoi(e) : -1; }();
+    if (cfg_env >= 0 && cfg == CFG_128x128) cfg = cfg_env;   // A/B experiments
+    static float *zeros_dev = nullptr;   // process-wide 256 B of zeros for the padding taps
+    if (!zeros_dev) {
+        if (hipMalloc(reinterpret_cast<void **>(&zeros_dev), 256) != hipSuccess) return 1;
+        if (hipMemset(zeros_dev, 0, 256) != hipSuccess) return 1;
+    }
+    a.zeros = zeros_dev;
     if (a.Cin % 32 != 0 || a.K != ks * ks * a.Cin) return 2;
     if (epi == EPI_GATES) {
         if (order != ORD_LINEAR) return 2;

@@ -44,10 +44,12 @@ struct ConvArgs {
     int c_ld;
     int B, H, W, Cin, N, M, K;
     float slope;  // LeakyReLU slope; 1.0f = linear
+    const float *zeros; // >= 16 B of device zeros: source of out-of-image taps (set by launch_conv_igemm)
+    int xcd_remap; // 1: give each XCD a contiguous range of tiles (set by launch_conv_igemm)
 };
 
 // Tile configurations of the MFMA kernel
-enum { CFG_128x128 = 0, CFG_128x64 = 1 };
+enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_256x128 = 2 };
 
 int launch_conv_igemm(hipStream_t st, const ConvArgs &a, int ks, int order, int epi, int cfg);
 

@@ -19,7 +19,7 @@ python $R/tools/rocprof_summary.py stats $O/prof_stats > $O/rocprof_kernel_stats
 head -12 $O/rocprof_kernel_stats.txt
 if [ "${SKIP_PMC:-0}" != "1" ]; then
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_$C -o pmc -- python $R/tools/pmc_probe.py 32 > $O/pmc_$C.log 2>&1
+    timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_$C -o pmc -- python $R/tools/pmc_probe.py 48 > $O/pmc_$C.log 2>&1
     tail -1 $O/pmc_$C.log
     python $R/tools/rocprof_summary.py pmc $O/pmc_$C $C > $O/rocprof_pmc_$C.txt 2>&1
     head -8 $O/rocprof_pmc_$C.txt

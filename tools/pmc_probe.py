@@ -13,7 +13,7 @@ import torch
 
 import bench
 
-clips = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+clips = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 dev = torch.device("cuda", 0)
 a = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
 b = torch.empty_like(a)
