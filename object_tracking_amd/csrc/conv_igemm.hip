@@ -130,7 +130,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
     for (int i = 0; i < PB; ++i) b_ptr[i] = p.wt + (long long)(n0 + lr + 32 * i) * p.K + lc;
 
     const int cpt = p.Cin >> 5;     // 32-float chunks per tap
-    const int nk = TAPS * cpt;
+    // split-K: blockIdx.y owns chunks [k0, k0+nk) of the TAPS*cpt chunks of K
+    const int nk_all = TAPS * cpt;
+    const int k0 = (int)(((long long)nk_all * blockIdx.y) / gridDim.y);
+    const int nk = (int)(((long long)nk_all * (blockIdx.y + 1)) / gridDim.y) - k0;
 
     f32x4 ra[PA], rb[PB];
     auto gload = [&](int tap, int cc, int kc) {
@@ -198,21 +201,24 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
     };
 
-    int gtap = 0, gcc = 0;             // (tap, chunk) of the NEXT tile to fetch from global memory
+    int gtap = k0 / cpt, gcc = k0 % cpt;   // (tap, chunk) of the NEXT tile to fetch from global memory
+    int gk = k0;                           // its absolute chunk index (B column offset)
+    const int k_end = k0 + nk;
     auto gadvance = [&]() {
+        ++gk;
         if (++gcc == cpt) { gcc = 0; ++gtap; }
     };
-    gload(0, 0, 0);
+    gload(gtap, gcc, gk);
     gadvance();
     lstore(0);
-    if (nk > 1) { gload(gtap, gcc, 1); gadvance(); }
+    if (nk > 1) { gload(gtap, gcc, gk); gadvance(); }
     __syncthreads();
     Frag f0, f1;
     lfrag(f0, 0, 0);
     // The body is branch-free so that the scheduler can interleave it with the MFMAs:
     // past the end of K the loads re-read the last chunk and the LDS traffic goes to
     // the buffer nobody reads again.
-    const int last_tap = TAPS - 1, last_cc = cpt - 1;
+    const int last_tap = (k_end - 1) / cpt, last_cc = (k_end - 1) % cpt;
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
         lfrag(f1, cur, 1);
@@ -220,8 +226,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
         mma(f0);
         lfrag(f0, cur, 2);
         {
-            const bool in = gtap < TAPS;
-            gload(in ? gtap : last_tap, in ? gcc : last_cc, in ? kc + 2 : nk - 1);
+            const bool in = gk < k_end;
+            gload(in ? gtap : last_tap, in ? gcc : last_cc, in ? gk : k_end - 1);
             gadvance();
         }
         mma(f1);
@@ -279,7 +285,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = leaky_act(acc[i][j][4 * g + q] + bv, p.slope);
                 if (!cok || rbase >= p.M) continue;
-                if (EPI == EPI_PLAIN) {
+                if (EPI == EPI_PARTIAL) {
+                    // split-K partial sums: raw accumulators to slab [split][M][N]
+                    float *slab = p.out + (long long)blockIdx.y * p.M * p.out_ld;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (rbase + q < p.M) slab[(long long)(rbase + q) * p.out_ld + col] = acc[i][j][4 * g + q];
+                } else if (EPI == EPI_PLAIN) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (rbase + q < p.M) p.out[(long long)(rbase + q) * p.out_ld + col] = v[q];
@@ -308,7 +320,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
 }
 
 template <int KS, int BM, int BN, int WGM, int WGN, int ORDER, int EPI>
-static int launch_one(hipStream_t st, const ConvArgs &a)
+static int launch_one(hipStream_t st, const ConvArgs &a, int ksplit = 1)
 {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
@@ -320,7 +332,7 @@ static int launch_one(hipStream_t st, const ConvArgs &a)
             return 1;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ntn)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ntn), (unsigned)ksplit), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -351,6 +363,11 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
         if (ks == 3) return launch_one<3, 128, 128, 4, 1, ORD_LINEAR, EPI_GATES>(st, a);
         return launch_one<1, 128, 128, 4, 1, ORD_LINEAR, EPI_GATES>(st, a);
     }
+    if (epi == EPI_PARTIAL) {
+        if (order != ORD_LINEAR || a.ksplit < 1) return 2;
+        return ks == 3 ? launch_one<3, 128, 128, 2, 2, ORD_LINEAR, EPI_PARTIAL>(st, a, a.ksplit)
+                       : launch_one<1, 128, 128, 2, 2, ORD_LINEAR, EPI_PARTIAL>(st, a, a.ksplit);
+    }
     if (order == ORD_LINEAR) {
         if (epi != EPI_PLAIN) return 2;
         return ks == 3 ? launch_cfg<3, ORD_LINEAR, EPI_PLAIN>(st, a, cfg) : launch_cfg<1, ORD_LINEAR, EPI_PLAIN>(st, a, cfg);
@@ -366,6 +383,34 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
     default:
         return 2;
     }
+}
+
+// split-K combine: out[row][col] = act(sum_s slab[s][row][col] + bias[col]); the
+// sum runs in split order, so the result is deterministic.
+__global__ void splitk_reduce_kernel(const float *slab, int S, long long M, int N, const float *bias, float slope,
+                                     float *out, int out_ld)
+{
+    const long long total = M * N;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long row = e / N;
+        const int col = (int)(e - row * N);
+        float v = slab[e];
+        for (int s = 1; s < S; ++s) v += slab[(long long)s * total + e];
+        v += bias ? bias[col] : 0.0f;
+        out[row * out_ld + col] = leaky_act(v, slope);
+    }
+}
+
+int launch_splitk_reduce(hipStream_t st, const float *slab, int S, long long M, int N, const float *bias, float slope,
+                         float *out, int out_ld)
+{
+    const long long total = M * N;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slab, S, M, N, bias, slope, out,
+                       out_ld);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 void pack_conv_weights(const float *hwio, int ks, int cin_src, int cout_src, const int *cin_map, int cin_dst,

@@ -18,7 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // implicit-GEMM convolution (conv_igemm.hip)
 // ---------------------------------------------------------------------------
 enum { ORD_LINEAR = 0, ORD_QUAD = 1 };
-enum { EPI_PLAIN = 0, EPI_POOL = 1, EPI_POOL_BOTH = 2, EPI_S2D = 3, EPI_GATES = 4 };
+enum { EPI_PLAIN = 0, EPI_POOL = 1, EPI_POOL_BOTH = 2, EPI_S2D = 3, EPI_GATES = 4, EPI_PARTIAL = 5 };
 
 struct ConvArgs {
     // input activation: pixel (b,h,w) at in + b*in_bs + (h*W+w)*in_ld, Cin floats read
@@ -45,6 +45,7 @@ struct ConvArgs {
     int B, H, W, Cin, N, M, K;
     float slope;  // LeakyReLU slope; 1.0f = linear
     const float *zeros; // >= 16 B of device zeros: source of out-of-image taps (set by launch_conv_igemm)
+    int ksplit;    // EPI_PARTIAL: number of K splits (grid.y); out = slab [ksplit][M][out_ld]
     int xcd_remap; // 1: give each XCD a contiguous range of tiles (set by launch_conv_igemm)
 };
 
@@ -52,6 +53,8 @@ struct ConvArgs {
 enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_256x128 = 2 };
 
 int launch_conv_igemm(hipStream_t st, const ConvArgs &a, int ks, int order, int epi, int cfg);
+int launch_splitk_reduce(hipStream_t st, const float *slab, int S, long long M, int N, const float *bias, float slope,
+                         float *out, int out_ld);
 
 // host-side packing: Keras HWIO kernel -> [npad][ks*ks*cin_dst], k contiguous.
 //   cin_map[cin_dst]: source input channel or -1 (zero);  n_map[npad]: source

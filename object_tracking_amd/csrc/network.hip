@@ -5,6 +5,7 @@
 //   tiny      models_tracking/TinyTracker.py:25-41
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 #include "dt_internal.h"
@@ -271,6 +272,36 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
                                 (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0));
     char tag[32];
     snprintf(tag, sizeof(tag), L.idx == 102 ? "tconv_2" : "conv_%d", L.idx);
+    // Small-M layers (few frames at 13x13/26x26) cannot fill 256 CUs with output tiles:
+    // split K over grid.y into a slab and combine deterministically.
+    int ksplit = 1;
+    if (epi == EPI_PLAIN && order == ORD_LINEAR && cfg == CFG_128x128) {
+        const int tiles = ((a.M + 127) / 128) * ((L.cout + 127) / 128);
+        const int nk = a.K / 32;
+        if (tiles < 384) {
+            ksplit = (512 + tiles - 1) / tiles;
+            if (ksplit > nk / 6) ksplit = nk / 6;       // keep >= 6 chunks (192 of K) per split
+            if (ksplit > 32) ksplit = 32;
+            if (ksplit < 1) ksplit = 1;
+        }
+        static const int ks_env = [] { const char *e = getenv("DT_KSPLIT"); return e ? atoi(e) : 0; }();
+        if (ks_env > 0) ksplit = ks_env < nk ? ks_env : nk;
+    }
+    if (ksplit > 1) {
+        float *slab = ws_get(ctx, "splitk", (size_t)ksplit * a.M * L.cout * sizeof(float));
+        if (!slab) return DT_ERR_DEVICE;
+        ConvArgs b = a;
+        b.out = slab; b.out_ld = L.cout; b.ksplit = ksplit; b.bias = nullptr;
+        {
+            ProfScope ps(ctx, "conv_igemm", flops, bytes + 4.0 * ksplit * a.M * (double)L.cout, tag);
+            const int rc = launch_conv_igemm(ctx->stream, b, L.ks, ORD_LINEAR, EPI_PARTIAL, CFG_128x128);
+            if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "conv_%d split-K launch failed (rc=%d)", L.idx, rc);
+        }
+        ProfScope ps2(ctx, "splitk_reduce", 0.0, 4.0 * (ksplit + 1.0) * a.M * (double)L.cout, tag);
+        if (launch_splitk_reduce(ctx->stream, slab, ksplit, a.M, L.cout, L.bias, slope, out, out_ld))
+            return dt_fail(ctx, DT_ERR_DEVICE, "conv_%d split-K reduce launch failed", L.idx);
+        return DT_OK;
+    }
     ProfScope ps(ctx, "conv_igemm", flops, bytes, tag);
     const int rc = launch_conv_igemm(ctx->stream, a, L.ks, order, epi, cfg);
     if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "conv_%d launch failed (rc=%d)", L.idx, rc);

@@ -236,15 +236,36 @@ def test_detector_full_size_one_frame_vs_oracle(ctx):
 
 
 def test_detector_batch_invariance_full_size(ctx):
-    """A frame's output must not depend on its position in the batch (bit-exact)."""
+    """A frame's output must not depend on WHERE it sits in the batch or on its
+    neighbours (bit-exact for a given batch size), and must be reproducible run to
+    run.  Across different batch sizes the split-K factor of the small-M layers
+    changes the fp32 summation order, so only closeness is required there."""
     det, _, _ = _detector(ctx, 416, 416, 12)
     frames = np.concatenate([synth.synth_clip(3, 416, 416, 2, seed=s) for s in (1, 2)])
     d = dev(frames, det.model.ctx)
     full = det.model.ctx.detect_forward(d)
-    single = det.model.ctx.detect_forward(d[4:5].contiguous())
-    assert torch.equal(single[0], full[4])
+    perm = [4, 0, 5, 2, 1, 3]
+    shuffled = det.model.ctx.detect_forward(d[perm].contiguous())
+    assert torch.equal(shuffled, full[perm]), "position / neighbour independence"
     again = det.model.ctx.detect_forward(d)
     assert torch.equal(again, full), "run-to-run determinism"
+    single = det.model.ctx.detect_forward(d[4:5].contiguous())
+    assert relerr(single[0].cpu().numpy(), full[4].cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("ks,Cin,Cout,M_hw,B", [(3, 512, 1024, 13, 1), (3, 1024, 1024, 13, 2), (1, 1024, 512, 13, 1),
+                                                (1, 1024, 85, 13, 3)])
+def test_conv2d_split_k_path(ctx, ks, Cin, Cout, M_hw, B):
+    """deep 13x13 layers at tiny batch take the split-K + deterministic combine path"""
+    rs = np.random.RandomState(ks * 100 + B)
+    x = rs.randn(B, M_hw, M_hw, Cin).astype(np.float32)
+    w = (rs.randn(ks, ks, Cin, Cout) * np.sqrt(2.0 / (ks * ks * Cin))).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32)
+    ref = orc.conv2d(x, w, b)
+    ref = np.where(ref > 0, ref, 0.1 * ref).astype(np.float32)
+    got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=0)
+    assert relerr(got.cpu().numpy(), ref) < 2e-5
+    assert torch.equal(ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=0), got)
 
 
 # ------------------------------------------------------------------ ConvLSTM / tracker
