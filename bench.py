@@ -113,6 +113,25 @@ def cpu_baseline_track(blob, tw, H, W, n_frames):
     return n_frames / dt, dt
 
 
+def load_traffic(clips, T, size):
+    """PMC-derived bytes per conv_igemm launch for this exact workload, measured
+    with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over
+    tools/pmc_probe.py and committed under profiles/ (tools/make_traffic_json.py).
+    bench.py cannot collect hardware counters itself; returns None if no
+    committed measurement matches the workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if (w.get("clips"), w.get("T"), w.get("size")) == (clips, T, size):
+            best = (f, d)
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,9 +247,16 @@ def main():
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "launches_per_step": ig["launches"] / max(1, args.steps),
-                         "avg_launch_ms": ig["ms"] / max(1, ig["launches"])},
+                         "avg_launch_ms": ig["ms"] / max(1, ig["launches"]),
+                         "algorithmic_gflop_per_launch": ig["flops"] / max(1, ig["launches"]) / 1e9,
+                         "algorithmic_bytes_per_launch": ig["bytes"] / max(1, ig["launches"])},
             "kernels": kern,
         }
+        tr = load_traffic(args.clips, args.T, args.size) if args.workload == "track" else None
+        if tr is not None:
+            out["roofline"]["traffic"] = tr[1]["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_unit"] = "bytes/launch (FETCH_SIZE x in-run calibration + WRITE_SIZE; beyond-L2, incl. Infinity Cache hits)"
+            out["roofline"]["traffic_source"] = os.path.relpath(tr[0], ROOT)
         if world == 1 and not args.no_cpu_baseline and args.workload == "track":
             from oracle import oracle as orc
             orc.lib()

@@ -14,7 +14,8 @@
 //   * v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak): 64-lane wavefront
 //     tiles of 32x32; each wave owns TM x TN such tiles, 4 waves per workgroup.
 //   * K is consumed in chunks of 32 floats of ONE tap, so a chunk of A is 32
-//     contiguous floats per pixel (128 B -> coalesced float4 loads, 8 lanes/row).
+//     contiguous floats per pixel (128 B -> coalesced float4 loads, 8 lanes/row);
+//     chunk order is channel-slice outer / tap inner for L2 reuse of the 3x3 halo.
 //   * LDS tiles are [rows][32+4] floats: k contiguous so one ds_read_b128 feeds
 //     four MFMA k-steps; the +4 pad makes the 16-lane b128 groups conflict-free.
 //     Lanes 0-31 take k-slots {0..3}, lanes 32-63 {4..7} of every 8 -- A and B
@@ -94,8 +95,20 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
         const int xcd = bid & 7, j = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;   // bijective for any nwg
     }
-    const int tile_n = bid % ntn;
-    const int tile_m = bid / ntn;
+    // Within the range, tiles go GN column tiles at a time over ALL row tiles (then the next
+    // GN columns): the ~64 workgroups resident on an XCD then cover (64/GN) row tiles x GN
+    // column tiles, which minimises weight-panel + activation-panel traffic per MFMA.
+    int tile_n, tile_m;
+    {
+        const int gn = p.tile_gn > 0 && p.tile_gn < ntn ? p.tile_gn : ntn;
+        const int ntm_all = gridDim.x / ntn;
+        const int per_group = gn * ntm_all;                 // tiles in a full column group
+        const int grp = bid / per_group;
+        const int rem = bid - grp * per_group;
+        const int gw = min(gn, ntn - grp * gn);             // width of this (possibly last, narrower) group
+        tile_m = rem / gw;
+        tile_n = grp * gn + (rem - tile_m * gw);
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- loader set-up ----------------------------------------------------
@@ -201,12 +214,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
     };
 
-    int gtap = k0 / cpt, gcc = k0 % cpt;   // (tap, chunk) of the NEXT tile to fetch from global memory
+    // K order is channel-chunk OUTER, tap INNER (k = (cc*TAPS + tap)*32 + c): the nine taps of one
+    // 32-channel slice are consumed back to back, so their shifted re-reads of the same activation
+    // rows hit L1/L2 instead of being re-fetched from the Infinity Cache nine chunk-rows apart.
+    int gtap = k0 % TAPS, gcc = k0 / TAPS;   // (tap, chunk) of the NEXT tile to fetch from global memory
     int gk = k0;                           // its absolute chunk index (B column offset)
     const int k_end = k0 + nk;
     auto gadvance = [&]() {
         ++gk;
-        if (++gcc == cpt) { gcc = 0; ++gtap; }
+        if (++gtap == TAPS) { gtap = 0; ++gcc; }
     };
     gload(gtap, gcc, gk);
     gadvance();
@@ -218,7 +234,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
     // The body is branch-free so that the scheduler can interleave it with the MFMAs:
     // past the end of K the loads re-read the last chunk and the LDS traffic goes to
     // the buffer nobody reads again.
-    const int last_tap = (k_end - 1) / cpt, last_cc = (k_end - 1) % cpt;
+    const int last_tap = (k_end - 1) % TAPS, last_cc = (k_end - 1) / TAPS;
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
         lfrag(f1, cur, 1);
@@ -349,6 +365,8 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
     ConvArgs a = a_in;
     static const int remap_env = [] { const char *e = getenv("DT_XCD_REMAP"); return e ? atoi(e) : 1; }();
     a.xcd_remap = remap_env;
+    static const int gn_env = [] { const char *e = getenv("DT_TILE_GN"); return e ? atoi(e) : 2; }();
+    a.tile_gn = gn_env;
     static const int cfg_env = [] { const char *e = getenv("DT_CONV_CFG"); return e ? atoi(e) : -1; }();
     if (cfg_env >= 0 && cfg == CFG_128x128) cfg = cfg_env;   // A/B experiments
     static float *zeros_dev = nullptr;   // process-wide 256 B of zeros for the padding taps
@@ -426,10 +444,11 @@ void pack_conv_weights(const float *hwio, int ks, int cin_src, int cout_src, con
             continue;
         }
         const float sc = scale ? scale[ns] : 1.0f;
+        // k = ((ci/32)*taps + t)*32 + ci%32  (channel-chunk outer, tap inner; cin_dst % 32 == 0)
         for (int t = 0; t < taps; ++t)
             for (int ci = 0; ci < cin_dst; ++ci) {
                 const int cs = cin_map ? cin_map[ci] : (ci < cin_src ? ci : -1);
-                row[(size_t)t * cin_dst + ci] =
+                row[((size_t)(ci >> 5) * taps + t) * 32 + (ci & 31)] =
                     cs < 0 ? 0.0f : hwio[((size_t)t * cin_src + cs) * cout_src + ns] * sc;
             }
     }

@@ -25,7 +25,7 @@ struct ConvArgs {
     const float *in;
     long long in_bs;
     int in_ld;
-    // packed weights [Npad][K], k = tap*Cin + ci (k contiguous); bias [Npad] or null
+    // packed weights [Npad][K], k = ((ci/32)*taps + tap)*32 + ci%32 (k contiguous); bias [Npad] or null
     const float *wt;
     const float *bias;
     // primary output (dense unless EPI_GATES): row r at out + r*out_ld (+ col)
@@ -46,6 +46,7 @@ struct ConvArgs {
     float slope;  // LeakyReLU slope; 1.0f = linear
     const float *zeros; // >= 16 B of device zeros: source of out-of-image taps (set by launch_conv_igemm)
     int ksplit;    // EPI_PARTIAL: number of K splits (grid.y); out = slab [ksplit][M][out_ld]
+    int tile_gn;   // column tiles per group in the tile order (0 = all)
     int xcd_remap; // 1: give each XCD a contiguous range of tiles (set by launch_conv_igemm)
 };
 
@@ -56,7 +57,7 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a, int ks, int order, int 
 int launch_splitk_reduce(hipStream_t st, const float *slab, int S, long long M, int N, const float *bias, float slope,
                          float *out, int out_ld);
 
-// host-side packing: Keras HWIO kernel -> [npad][ks*ks*cin_dst], k contiguous.
+// host-side packing: Keras HWIO kernel -> [npad][ks*ks*cin_dst], k contiguous in the kernel's chunk order.
 //   cin_map[cin_dst]: source input channel or -1 (zero);  n_map[npad]: source
 //   output channel or -1 (zero row);  scale[cout_src] multiplies each output
 //   channel (folded BatchNorm) or null.

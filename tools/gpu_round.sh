@@ -27,4 +27,5 @@ if [ "${SKIP_PMC:-0}" != "1" ]; then
 fi
 # keep the merged payload small: drop raw per-dispatch CSVs above 20 MB
 find $O -name "*.csv" -size +20M -delete
+python $R/tools/make_traffic_json.py $O ${CLIPS:-48} > $O/traffic.json 2>/dev/null; cat $O/traffic.json | head -20
 du -sh $O

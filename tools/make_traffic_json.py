@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 PMC passes of tools/pmc_probe.py (FETCH_SIZE and
+WRITE_SIZE, collected in SEPARATE runs with --kernel-trace only) into the small
+JSON bench.py reads for `roofline.traffic`.
+
+    make_traffic_json.py <dir with pmc_FETCH_SIZE/ and pmc_WRITE_SIZE/> <clips> > profiles/rNN_traffic.json
+
+Units / corrections (MI355X_MICROARCH.md "HBM"): both counters are in KiB; on
+gfx950 FETCH_SIZE reports exactly half of a wide coalesced read stream.  The
+probe's first dispatch is a 1 GiB device-to-device copy, which calibrates the
+read-side factor in the same run (expected ~2.0); WRITE_SIZE is checked against
+the 1 GiB normal_() fill (expected ~1.0).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+GIB = float(1 << 30)
+
+
+def rows(d, counter):
+    out = []
+    for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                out.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
+    return sorted(out)
+
+
+def main():
+    base, clips = sys.argv[1], int(sys.argv[2])
+    fetch = rows(os.path.join(base, "pmc_FETCH_SIZE"), "FETCH_SIZE")
+    write = rows(os.path.join(base, "pmc_WRITE_SIZE"), "WRITE_SIZE")
+    cal_r = [v for _, k, v in fetch if "copyBuffer" in k and v > 100000][0]       # 1 GiB read
+    cal_w = [v for _, k, v in write if "distribution" in k and v > 100000][0]     # 1 GiB written
+    f_read = GIB / (cal_r * 1024.0)
+    f_write = GIB / (cal_w * 1024.0)
+    fam = lambda k: k.startswith("void conv_igemm_f32")
+    fr = [v for _, k, v in fetch if fam(k)]
+    wr = [v for _, k, v in write if fam(k)]
+    out = {
+        "workload": {"clips": clips, "T": 30, "size": 416},
+        "kernel_family": "conv_igemm_f32",
+        "launches_sampled": len(fr),
+        "read_calibration_factor": f_read, "write_calibration_factor": f_write,
+        "fetch_bytes_per_launch": sum(fr) * 1024.0 * f_read / len(fr),
+        "write_bytes_per_launch": sum(wr) * 1024.0 * f_write / len(wr),
+        "note": "FETCH_SIZE/WRITE_SIZE (KiB) from separate rocprofv3 --pmc passes over tools/pmc_probe.py; "
+                "read side multiplied by the in-run 1 GiB copy calibration (gfx950 FETCH_SIZE counts 64 B per "
+                "128 B request); Infinity-Cache hits are included in FETCH_SIZE, so this is traffic beyond L2, "
+                "an upper bound on HBM bytes",
+    }
+    out["traffic_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
