@@ -137,7 +137,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["track", "detect"], default="track")
+    ap.add_argument("--workload", choices=["track", "detect", "tiny"], default="track")
+    ap.add_argument("--seqs", type=int, default=32, help="sequences per step (tiny)")
     ap.add_argument("--clips", type=int, default=48, help="clips per GPU per step (track)")
     ap.add_argument("--T", type=int, default=30)
     ap.add_argument("--size", type=int, default=416)
@@ -165,6 +166,31 @@ def main():
             if world > 1:
                 res = gather_detections(res)
             return res
+    elif args.workload == "tiny":
+        # BASELINE.json configs[3]: TinyTracker (ROLO-style) over 64-frame sequences, FRAME-sharded:
+        # every rank runs detector + pooling on its slice of the time axis of all sequences, the
+        # small per-frame rows are all-gathered, the LSTM over T runs replicated.  Strong scaling.
+        from models_tracking.TinyTracker import TinyTracker
+        from parallel import gather_frame_rows
+        C, T = 80, 64
+        assert T % world == 0
+        blob = synth.synth_darknet_blob(C, seed=1234)
+        det = KerasYOLO({'LABELS': KerasYOLO.LABELS_COCO, 'BATCH_SIZE': 4, 'IMAGE_H': H, 'IMAGE_W': W,
+                         'GRID_H': H // 32, 'GRID_W': W // 32}, weights=blob)
+        ctx = det.model.ctx
+        cfg = {"model_tracker": {"name": "TinyTracker", "lstm_units": 512, "sequence_length": T},
+               "train": {"pool": "Global", "batch_size": 4}}
+        tt = TinyTracker(cfg, feature_dims=(H // 16, W // 16, 512), weights=synth.synth_tiny_weights(512), ctx=ctx)
+        t_loc = T // world
+        frames = make_frames(args.seqs, t_loc, H, W, device, seed0=42 + 100 * rank)
+        frames_per_step = args.seqs * t_loc
+        gflop_per_frame = GFLOP_DETECT_416_C80 * (H * W) / (416.0 * 416.0)
+        tw = None
+
+        def step():
+            rows, _ = tt.frame_rows(frames.reshape(args.seqs * t_loc, H, W, 3), det)
+            rows = gather_frame_rows(rows.reshape(args.seqs, t_loc, -1).contiguous())
+            return ctx.tiny_sequence(rows)
     else:
         C = 80
         blob = synth.synth_darknet_blob(C, seed=1234)
@@ -199,12 +225,13 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     kern = {}
-    for name in ("conv_igemm", "conv1_direct", "convlstm_gates", "decode_nms", "associate", "misc"):
+    for name in ("conv_igemm", "conv1_direct", "convlstm_gates", "decode_nms", "associate", "splitk_reduce", "pool",
+                 "lstm_step", "misc"):
         p = ctx.profile_read(name)
         if p["launches"]:
             kern[name] = dict(launches=p["launches"], ms_per_step=p["ms"] / args.steps,
@@ -213,7 +240,7 @@ def main():
     ig = ctx.profile_read("conv_igemm")
     achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
     boxes_per_frame = None
-    if args.workload == "track" and res is not None:
+    if args.workload == "track" and res is not None and isinstance(res, dict):
         boxes_per_frame = float(res["counts"].float().mean().item())
 
     if rank == 0 and args.layer_report:
@@ -231,15 +258,18 @@ def main():
         total_frames = frames_per_step * world * args.steps
         fps = total_frames / elapsed
         out = {
-            "metric": "frames/sec detect+track @416x416" if args.workload == "track" else "frames/sec detect @416x416",
+            "metric": {"track": "frames/sec detect+track @416x416", "detect": "frames/sec detect @416x416",
+                       "tiny": "frames/sec detect + single-object LSTM track @416x416"}[args.workload],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if args.workload == "tiny" else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[2]: MultiObjDetTracker (YOLOv2 C=12 + ConvLSTM2D(512) + 1x1 "
                                     "+ decode/NMS + track ids), %d clips x %d frames per GPU per step, %dx%d uint8"
                                     % (args.clips, args.T, H, W)) if args.workload == "track" else
                        ("BASELINE.json configs[1]: YOLOv2 C=80 forward + decode/NMS, batch %d, %dx%d uint8"
-                        % (args.batch, H, W)),
+                        % (args.batch, H, W)) if args.workload == "detect" else
+                       ("BASELINE.json configs[3]: TinyTracker, %d sequences x 64 frames, frame-sharded x%d: YOLOv2 C=80 "
+                        "+ act_13 global max-pool + decode/top box per frame, LSTM(512)+Dense(4) over T" % (args.seqs, world)),
                        "frames_per_step_per_gpu": frames_per_step, "parallelism": "clip-shard x%d" % world,
                        "gflop_per_frame": gflop_per_frame, "boxes_per_frame": boxes_per_frame},
             "whole_path_tflops": fps * gflop_per_frame / 1e3,

@@ -135,6 +135,21 @@ DT_API int dt_tiny_forward(dt_ctx *ctx, const float *d_feat, const float *d_det,
                     int n_seq, int T, int fh, int fw, int fc, int pool,
                     float *d_out);
 
+/* The two halves of dt_tiny_forward, exposed so that a frame-sharded deployment
+ * (BASELINE.json configs[3]) can all-gather the small per-frame rows between them:
+ *   dt_tiny_features: pool + concatenate([feat, det]) -> d_x [n_rows, D]   (TinyTracker.py:29-34)
+ *   dt_tiny_sequence: d_x [n_seq, T, D] -> LSTM over T -> Dense -> d_out [n_seq, T, 4]  (:36-37) */
+DT_API int dt_tiny_features(dt_ctx *ctx, const float *d_feat, const float *d_det, int n_rows,
+                     int fh, int fw, int fc, int pool, float *d_x);
+DT_API int dt_tiny_sequence(dt_ctx *ctx, const float *d_x, int n_seq, int T, float *d_out);
+
+/* Detection box handed to the single-object tracker at inference (build-defined:
+ * the reference only has the training-time choice, preprocessing.py:421-456):
+ * highest-score survivor per frame as (cx,cy,w,h), zeros when a frame has none.
+ *   d_boxes [n_frames, cap, 8], d_counts [n_frames] -> d_out4 [n_frames, 4] */
+DT_API int dt_top_box(dt_ctx *ctx, const float *d_boxes, const int *d_counts, int n_frames,
+               int cap, float *d_out4);
+
 /* ---- layer-level entry points (used by the parity tests) --------------- */
 /* Conv2D 'same' stride 1 (+ optional folded bias, LeakyReLU slope, fused 2x2
  * maxpool) through the MFMA implicit-GEMM kernel.  h_kernel is Keras HWIO

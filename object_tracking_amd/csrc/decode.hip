@@ -413,3 +413,33 @@ int launch_associate(hipStream_t st, const float *boxes, const int *counts, int 
                        nids);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
+
+// ---------------------------------------------------------------------------
+// highest-score box per frame (ties -> lowest index), one wavefront per frame
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void top_box_kernel(const float *boxes, const int *counts, int cap, float *out4)
+{
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const int n = min(counts[f], cap);
+    const float *b = boxes + (long long)f * cap * DT_BOX_FLOATS;
+    float best = -1.0f;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const float s = b[i * 8 + 6];
+        if (s > best) { best = s; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane < 4) out4[(long long)f * 4 + lane] = (n > 0) ? b[bi * 8 + lane] : 0.0f;
+}
+
+int launch_top_box(hipStream_t st, const float *boxes, const int *counts, int n_frames, int cap, float *out4)
+{
+    if (n_frames <= 0) return 0;
+    hipLaunchKernelGGL(top_box_kernel, dim3((unsigned)n_frames), dim3(64), 0, st, boxes, counts, cap, out4);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}

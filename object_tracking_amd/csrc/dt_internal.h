@@ -80,6 +80,8 @@ int launch_bbox_iou(hipStream_t st, const float *pairs, int n, float *iou);
 int launch_associate(hipStream_t st, const float *boxes, const int *counts, int n_clips, int T, int cap,
                      float thr, int *ids, int *nids);
 
+int launch_top_box(hipStream_t st, const float *boxes, const int *counts, int n_frames, int cap, float *out4);
+
 int launch_convlstm_gates_only(hipStream_t st, const float *xproj, long long xp_bs, int xp_ld, float *cstate,
                                long long c_bs, int c_ld, float *hout, long long h_bs, int h_ld, int B, int HW,
                                int U);

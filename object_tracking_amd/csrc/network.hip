@@ -596,28 +596,38 @@ extern "C" int dt_tiny_load(dt_ctx *ctx, int D, int units, const float *h_kernel
     return DT_OK;
 }
 
-extern "C" int dt_tiny_forward(dt_ctx *ctx, const float *d_feat, const float *d_det, int n_seq, int T, int fh, int fw,
-                               int fc, int pool, float *d_out)
+extern "C" int dt_tiny_features(dt_ctx *ctx, const float *d_feat, const float *d_det, int n_rows, int fh, int fw,
+                                int fc, int pool, float *d_x)
 {
-    if (!ctx || !d_feat || !d_det || !d_out) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (!ctx || !d_feat || !d_det || !d_x) return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (!ctx->tiny_loaded) return dt_fail(ctx, DT_ERR_STATE, "TinyTracker weights not loaded");
-    const int U = ctx->tiny_U, D = ctx->tiny_D, Dp = ctx->tiny_Dpad, N4 = 4 * U;
+    const int D = ctx->tiny_D;
     const int fdim = pool == 0 ? fc : (fh / 4) * (fw / 4) * fc;
     if (fdim + 4 != D) return dt_fail(ctx, DT_ERR_ARG, "pooled feature width %d + 4 != D %d", fdim, D);
+    // GlobalMaxPooling2D / MaxPooling2D(4,4)+Flatten, then concatenate([x, det]) (TinyTracker.py:29-34)
+    ProfScope ps(ctx, "pool", 0.0, 4.0 * n_rows * ((double)fh * fw * fc + fdim));
+    int rc = pool == 0 ? launch_global_maxpool(ctx->stream, d_feat, n_rows, fh * fw, fc, d_x, D)
+                       : launch_maxpool4_flatten(ctx->stream, d_feat, n_rows, fh, fw, fc, d_x, D);
+    if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "pool launch failed");
+    if (launch_copy_cols(ctx->stream, d_det, 4, d_x + fdim, D, n_rows, 4))
+        return dt_fail(ctx, DT_ERR_DEVICE, "det concat launch failed");
+    return DT_OK;
+}
+
+extern "C" int dt_tiny_sequence(dt_ctx *ctx, const float *d_x, int n_seq, int T, float *d_out)
+{
+    if (!ctx || !d_x || !d_out) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (!ctx->tiny_loaded) return dt_fail(ctx, DT_ERR_STATE, "TinyTracker weights not loaded");
+    if (n_seq <= 0 || T <= 0) return dt_fail(ctx, DT_ERR_ARG, "n_seq and T must be positive");
+    const int U = ctx->tiny_U, D = ctx->tiny_D, Dp = ctx->tiny_Dpad, N4 = 4 * U;
     const int R = n_seq * T;
     float *x = ws_get(ctx, "tiny_x", (size_t)R * Dp * sizeof(float), /*zero_on_grow=*/true);
     float *xproj = ws_get(ctx, "tiny_xproj", (size_t)R * N4 * sizeof(float));
     float *hseq = ws_get(ctx, "tiny_h", (size_t)R * U * sizeof(float));
     float *cst = ws_get(ctx, "tiny_c", (size_t)n_seq * U * sizeof(float));
     if (!x || !xproj || !hseq || !cst) return DT_ERR_DEVICE;
-    {   // GlobalMaxPooling2D / MaxPooling2D(4,4)+Flatten, then concatenate([x, det]) (TinyTracker.py:29-34)
-        ProfScope ps(ctx, "pool", 0.0, 4.0 * R * ((double)fh * fw * fc + fdim));
-        int rc = pool == 0 ? launch_global_maxpool(ctx->stream, d_feat, R, fh * fw, fc, x, Dp)
-                           : launch_maxpool4_flatten(ctx->stream, d_feat, R, fh, fw, fc, x, Dp);
-        if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "pool launch failed");
-        if (launch_copy_cols(ctx->stream, d_det, 4, x + fdim, Dp, R, 4))
-            return dt_fail(ctx, DT_ERR_DEVICE, "det concat launch failed");
-    }
+    if (launch_copy_cols(ctx->stream, d_x, D, x, Dp, R, D))   // K padded to a multiple of 32 (pad columns stay 0)
+        return dt_fail(ctx, DT_ERR_DEVICE, "x staging launch failed");
     {   // x.W + b for every (sequence, t) at once on the matrix cores
         ConvArgs a;
         memset(&a, 0, sizeof(a));
@@ -647,6 +657,28 @@ extern "C" int dt_tiny_forward(dt_ctx *ctx, const float *d_feat, const float *d_
         if (launch_dense_sigmoid(ctx->stream, hseq, U, ctx->tiny_wd, ctx->tiny_bd, R, U, 4, d_out, 4))
             return dt_fail(ctx, DT_ERR_DEVICE, "Dense launch failed");
     }
+    return DT_OK;
+}
+
+extern "C" int dt_tiny_forward(dt_ctx *ctx, const float *d_feat, const float *d_det, int n_seq, int T, int fh, int fw,
+                               int fc, int pool, float *d_out)
+{
+    if (!ctx) return DT_ERR_ARG;
+    if (!ctx->tiny_loaded) return dt_fail(ctx, DT_ERR_STATE, "TinyTracker weights not loaded");
+    float *rows = ws_get(ctx, "tiny_rows", (size_t)n_seq * T * ctx->tiny_D * sizeof(float));
+    if (!rows) return DT_ERR_DEVICE;
+    int rc = dt_tiny_features(ctx, d_feat, d_det, n_seq * T, fh, fw, fc, pool, rows);
+    if (rc) return rc;
+    return dt_tiny_sequence(ctx, rows, n_seq, T, d_out);
+}
+
+// detection box fed to the single-object tracker: the highest-score survivor of a frame
+// as (cx, cy, w, h) in image-relative units (preprocessing.py:441-444), zeros if none
+extern "C" int dt_top_box(dt_ctx *ctx, const float *d_boxes, const int *d_counts, int n_frames, int cap, float *d_out4)
+{
+    if (!ctx || !d_boxes || !d_counts || !d_out4) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (launch_top_box(ctx->stream, d_boxes, d_counts, n_frames, cap, d_out4))
+        return dt_fail(ctx, DT_ERR_DEVICE, "top_box launch failed");
     return DT_OK;
 }
 

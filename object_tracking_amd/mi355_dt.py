@@ -24,7 +24,7 @@ SYMBOLS = [
     "dt_create", "dt_destroy", "dt_last_error", "dt_set_stream", "dt_abi_version",
     "dt_detector_config", "dt_load_darknet_weights", "dt_detect_forward", "dt_detector_tap",
     "dt_decode", "dt_bbox_iou", "dt_tracker_load", "dt_track_forward", "dt_associate",
-    "dt_tiny_load", "dt_tiny_forward", "dt_conv2d", "dt_convlstm_step",
+    "dt_tiny_load", "dt_tiny_forward", "dt_tiny_features", "dt_tiny_sequence", "dt_top_box", "dt_conv2d", "dt_convlstm_step",
     "dt_profile_enable", "dt_profile_reset", "dt_profile_read", "dt_profile_names",
 ]
 
@@ -64,6 +64,9 @@ def load_library():
     L.dt_associate.argtypes = [vp, vp, vp, ci, ci, ci, cf, vp, vp]
     L.dt_tiny_load.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp]
     L.dt_tiny_forward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
+    L.dt_tiny_features.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    L.dt_tiny_sequence.argtypes = [vp, vp, ci, ci, vp]
+    L.dt_top_box.argtypes = [vp, vp, vp, ci, ci, vp]
     L.dt_conv2d.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, vp, cf, ci, vp, vp]
     L.dt_convlstm_step.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]
     L.dt_profile_enable.argtypes = [vp, ci]
@@ -260,6 +263,32 @@ class Context(object):
         self._sync_stream()
         self._check(self.lib.dt_tiny_forward(self.h, _dptr(feat), _dptr(det), n_seq, T, fh, fw, fc,
                                              0 if pool == "Global" else 1, _dptr(out)), "dt_tiny_forward")
+        return out
+
+    def tiny_features(self, feat, det, D, pool="Global"):
+        """feat [n,fh,fw,fc], det [n,4] -> rows [n,D] (pooled feature (+) det box)."""
+        n, fh, fw, fc = feat.shape
+        x = self._f32(n, D)
+        self._sync_stream()
+        self._check(self.lib.dt_tiny_features(self.h, _dptr(feat), _dptr(det), n, fh, fw, fc,
+                                              0 if pool == "Global" else 1, _dptr(x)), "dt_tiny_features")
+        return x
+
+    def tiny_sequence(self, x):
+        """x [n_seq,T,D] -> [n_seq,T,4]."""
+        assert x.is_cuda and x.is_contiguous()
+        n_seq, T, _ = x.shape
+        out = self._f32(n_seq, T, 4)
+        self._sync_stream()
+        self._check(self.lib.dt_tiny_sequence(self.h, _dptr(x), n_seq, T, _dptr(out)), "dt_tiny_sequence")
+        return out
+
+    def top_box(self, boxes, counts):
+        """boxes [F,cap,8], counts [F] -> [F,4] highest-score box per frame (zeros if none)."""
+        F, cap, _ = boxes.shape
+        out = self._f32(F, 4)
+        self._sync_stream()
+        self._check(self.lib.dt_top_box(self.h, _dptr(boxes), _dptr(counts), F, cap, _dptr(out)), "dt_top_box")
         return out
 
     # ---- layer-level (parity tests) -----------------------------------

@@ -69,3 +69,32 @@ class TinyTracker(BaseTracker):
         if self._weights is not None:
             self.model_tracker.set_weights(self._weights)
         self.model_tracker.summary()
+
+    # ------------------------------------------------------------------
+    # Inference pipeline (addition: the reference only trains this model).  The
+    # detector is this build's KerasYOLO sharing the tracker's dt_ctx; the feature
+    # layer is its 'act_13' tap (26x26x512 at 416x416, config.json:9 fv_layer) and
+    # the detection box is the highest-score survivor of the frame as (cx,cy,w,h)
+    # in image-relative units (the training-time generator takes the first
+    # detection matching the ground-truth label, preprocessing.py:421-456).
+    def frame_rows(self, frames, detector):
+        """frames [F,H,W,3] (numpy / device) -> (rows [F,D] = pooled feature (+) det box, det4 [F,4])."""
+        ctx = self.model_tracker.ctx
+        assert detector.model.ctx is ctx, "construct TinyTracker(ctx=detector.model.ctx)"
+        d = detector.model.to_device(frames)
+        F = d.shape[0]
+        ctx.detect_forward_internal(d)
+        feat = ctx.detector_tap("act_13", F)
+        gh, gw = ctx.grid
+        netout = ctx.detector_tap("conv_23", F).reshape(F, gh, gw, ctx.nb_box, 5 + ctx.nb_class)
+        r = ctx.decode(netout, detector.OBJ_THRESHOLD, detector.NMS_THRESHOLD, detector.ANCHORS,
+                       len(detector.LABELS), cap=detector.MAX_BOX_PER_IMAGE)
+        det4 = ctx.top_box(r["boxes"], r["counts"])
+        return ctx.tiny_features(feat, det4, self.feature_width() + 4, self.pool), det4
+
+    def track_sequences(self, frames, detector):
+        """frames [n_seq,T,H,W,3] -> tracked boxes [n_seq,T,4] (device tensor)."""
+        n_seq, T = frames.shape[:2]
+        flat = frames.reshape((n_seq * T,) + tuple(frames.shape[2:]))
+        rows, _ = self.frame_rows(flat, detector)
+        return self.model_tracker.ctx.tiny_sequence(rows.reshape(n_seq, T, -1).contiguous())

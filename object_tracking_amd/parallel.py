@@ -27,15 +27,23 @@ def shard_range(n_total, rank, world):
 
 
 def _all_gather_cat(t, group=None):
-    """all-gather equal-shaped tensors along dim 0."""
+    """all-gather equal-shaped tensors along dim 0.  With the nccl (= RCCL)
+    backend the device tensors go straight over xGMI; with gloo (CPU tests, or a
+    functional test of the multi-process path on a single GPU) device tensors are
+    staged through the host."""
     world = dist.get_world_size(group)
-    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    if hasattr(dist, "all_gather_into_tensor") and t.is_cuda:
-        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    backend = dist.get_backend(group)
+    dev = t.device
+    src = t.contiguous()
+    if backend == "gloo" and src.is_cuda:
+        src = src.cpu()
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    if backend == "nccl" and hasattr(dist, "all_gather_into_tensor"):
+        dist.all_gather_into_tensor(out, src, group=group)
     else:
         parts = list(out.chunk(world, dim=0))
-        dist.all_gather(parts, t.contiguous(), group=group)
-    return out
+        dist.all_gather(parts, src, group=group)
+    return out.to(dev)
 
 
 def global_track_ids(ids, nids):
@@ -75,6 +83,20 @@ def gather_detections(res, n_clips_max=None, group=None):
     return dict(boxes=boxes, counts=counts, ids=ids, nids=nids, gids=global_track_ids(ids, nids))
 
 
+def gather_frame_rows(rows_local, group=None):
+    """Frame-sharded TinyTracker (BASELINE.json configs[3]): every rank ran the
+    detector + pooling on its contiguous slice of the time axis and holds
+    rows_local [n_seq, T_local, D]; all-gather the small rows (a few KB per
+    frame) and stitch the time axis back in rank order -> [n_seq, world*T_local, D]
+    on every rank, which then runs the (cheap, sequential) LSTM replicated."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return rows_local
+    world = dist.get_world_size(group)
+    n_seq, t_loc, D = rows_local.shape
+    allr = _all_gather_cat(rows_local.reshape(1, n_seq, t_loc, D), group)      # [world, n_seq, T_local, D]
+    return allr.permute(1, 0, 2, 3).reshape(n_seq, world * t_loc, D).contiguous()
+
+
 def init_from_env(backend=None):
     """Initialise the default process group from torchrun's environment
     (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT).  Returns
@@ -83,6 +105,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DT_ONE_DEVICE") == "1":     # functional test: every rank on GPU 0 (use with gloo)
+        local = 0
+    if backend is None:
+        backend = os.environ.get("DT_DIST_BACKEND")
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

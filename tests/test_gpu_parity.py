@@ -383,3 +383,81 @@ def test_tiny_forward_vs_oracle(ctx, pool, fh, fw, fc, n_seq, T):
     got = tt.model_tracker.predict([feat, det])
     ref = orc.tinytracker_forward(feat, det, tw, pool=pool)
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5)
+
+
+def test_tinytracker_pipeline_vs_oracle(ctx):
+    """detector -> act_13 tap + decode -> top box -> pool (+) det -> LSTM -> Dense,
+    the whole single-object chain against the oracle."""
+    from models_detection.KerasYOLO import KerasYOLO
+    from models_tracking.TinyTracker import TinyTracker
+    H = W = 64
+    C, n_seq, T = 12, 3, 4
+    blob = synth.synth_darknet_blob(C, head_std=0.3)
+    det = KerasYOLO({'LABELS': [str(i) for i in range(C)], 'BATCH_SIZE': 4, 'IMAGE_H': H, 'IMAGE_W': W,
+                     'GRID_H': 2, 'GRID_W': 2}, weights=blob)
+    det.OBJ_THRESHOLD = 0.2
+    tw = synth.synth_tiny_weights(512)
+    cfg = {"model_tracker": {"name": "TinyTracker", "lstm_units": 512, "sequence_length": T},
+           "train": {"pool": "Global", "batch_size": 4}}
+    tt = TinyTracker(cfg, feature_dims=(4, 4, 512), weights=tw, ctx=det.model.ctx)
+    frames = np.stack([synth.synth_clip(T, H, W, 2, seed=90 + i) for i in range(n_seq)])
+    got = tt.track_sequences(frames, det).cpu().numpy()
+    layers, _ = orc.parse_darknet_blob(blob, C)
+    flat = frames.reshape(n_seq * T, H, W, 3)
+    net, _, taps = orc.yolov2_forward(orc.normalize_u8(flat), layers, taps=("act_13",))
+    det4 = np.zeros((n_seq * T, 4), dtype=np.float32)
+    nbox = 0
+    for f in range(n_seq * T):
+        rows, _ = orc.decode_netout(net[f], 0.2, 0.45, ANCHORS, C)
+        if len(rows):
+            det4[f] = rows[int(np.argmax(rows[:, 6])), :4]
+            nbox += 1
+    assert nbox > 0, "vacuous without detections"
+    ref = orc.tinytracker_forward(taps["act_13"].reshape(n_seq, T, 4, 4, 512), det4.reshape(n_seq, T, 4), tw)
+    np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-4)
+
+
+def test_multi_process_path_on_one_gpu(tmp_path):
+    """Functional test of the N>1 code path on the single GPU of this box: 2
+    processes (gloo, both on cuda:0) each run detect+track on their shard of 4
+    clips and gather; the table and the global ids must equal the 1-process result."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = tmp_path / "w.py"
+    worker.write_text(r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import object_tracking_amd
+from parallel import gather_detections, shard_range, init_from_env
+from utility import synth
+from models_tracking.MultiObjDetTracker import MultiObjDetTracker
+rank, world, _ = init_from_env()
+H = W = 64; T = 3; N = 4; C = 12
+class Trk(MultiObjDetTracker):
+    IMAGE_H, IMAGE_W = H, W
+    GRID_H, GRID_W = 2, 2
+    SEQUENCE_LENGTH = T
+    LOAD_MODEL = False
+    OBJ_THRESHOLD = 0.3
+tw = synth.synth_tracker_weights(C); tw["out_kernel"] = tw["out_kernel"] * 40.0; tw["out_bias"][4::17] = 1.5
+trk = Trk(detector_weights=synth.synth_darknet_blob(C), tracker_weights=tw)
+frames = np.stack([synth.synth_clip(T, H, W, 2, seed=300 + i) for i in range(N)])
+a, b = shard_range(N, rank, world)
+out = gather_detections(trk.track_clips(frames[a:b]))
+full = gather_detections.__globals__["global_track_ids"]
+ref = trk.track_clips(frames)
+ok = (torch.equal(out["boxes"], ref["boxes"]) and torch.equal(out["counts"], ref["counts"])
+      and torch.equal(out["ids"], ref["ids"]) and torch.equal(out["gids"], full(ref["ids"], ref["nids"]))
+      and int(ref["counts"].sum()) > 0)
+print("RANK", rank, "OK" if ok else "MISMATCH", int(ref["counts"].sum()), flush=True)
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", WORLD_SIZE="2", DT_ONE_DEVICE="1",
+               DT_DIST_BACKEND="gloo")
+    procs = [subprocess.Popen([sys.executable, str(worker), root], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o[-2000:]
+        assert "RANK %d OK" % r in o, o[-2000:]

@@ -172,3 +172,33 @@ def test_gather_detections_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "RANK %d OK" % r in o, o
+
+
+_WORKER_ROWS = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import object_tracking_amd
+from parallel import gather_frame_rows, init_from_env
+rank, world, _ = init_from_env("gloo")
+n_seq, T, D = 3, 8, 5
+full = torch.arange(n_seq * T * D, dtype=torch.float32).reshape(n_seq, T, D)
+t_loc = T // world
+out = gather_frame_rows(full[:, rank * t_loc:(rank + 1) * t_loc].contiguous())
+ok = torch.equal(out, full)
+print("RANK", rank, "OK" if ok else "MISMATCH", flush=True)
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+def test_gather_frame_rows_gloo_world2(tmp_path):
+    """configs[3] exchange: time-sharded per-frame rows are stitched back in order."""
+    script = tmp_path / "worker_rows.py"
+    script.write_text(_WORKER_ROWS)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "RANK %d OK" % r in o, o
