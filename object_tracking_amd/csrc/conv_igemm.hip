@@ -34,7 +34,17 @@
 
 #include "dt_internal.h"
 
+#ifndef DT_GLDS
+#define DT_GLDS 1   // 1: async global->LDS DMA staging (global_load_lds), XOR-swizzled unpadded tiles
+#endif              // 0: register staging (global_load -> VGPR -> ds_write), rows padded to 36 floats
+#if DT_GLDS
+#define LDK 32
+#else
 #define LDK 36  // LDS row stride in floats (32 + 4 pad)
+#endif
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
 
 __device__ __forceinline__ float leaky_act(float v, float slope) { return v > 0.0f ? v : v * slope; }
 
@@ -112,8 +122,19 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- loader set-up ----------------------------------------------------
+    // Register staging: thread -> row lr + 32*i, 16-byte slot tid&7 of the 128-byte chunk row.
+    // DMA staging (global_load_lds writes LDS at wave-uniform base + lane*16): wave w, pass i
+    // fills the 8 consecutive rows of group g = 4*i + w; lane -> row g*8 + lane/8, PHYSICAL
+    // slot lane&7, and loads the LOGICAL slot (lane&7) ^ ((row>>1)&7) from global memory, i.e.
+    // the XOR swizzle is applied on the source side and again on the fragment reads, which makes
+    // the unpadded 128-byte rows conflict-free for ds_read_b128.
+#if DT_GLDS
+    const int lr = wave * 8 + (lane >> 3);                 // + 32*i
+    const int lc = ((lane & 7) ^ ((lr >> 1) & 7)) * 4;     // (row>>1)&7 does not depend on i (32*i)
+#else
     const int lr = tid >> 3;        // 0..31 row within pass
     const int lc = (tid & 7) * 4;   // float offset within the 32-float chunk
+#endif
     const float *a_ptr[PA];
     unsigned a_mask[PA];
 #pragma unroll
@@ -148,6 +169,29 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
     const int k0 = (int)(((long long)nk_all * blockIdx.y) / gridDim.y);
     const int nk = (int)(((long long)nk_all * (blockIdx.y + 1)) / gridDim.y) - k0;
 
+#if DT_GLDS
+    // one 1 KiB DMA piece per (wave, pass): 8 rows x 128 B, LDS destination wave-uniform
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma = [&](int buf, int tap, int cc, int kc) {
+        int aoff;
+        if (KS == 1)
+            aoff = cc * 32;
+        else
+            aoff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.in_ld + cc * 32;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const bool ok = (a_mask[i] >> tap) & 1u;
+            const float *src = ok ? a_ptr[i] + aoff : p.zeros;   // branch-free 'same' padding
+            float *dst = sA + (buf * BM + (4 * i + wave_u) * 8) * LDK;
+            __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            float *dst = sB + (buf * BN + (4 * i + wave_u) * 8) * LDK;
+            __builtin_amdgcn_global_load_lds((gptr_t *)(b_ptr[i] + kc * 32), (lptr_t *)dst, 16, 0, 0);
+        }
+    };
+#endif
     f32x4 ra[PA], rb[PB];
     auto gload = [&](int tap, int cc, int kc) {
         int aoff;
@@ -193,16 +237,34 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
     // 64-cycle MFMAs and the matrix pipe only idles for barrier skew.
     const int fr = lane & 31;          // fragment row within a 32-row tile
     const int fk = (lane >> 5) * 4;    // k sub-slot: lanes 0-31 -> 0..3, 32-63 -> 4..7
+    (void)fk;
     struct Frag {
         f32x4 a[TM], b[TN];
     };
     auto lfrag = [&](Frag &f, int buf, int kk) {
+#if DT_GLDS
+        const int ko = (((kk * 2 + (lane >> 5)) ^ ((fr >> 1) & 7)) * 4);   // swizzled 16-byte slot
+        const float *cA = sA + (buf * BM + wm * WTM + fr) * LDK + ko;
+        const float *cB = sB + (buf * BN + wn * WTN + fr) * LDK + ko;
+#else
         const float *cA = sA + (buf * BM + wm * WTM + fr) * LDK + fk + kk * 8;
         const float *cB = sB + (buf * BN + wn * WTN + fr) * LDK + fk + kk * 8;
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const f32x4 *>(cA + i * 32 * LDK);
 #pragma unroll
         for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const f32x4 *>(cB + j * 32 * LDK);
+    };
+    // one fragment = four MFMA k-steps per tile; `mma_part<lo,hi>` issues steps [lo,hi)
+    auto mma_part = [&](const Frag &f, int lo, int hi) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (s >= lo && s < hi)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
     };
     auto mma = [&](const Frag &f) {
 #pragma unroll
@@ -224,35 +286,96 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
         ++gk;
         if (++gtap == TAPS) { gtap = 0; ++gcc; }
     };
+    const int last_tap = (k_end - 1) % TAPS, last_cc = (k_end - 1) / TAPS;
+#ifndef DT_ABLATE
+#define DT_ABLATE 0   // timing-only ablation builds (tools/ablate.sh): results are WRONG when != 0
+#endif
+    constexpr bool AB_BARRIER = (DT_ABLATE & 1) != 0, AB_GLOAD = (DT_ABLATE & 2) != 0;
+    constexpr bool AB_LSTORE = (DT_ABLATE & 4) != 0, AB_LFRAG = (DT_ABLATE & 8) != 0;
+    Frag f0, f1;
+#if DT_GLDS
+    // DMA variant: chunk t+1 streams straight into the other LDS buffer while chunk t is
+    // multiplied; no staging registers, no ds_write.  The drain (vmcnt(0)) sits right before
+    // the one barrier of the iteration, a full chunk of MFMAs after the DMA was issued.
+    (void)ra; (void)rb; (void)gload; (void)lstore; (void)AB_LSTORE;
+    dma(0, gtap, gcc, gk);
+    gadvance();
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+    __syncthreads();
+    lfrag(f0, 0, 0);
+    // Every block of LDS reads / DMA issues sits AFTER the first k-step of an MFMA group and
+    // BEFORE its other three (pinned with sched_barrier): hipcc waits lgkmcnt(0) ahead of the
+    // first MFMA that consumes a fragment once LDS-DMA is in flight, so a read block placed in
+    // front of a group would be waited for immediately; placed here it has 12 x TM x TN MFMAs of
+    // cover and the wait in front of the next group finds nothing outstanding.
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    for (int kc = 0; kc < nk; ++kc) {
+        const int cur = kc & 1;
+        mma_part(f0, 0, 1);
+        SB();
+        if (!AB_LFRAG) lfrag(f1, cur, 1);
+        if (!AB_GLOAD) {
+            const bool in = gk < k_end;          // past the end: re-fetch the last chunk into the dead buffer
+            dma(cur ^ 1, in ? gtap : last_tap, in ? gcc : last_cc, in ? gk : k_end - 1);
+            gadvance();
+        }
+        __builtin_amdgcn_sched_barrier(0x16);   // DS reads and MFMAs stay put; the DMA issues and their address
+                                                // VALU/SALU may sink in between the twelve MFMAs that follow
+        mma_part(f0, 1, 4);
+        mma_part(f1, 0, 1);
+        SB();
+        if (!AB_LFRAG) lfrag(f0, cur, 2);
+        SB();
+        mma_part(f1, 1, 4);
+        mma_part(f0, 0, 1);
+        SB();
+        if (!AB_LFRAG) lfrag(f1, cur, 3);
+        SB();
+        mma_part(f0, 1, 4);
+        SB();
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's DMA pieces of chunk t+1 have landed
+        if (!AB_BARRIER) __syncthreads();
+        SB();
+        mma_part(f1, 0, 1);
+        SB();
+        if (!AB_LFRAG) lfrag(f0, cur ^ 1, 0);
+        SB();
+        mma_part(f1, 1, 4);
+    }
+#undef SB
+#else
     gload(gtap, gcc, gk);
     gadvance();
     lstore(0);
     if (nk > 1) { gload(gtap, gcc, gk); gadvance(); }
     __syncthreads();
-    Frag f0, f1;
     lfrag(f0, 0, 0);
     // The body is branch-free so that the scheduler can interleave it with the MFMAs:
     // past the end of K the loads re-read the last chunk and the LDS traffic goes to
     // the buffer nobody reads again.
-    const int last_tap = (k_end - 1) % TAPS, last_cc = (k_end - 1) / TAPS;
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = kc & 1;
-        lfrag(f1, cur, 1);
-        lstore(cur ^ 1);                                // chunk kc+1 (in registers since last iteration)
+        if (!AB_LFRAG) lfrag(f1, cur, 1);
+        if (!AB_LSTORE) lstore(cur ^ 1);                // chunk kc+1 (in registers since last iteration)
         mma(f0);
-        lfrag(f0, cur, 2);
-        {
+        if (!AB_LFRAG) lfrag(f0, cur, 2);
+        if (!AB_GLOAD) {
             const bool in = gk < k_end;
             gload(in ? gtap : last_tap, in ? gcc : last_cc, in ? gk : k_end - 1);
             gadvance();
         }
         mma(f1);
-        lfrag(f1, cur, 3);
+        if (!AB_LFRAG) lfrag(f1, cur, 3);
         mma(f0);
-        __syncthreads();
+        if (!AB_BARRIER) __syncthreads();
         __builtin_amdgcn_sched_barrier(0);   // keep the kk=3 MFMAs BELOW the barrier: they cover the reads that follow it
-        lfrag(f0, cur ^ 1, 0);
+        if (!AB_LFRAG) lfrag(f0, cur ^ 1, 0);
         __builtin_amdgcn_sched_barrier(0);   // ...and keep those reads ABOVE them
+        mma(f1);
+    }
+#endif
+    if (AB_LFRAG) {   // keep the fragments formally live
+        lfrag(f1, 0, 1);
         mma(f1);
     }
 

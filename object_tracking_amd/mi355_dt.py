@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355_dt.so")
+LIB_PATH = os.environ.get("MI355_DT_LIB") or os.path.join(_HERE, "libmi355_dt.so")   # override: ablation builds only
 
 DT_FRAMES_U8 = 0
 DT_FRAMES_F32 = 1
