@@ -43,6 +43,9 @@
 #define LDK 36  // LDS row stride in floats (32 + 4 pad)
 #endif
 
+#ifndef DT_DMA_AUX
+#define DT_DMA_AUX 0   // cache-policy bits of the global_load_lds instructions (0 = default)
+#endif
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
@@ -183,12 +186,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
             const bool ok = (a_mask[i] >> tap) & 1u;
             const float *src = ok ? a_ptr[i] + aoff : p.zeros;   // branch-free 'same' padding
             float *dst = sA + (buf * BM + (4 * i + wave_u) * 8) * LDK;
-            __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 0, DT_DMA_AUX);
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             float *dst = sB + (buf * BN + (4 * i + wave_u) * 8) * LDK;
-            __builtin_amdgcn_global_load_lds((gptr_t *)(b_ptr[i] + kc * 32), (lptr_t *)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)(b_ptr[i] + kc * 32), (lptr_t *)dst, 16, 0, DT_DMA_AUX);
         }
     };
 #endif
@@ -488,8 +491,10 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
     ConvArgs a = a_in;
     static const int remap_env = [] { const char *e = getenv("DT_XCD_REMAP"); return e ? atoi(e) : 1; }();
     a.xcd_remap = remap_env;
-    static const int gn_env = [] { const char *e = getenv("DT_TILE_GN"); return e ? atoi(e) : 2; }();
-    a.tile_gn = gn_env;
+    // column tiles per group of the tile order: measured FETCH_SIZE optimum is 1 for the 3x3
+    // layers (all ~64 workgroups resident on an XCD share ONE weight panel) and 2 for 1x1 / gates
+    static const int gn_env = [] { const char *e = getenv("DT_TILE_GN"); return e ? atoi(e) : -1; }();
+    a.tile_gn = gn_env >= 0 ? gn_env : ((ks == 3 && epi != EPI_GATES) ? 1 : 2);
     static const int cfg_env = [] { const char *e = getenv("DT_CONV_CFG"); return e ? atoi(e) : -1; }();
     if (cfg_env >= 0 && cfg == CFG_128x128) cfg = cfg_env;   // A/B experiments
     static float *zeros_dev = nullptr;   // process-wide 256 B of zeros for the padding taps
