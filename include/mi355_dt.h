@@ -123,14 +123,17 @@ DT_API int dt_associate(dt_ctx *ctx, const float *d_boxes, const int *d_counts,
                  int *d_ids, int *d_nids);
 
 /* ---- TinyTracker (models_tracking/TinyTracker.py:25-41) ---------------- */
-/*   h_kernel [D,4U], h_recurrent [U,4U], h_bias [4U], h_dense_kernel [U,4],
- *   h_dense_bias [4]; D = feature width + 4.  pool: 0 = 'Global', 1 = 'Max'. */
-DT_API int dt_tiny_load(dt_ctx *ctx, int D, int units, const float *h_kernel,
+/* Also serves TinyHeatmapTracker (models_tracking/TinyHeatmapTracker.py:26-48): same
+ * graph with a heatmap_size^2-wide detection input and Dense(heatmap_size^2, sigmoid).
+ *   h_kernel [D,4U], h_recurrent [U,4U], h_bias [4U], h_dense_kernel [U,out_dim],
+ *   h_dense_bias [out_dim]; D = pooled feature width + detection input width
+ *   (4 or heatmap_size^2); out_dim = 4 or heatmap_size^2.  pool: 0 = 'Global', 1 = 'Max'. */
+DT_API int dt_tiny_load(dt_ctx *ctx, int D, int units, int out_dim, const float *h_kernel,
                  const float *h_recurrent, const float *h_bias,
                  const float *h_dense_kernel, const float *h_dense_bias);
 
 /* Replaces model_tracker.predict([img_fv, det]).
- *   d_feat [n_seq, T, fh, fw, fc], d_det [n_seq, T, 4] -> d_out [n_seq, T, 4] */
+ *   d_feat [n_seq, T, fh, fw, fc], d_det [n_seq, T, D - feature width] -> d_out [n_seq, T, out_dim] */
 DT_API int dt_tiny_forward(dt_ctx *ctx, const float *d_feat, const float *d_det,
                     int n_seq, int T, int fh, int fw, int fc, int pool,
                     float *d_out);
@@ -142,6 +145,16 @@ DT_API int dt_tiny_forward(dt_ctx *ctx, const float *d_feat, const float *d_det,
 DT_API int dt_tiny_features(dt_ctx *ctx, const float *d_feat, const float *d_det, int n_rows,
                      int fh, int fw, int fc, int pool, float *d_x);
 DT_API int dt_tiny_sequence(dt_ctx *ctx, const float *d_x, int n_seq, int T, float *d_out);
+
+/* generate_heatmap_feat (utility/utils.py:53-58) applied as the data generator does
+ * (preprocessing.py:455): d_box4 [n,4] centre-format (cx,cy,w,h) -> d_heat [n, hs*hs] of 0/1.
+ * generate_rectangle_from_heatmap (utility/utils.py:61-79): d_heat [n, hs*hs] ->
+ * d_rect [n,4] int32 (x1,y1,x2,y2), (hs,hs,-1,-1) when no cell reaches thresh. */
+DT_API int dt_heatmap_from_boxes(dt_ctx *ctx, const float *d_box4, int n, int hmap_size, float *d_heat);
+/* same with the function's own argument list: d_xywh [n,4] float64 (det_x, det_y, det_w, det_h) */
+DT_API int dt_heatmap_from_xywh64(dt_ctx *ctx, const double *d_xywh, int n, int hmap_size, float *d_heat);
+DT_API int dt_rect_from_heatmap(dt_ctx *ctx, const float *d_heat, int n, int hmap_size, float thresh,
+                         int *d_rect);
 
 /* Detection box handed to the single-object tracker at inference (build-defined:
  * the reference only has the training-time choice, preprocessing.py:421-456):

@@ -425,7 +425,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
                 const int rbase = m0 + wm * WTM + i * 32 + 8 * g + 4 * hi;
                 float v[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = leaky_act(acc[i][j][4 * g + q] + bv, p.slope);
+                for (int q = 0; q < 4; ++q) {
+                    const float z = acc[i][j][4 * g + q] + bv;
+                    v[q] = p.act == 1 ? 1.0f / (1.0f + expf(-z)) : leaky_act(z, p.slope);   // Dense(sigmoid) / LeakyReLU
+                }
                 if (!cok || rbase >= p.M) continue;
                 if (EPI == EPI_PARTIAL) {
                     // split-K partial sums: raw accumulators to slab [split][M][N]

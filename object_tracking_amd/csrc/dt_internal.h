@@ -44,6 +44,7 @@ struct ConvArgs {
     int c_ld;
     int B, H, W, Cin, N, M, K;
     float slope;  // LeakyReLU slope; 1.0f = linear
+    int act;      // 0: LeakyReLU(slope), 1: sigmoid (Dense heads)
     const float *zeros; // >= 16 B of device zeros: source of out-of-image taps (set by launch_conv_igemm)
     int ksplit;    // EPI_PARTIAL: number of K splits (grid.y); out = slab [ksplit][M][out_ld]
     int tile_gn;   // column tiles per group in the tile order (0 = all)
@@ -80,6 +81,8 @@ int launch_bbox_iou(hipStream_t st, const float *pairs, int n, float *iou);
 int launch_associate(hipStream_t st, const float *boxes, const int *counts, int n_clips, int T, int cap,
                      float thr, int *ids, int *nids);
 
+int launch_heatmap_from_boxes(hipStream_t st, const float *box4, const double *xywh64, int n, int hs, float *out);
+int launch_rect_from_heatmap(hipStream_t st, const float *heat, int n, int hs, float thresh, int *rect);
 int launch_top_box(hipStream_t st, const float *boxes, const int *counts, int n_frames, int cap, float *out4);
 
 int launch_convlstm_gates_only(hipStream_t st, const float *xproj, long long xp_bs, int xp_ld, float *cstate,
@@ -142,7 +145,7 @@ struct dt_ctx {
     int trk_wo_npad = 0;
     // tiny tracker
     bool tiny_loaded = false;
-    int tiny_D = 0, tiny_Dpad = 0, tiny_U = 0;
+    int tiny_D = 0, tiny_Dpad = 0, tiny_U = 0, tiny_O = 0, tiny_Opad = 0;
     float *tiny_wx = nullptr, *tiny_bx = nullptr, *tiny_ur = nullptr, *tiny_wd = nullptr, *tiny_bd = nullptr;
     // workspaces (grown on demand)
     std::map<std::string, DevBuf> ws;

@@ -568,13 +568,14 @@ extern "C" int dt_track_forward(dt_ctx *ctx, const void *d_frames, int frames_dt
 // ---------------------------------------------------------------------------
 // TinyTracker
 // ---------------------------------------------------------------------------
-extern "C" int dt_tiny_load(dt_ctx *ctx, int D, int units, const float *h_kernel, const float *h_recurrent,
-                            const float *h_bias, const float *h_dense_kernel, const float *h_dense_bias)
+extern "C" int dt_tiny_load(dt_ctx *ctx, int D, int units, int out_dim, const float *h_kernel,
+                            const float *h_recurrent, const float *h_bias, const float *h_dense_kernel,
+                            const float *h_dense_bias)
 {
     if (!ctx || !h_kernel || !h_recurrent || !h_bias || !h_dense_kernel || !h_dense_bias)
         return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (units != 512) return dt_fail(ctx, DT_ERR_ARG, "LSTM units must be 512 (config.json:19)");
-    if (D < 8 || (D - 4) % 4) return dt_fail(ctx, DT_ERR_ARG, "feature width D-4 must be a multiple of 4");
+    if (D < 8 || out_dim < 1) return dt_fail(ctx, DT_ERR_ARG, "bad D / out_dim");
     const int U = units, Dp = round_up(D, 32), N4 = 4 * U;
     // x.W as a 1x1 "convolution": kernel [D,4U] is HWIO with k=1
     std::vector<float> wx((size_t)N4 * Dp), bx(h_bias, h_bias + N4);
@@ -584,14 +585,26 @@ extern "C" int dt_tiny_load(dt_ctx *ctx, int D, int units, const float *h_kernel
     for (int j = 0; j < U; ++j)
         for (int g = 0; g < 4; ++g)
             for (int k = 0; k < U; ++k) ur[((size_t)j * 4 + g) * U + k] = h_recurrent[(size_t)k * N4 + g * U + j];
-    std::vector<float> wd(h_dense_kernel, h_dense_kernel + (size_t)U * 4), bd(h_dense_bias, h_dense_bias + 4);
+    // Dense head: O <= 8 (TinyTracker, 4) keeps the [U][O] matrix for the wavefront-reduction
+    // kernel; wider heads (TinyHeatmapTracker, 32*32) run as a 1x1 MFMA GEMM with a sigmoid epilogue
+    const int O = out_dim, Opad = round_up(O, 128);
+    std::vector<float> wd, bd;
+    if (O <= 8) {
+        wd.assign(h_dense_kernel, h_dense_kernel + (size_t)U * O);
+        bd.assign(h_dense_bias, h_dense_bias + O);
+    } else {
+        wd.resize((size_t)Opad * U);
+        pack_conv_weights(h_dense_kernel, 1, U, O, nullptr, U, nullptr, Opad, nullptr, wd.data());
+        bd.assign(Opad, 0.0f);
+        for (int o = 0; o < O; ++o) bd[o] = h_dense_bias[o];
+    }
     int rc;
     if ((rc = upload(ctx, &ctx->tiny_wx, wx))) return rc;
     if ((rc = upload(ctx, &ctx->tiny_bx, bx))) return rc;
     if ((rc = upload(ctx, &ctx->tiny_ur, ur))) return rc;
     if ((rc = upload(ctx, &ctx->tiny_wd, wd))) return rc;
     if ((rc = upload(ctx, &ctx->tiny_bd, bd))) return rc;
-    ctx->tiny_D = D; ctx->tiny_Dpad = Dp; ctx->tiny_U = U;
+    ctx->tiny_D = D; ctx->tiny_Dpad = Dp; ctx->tiny_U = U; ctx->tiny_O = O; ctx->tiny_Opad = Opad;
     ctx->tiny_loaded = true;
     return DT_OK;
 }
@@ -603,13 +616,14 @@ extern "C" int dt_tiny_features(dt_ctx *ctx, const float *d_feat, const float *d
     if (!ctx->tiny_loaded) return dt_fail(ctx, DT_ERR_STATE, "TinyTracker weights not loaded");
     const int D = ctx->tiny_D;
     const int fdim = pool == 0 ? fc : (fh / 4) * (fw / 4) * fc;
-    if (fdim + 4 != D) return dt_fail(ctx, DT_ERR_ARG, "pooled feature width %d + 4 != D %d", fdim, D);
+    const int ddim = D - fdim;   // 4 (TinyTracker box) or heatmap_size^2 (TinyHeatmapTracker.py:31)
+    if (ddim < 1) return dt_fail(ctx, DT_ERR_ARG, "pooled feature width %d leaves no room for the detection input (D %d)", fdim, D);
     // GlobalMaxPooling2D / MaxPooling2D(4,4)+Flatten, then concatenate([x, det]) (TinyTracker.py:29-34)
     ProfScope ps(ctx, "pool", 0.0, 4.0 * n_rows * ((double)fh * fw * fc + fdim));
     int rc = pool == 0 ? launch_global_maxpool(ctx->stream, d_feat, n_rows, fh * fw, fc, d_x, D)
                        : launch_maxpool4_flatten(ctx->stream, d_feat, n_rows, fh, fw, fc, d_x, D);
     if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "pool launch failed");
-    if (launch_copy_cols(ctx->stream, d_det, 4, d_x + fdim, D, n_rows, 4))
+    if (launch_copy_cols(ctx->stream, d_det, ddim, d_x + fdim, D, n_rows, ddim))
         return dt_fail(ctx, DT_ERR_DEVICE, "det concat launch failed");
     return DT_OK;
 }
@@ -652,10 +666,22 @@ extern "C" int dt_tiny_sequence(dt_ctx *ctx, const float *d_x, int n_seq, int T,
                                   cst, ctx->tiny_ur, hseq + (long long)t * U, h_bs, n_seq, U);
         if (rc) return dt_fail(ctx, DT_ERR_DEVICE, "LSTM step launch failed");
     }
-    {
-        ProfScope ps(ctx, "misc", 2.0 * R * U * 4.0, 4.0 * R * (U + 4.0));
-        if (launch_dense_sigmoid(ctx->stream, hseq, U, ctx->tiny_wd, ctx->tiny_bd, R, U, 4, d_out, 4))
+    const int O = ctx->tiny_O;
+    if (O <= 8) {
+        ProfScope ps(ctx, "misc", 2.0 * R * U * (double)O, 4.0 * R * (U + (double)O));
+        if (launch_dense_sigmoid(ctx->stream, hseq, U, ctx->tiny_wd, ctx->tiny_bd, R, U, O, d_out, O))
             return dt_fail(ctx, DT_ERR_DEVICE, "Dense launch failed");
+    } else {   // TimeDistributed(Dense(heatmap_size^2, sigmoid))  (TinyHeatmapTracker.py:43)
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = hseq; a.in_ld = U; a.in_bs = U;
+        a.wt = ctx->tiny_wd; a.bias = ctx->tiny_bd;
+        a.out = d_out; a.out_ld = O; a.out_bs = O;
+        a.B = R; a.H = 1; a.W = 1; a.Cin = U; a.N = O; a.M = R; a.K = U;
+        a.slope = 1.0f; a.act = 1;
+        ProfScope ps(ctx, "conv_igemm", 2.0 * R * (double)U * O, 4.0 * ((double)R * U + (double)U * O + (double)R * O), "dense_head");
+        if (launch_conv_igemm(ctx->stream, a, 1, ORD_LINEAR, EPI_PLAIN, CFG_128x128))
+            return dt_fail(ctx, DT_ERR_DEVICE, "Dense head launch failed");
     }
     return DT_OK;
 }
@@ -670,6 +696,32 @@ extern "C" int dt_tiny_forward(dt_ctx *ctx, const float *d_feat, const float *d_
     int rc = dt_tiny_features(ctx, d_feat, d_det, n_seq * T, fh, fw, fc, pool, rows);
     if (rc) return rc;
     return dt_tiny_sequence(ctx, rows, n_seq, T, d_out);
+}
+
+// generate_heatmap_feat (utility/utils.py:53-58) for n centre-format boxes and
+// generate_rectangle_from_heatmap (utility/utils.py:61-79)
+extern "C" int dt_heatmap_from_boxes(dt_ctx *ctx, const float *d_box4, int n, int hmap_size, float *d_heat)
+{
+    if (!ctx || !d_box4 || !d_heat || hmap_size < 1) return dt_fail(ctx, DT_ERR_ARG, "bad argument");
+    if (launch_heatmap_from_boxes(ctx->stream, d_box4, nullptr, n, hmap_size, d_heat))
+        return dt_fail(ctx, DT_ERR_DEVICE, "heatmap launch failed");
+    return DT_OK;
+}
+
+extern "C" int dt_heatmap_from_xywh64(dt_ctx *ctx, const double *d_xywh, int n, int hmap_size, float *d_heat)
+{
+    if (!ctx || !d_xywh || !d_heat || hmap_size < 1) return dt_fail(ctx, DT_ERR_ARG, "bad argument");
+    if (launch_heatmap_from_boxes(ctx->stream, nullptr, d_xywh, n, hmap_size, d_heat))
+        return dt_fail(ctx, DT_ERR_DEVICE, "heatmap launch failed");
+    return DT_OK;
+}
+
+extern "C" int dt_rect_from_heatmap(dt_ctx *ctx, const float *d_heat, int n, int hmap_size, float thresh, int *d_rect)
+{
+    if (!ctx || !d_heat || !d_rect || hmap_size < 1) return dt_fail(ctx, DT_ERR_ARG, "bad argument");
+    if (launch_rect_from_heatmap(ctx->stream, d_heat, n, hmap_size, thresh, d_rect))
+        return dt_fail(ctx, DT_ERR_DEVICE, "rect_from_heatmap launch failed");
+    return DT_OK;
 }
 
 // detection box fed to the single-object tracker: the highest-score survivor of a frame

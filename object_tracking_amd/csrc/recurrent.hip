@@ -290,3 +290,86 @@ int launch_dense_sigmoid(hipStream_t st, const float *h, long long h_bs, const f
                        out, out_bs);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
+
+// ---------------------------------------------------------------------------
+// TinyHeatmapTracker helpers.
+// generate_heatmap_feat (utility/utils.py:53-58), called with the top-left corner of a
+// centre-format box (preprocessing.py:455: x - w/2.0, y - h/2.0, w, h): float64 arithmetic,
+// int() truncation toward zero, then numpy slice assignment
+//   heatmap[sy:sy+sh+1, sx:sx+sw+1] = 1.0   -- INCLUDING numpy's treatment of negative slice
+// bounds (a negative start counts from the end), which the reference inherits for boxes that
+// stick out of the image on the top/left.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void py_slice(int start, int stop, int n, int &lo, int &hi)
+{
+    if (start < 0) { start += n; if (start < 0) start = 0; } else if (start > n) start = n;
+    if (stop < 0) { stop += n; if (stop < 0) stop = 0; } else if (stop > n) stop = n;
+    lo = start; hi = stop;
+}
+
+// box4 != null: float32 centre-format boxes (cx,cy,w,h), corner formed in float64 as the data
+// generator does; xywh64 != null: float64 (det_x, det_y, det_w, det_h) exactly as the reference
+// function receives them.
+__global__ void heatmap_from_boxes_kernel(const float *box4, const double *xywh64, int n, int hs, float *out)
+{
+    const long long total = (long long)n * hs * hs;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(e % hs);
+        const int y = (int)((e / hs) % hs);
+        const long long b = e / ((long long)hs * hs);
+        double tx, ty, w, h;
+        if (box4) {
+            const double cx = box4[b * 4 + 0], cy = box4[b * 4 + 1];
+            w = box4[b * 4 + 2]; h = box4[b * 4 + 3];
+            tx = cx - w / 2.0; ty = cy - h / 2.0;
+        } else {
+            tx = xywh64[b * 4 + 0]; ty = xywh64[b * 4 + 1]; w = xywh64[b * 4 + 2]; h = xywh64[b * 4 + 3];
+        }
+        const int sx = (int)(tx * hs), sy = (int)(ty * hs);
+        const int sh = (int)(h * hs), sw = (int)(w * hs);
+        int y0, y1, x0, x1;
+        py_slice(sy, sy + sh + 1, hs, y0, y1);
+        py_slice(sx, sx + sw + 1, hs, x0, x1);
+        out[e] = (y >= y0 && y < y1 && x >= x0 && x < x1) ? 1.0f : 0.0f;
+    }
+}
+
+int launch_heatmap_from_boxes(hipStream_t st, const float *box4, const double *xywh64, int n, int hs, float *out)
+{
+    const long long total = (long long)n * hs * hs;
+    if (total <= 0) return 0;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(heatmap_from_boxes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, box4, xywh64, n, hs, out);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// generate_rectangle_from_heatmap (utility/utils.py:61-79): bounding rectangle
+// (x1,y1,x2,y2) of the cells >= thresh; (hs, hs, -1, -1) when none.  One wavefront
+// per heatmap, min/max reduced with wavefront shuffles.
+__global__ __launch_bounds__(64) void rect_from_heatmap_kernel(const float *heat, int hs, float thresh, int *rect)
+{
+    const long long b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float *hm = heat + b * hs * hs;
+    int x1 = hs, y1 = hs, x2 = -1, y2 = -1;
+    for (int e = lane; e < hs * hs; e += 64)
+        if (hm[e] >= thresh) {
+            const int i = e / hs, j = e - i * hs;
+            y1 = min(y1, i); y2 = max(y2, i); x1 = min(x1, j); x2 = max(x2, j);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x1 = min(x1, __shfl_xor(x1, o)); y1 = min(y1, __shfl_xor(y1, o));
+        x2 = max(x2, __shfl_xor(x2, o)); y2 = max(y2, __shfl_xor(y2, o));
+    }
+    if (lane == 0) { rect[b * 4 + 0] = x1; rect[b * 4 + 1] = y1; rect[b * 4 + 2] = x2; rect[b * 4 + 3] = y2; }
+}
+
+int launch_rect_from_heatmap(hipStream_t st, const float *heat, int n, int hs, float thresh, int *rect)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(rect_from_heatmap_kernel, dim3((unsigned)n), dim3(64), 0, st, heat, hs, thresh, rect);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}

@@ -24,7 +24,7 @@ SYMBOLS = [
     "dt_create", "dt_destroy", "dt_last_error", "dt_set_stream", "dt_abi_version",
     "dt_detector_config", "dt_load_darknet_weights", "dt_detect_forward", "dt_detector_tap",
     "dt_decode", "dt_bbox_iou", "dt_tracker_load", "dt_track_forward", "dt_associate",
-    "dt_tiny_load", "dt_tiny_forward", "dt_tiny_features", "dt_tiny_sequence", "dt_top_box", "dt_conv2d", "dt_convlstm_step",
+    "dt_tiny_load", "dt_tiny_forward", "dt_tiny_features", "dt_tiny_sequence", "dt_top_box", "dt_heatmap_from_boxes", "dt_heatmap_from_xywh64", "dt_rect_from_heatmap", "dt_conv2d", "dt_convlstm_step",
     "dt_profile_enable", "dt_profile_reset", "dt_profile_read", "dt_profile_names",
 ]
 
@@ -62,7 +62,10 @@ def load_library():
     L.dt_tracker_load.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     L.dt_track_forward.argtypes = [vp, vp, ci, ci, ci, vp, vp]
     L.dt_associate.argtypes = [vp, vp, vp, ci, ci, ci, cf, vp, vp]
-    L.dt_tiny_load.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp]
+    L.dt_tiny_load.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, vp]
+    L.dt_heatmap_from_boxes.argtypes = [vp, vp, ci, ci, vp]
+    L.dt_heatmap_from_xywh64.argtypes = [vp, vp, ci, ci, vp]
+    L.dt_rect_from_heatmap.argtypes = [vp, vp, ci, ci, cf, vp]
     L.dt_tiny_forward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     L.dt_tiny_features.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
     L.dt_tiny_sequence.argtypes = [vp, vp, ci, ci, vp]
@@ -251,7 +254,36 @@ class Context(object):
     # ---- tiny tracker ---------------------------------------------------
     def tiny_load(self, D, units, kernel, recurrent, bias, dense_kernel, dense_bias):
         ks = [_hptr(a) for a in (kernel, recurrent, bias, dense_kernel, dense_bias)]
-        self._check(self.lib.dt_tiny_load(self.h, D, units, *[k[1] for k in ks]), "dt_tiny_load")
+        self.tiny_out = int(np.asarray(dense_kernel).shape[1])
+        self.tiny_D = int(D)
+        self._check(self.lib.dt_tiny_load(self.h, D, units, self.tiny_out, *[k[1] for k in ks]), "dt_tiny_load")
+
+    def heatmap_from_boxes(self, box4, hmap_size):
+        """box4 [n,4] centre-format -> [n, hs*hs] 0/1 heatmaps (utils.generate_heatmap_feat)."""
+        n = box4.shape[0]
+        out = self._f32(n, hmap_size * hmap_size)
+        self._sync_stream()
+        self._check(self.lib.dt_heatmap_from_boxes(self.h, _dptr(box4), n, hmap_size, _dptr(out)), "dt_heatmap_from_boxes")
+        return out
+
+    def heatmap_from_xywh64(self, xywh, hmap_size):
+        """xywh [n,4] float64 (det_x, det_y, det_w, det_h) exactly as utils.generate_heatmap_feat takes them."""
+        assert xywh.dtype == self.torch.float64 and xywh.is_cuda and xywh.is_contiguous()
+        n = xywh.shape[0]
+        out = self._f32(n, hmap_size * hmap_size)
+        self._sync_stream()
+        self._check(self.lib.dt_heatmap_from_xywh64(self.h, _dptr(xywh), n, hmap_size, _dptr(out)), "dt_heatmap_from_xywh64")
+        return out
+
+    def rect_from_heatmap(self, heat, hmap_size, thresh=0.75):
+        """heat [n, hs*hs] -> int32 [n,4] (x1,y1,x2,y2) (utils.generate_rectangle_from_heatmap)."""
+        t = self.torch
+        n = heat.shape[0]
+        out = t.empty((n, 4), dtype=t.int32, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.dt_rect_from_heatmap(self.h, _dptr(heat), n, hmap_size, float(thresh), _dptr(out)),
+                    "dt_rect_from_heatmap")
+        return out
 
     def tiny_forward(self, feat, det, pool="Global"):
         """feat [n_seq,T,fh,fw,fc], det [n_seq,T,4] -> [n_seq,T,4]."""
@@ -259,7 +291,7 @@ class Context(object):
         assert feat.is_cuda and feat.is_contiguous() and feat.dtype == t.float32
         assert det.is_cuda and det.is_contiguous() and det.dtype == t.float32
         n_seq, T, fh, fw, fc = feat.shape
-        out = self._f32(n_seq, T, 4)
+        out = self._f32(n_seq, T, self.tiny_out)
         self._sync_stream()
         self._check(self.lib.dt_tiny_forward(self.h, _dptr(feat), _dptr(det), n_seq, T, fh, fw, fc,
                                              0 if pool == "Global" else 1, _dptr(out)), "dt_tiny_forward")
@@ -278,7 +310,7 @@ class Context(object):
         """x [n_seq,T,D] -> [n_seq,T,4]."""
         assert x.is_cuda and x.is_contiguous()
         n_seq, T, _ = x.shape
-        out = self._f32(n_seq, T, 4)
+        out = self._f32(n_seq, T, self.tiny_out)
         self._sync_stream()
         self._check(self.lib.dt_tiny_sequence(self.h, _dptr(x), n_seq, T, _dptr(out)), "dt_tiny_sequence")
         return out

@@ -59,6 +59,9 @@ class TinyTracker(BaseTracker):
         self._ctx = ctx
         self.load_tracker_model()
 
+    def det_width(self):
+        return 4
+
     def feature_width(self):
         if self.pool == 'Global':
             return self._c
@@ -90,7 +93,7 @@ class TinyTracker(BaseTracker):
         r = ctx.decode(netout, detector.OBJ_THRESHOLD, detector.NMS_THRESHOLD, detector.ANCHORS,
                        len(detector.LABELS), cap=detector.MAX_BOX_PER_IMAGE)
         det4 = ctx.top_box(r["boxes"], r["counts"])
-        return ctx.tiny_features(feat, det4, self.feature_width() + 4, self.pool), det4
+        return ctx.tiny_features(feat, det4, self.feature_width() + self.det_width(), self.pool), det4
 
     def track_sequences(self, frames, detector):
         """frames [n_seq,T,H,W,3] -> tracked boxes [n_seq,T,4] (device tensor)."""

@@ -83,6 +83,21 @@ def synth_tiny_weights(feat_dim=512, units=512, seed=1236):
     return w
 
 
+def synth_heatmap_weights(feat_dim=512, hmap=32, units=512, seed=1237):
+    """LSTM(512) + Dense(hmap*hmap) weights (TinyHeatmapTracker.py:42-43)."""
+    rs = np.random.RandomState(seed)
+    D, O = feat_dim + hmap * hmap, hmap * hmap
+    w = dict(
+        kernel=_glorot(rs, (D, 4 * units), D, 4 * units),
+        recurrent=_glorot(rs, (units, 4 * units), units, 4 * units),
+        bias=np.zeros(4 * units, dtype=np.float32),
+        dense_kernel=_glorot(rs, (units, O), units, O) * 4.0,
+        dense_bias=(rs.randn(O) * 0.5).astype(np.float32),
+    )
+    w["bias"][units:2 * units] = 1.0
+    return w
+
+
 def synth_clip(T, H, W, n_obj, seed):
     """uint8 [T,H,W,3] frames: low-frequency background + n_obj bright rectangles
     moving at constant velocity (ImageNet-VID / MOT17-shaped: consecutive frames

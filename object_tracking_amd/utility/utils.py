@@ -143,6 +143,23 @@ def decode_netout_batch(netouts, obj_threshold, nms_threshold, anchors, nb_class
     return out, rows_out
 
 
+def generate_heatmap_feat(det_x, det_y, det_w, det_h, hmap_size=32):
+    """utility/utils.py:53-58 (device kernel, float64 arguments as given)."""
+    import torch
+    ctx = mi355_dt.default_context()
+    b = torch.as_tensor(np.asarray([[det_x, det_y, det_w, det_h]], dtype=np.float64)).to(ctx.device)
+    return ctx.heatmap_from_xywh64(b, hmap_size)[0].cpu().numpy().astype(np.float64)
+
+
+def generate_rectangle_from_heatmap(heat_map, thresh=0.75, hmap_size=32):
+    """utility/utils.py:61-79 (device kernel): returns x1, y1, x2, y2."""
+    import torch
+    ctx = mi355_dt.default_context()
+    h = torch.as_tensor(np.ascontiguousarray(heat_map, dtype=np.float32).reshape(1, -1)).to(ctx.device)
+    x1, y1, x2, y2 = ctx.rect_from_heatmap(h, hmap_size, thresh)[0].cpu().numpy().tolist()
+    return x1, y1, x2, y2
+
+
 def draw_boxes(image, boxes, labels):
     """utility/utils.py:190-206 with PIL instead of OpenCV (cv2 is not part of
     this image).  `image` is an HxWx3 uint8 array; returns the annotated array."""

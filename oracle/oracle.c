@@ -482,3 +482,50 @@ ORC_API int orc_associate_clip(const float *boxes, const int *counts, int T,
     free(claimed);
     return next_id;
 }
+
+/* ---------------------------------------------------------------------------
+ * TinyHeatmapTracker helpers (utility/utils.py:53-79).
+ * ------------------------------------------------------------------------- */
+static void py_slice(int start, int stop, int n, int *lo, int *hi)
+{
+    /* numpy basic-slice normalisation of a[start:stop] on an axis of length n */
+    if (start < 0) { start += n; if (start < 0) start = 0; } else if (start > n) start = n;
+    if (stop < 0) { stop += n; if (stop < 0) stop = 0; } else if (stop > n) stop = n;
+    *lo = start; *hi = stop;
+}
+
+/* generate_heatmap_feat(det_x, det_y, det_w, det_h, hmap_size) (utils.py:53-58) called as
+ * the data generator does, preprocessing.py:455: (cx - w/2.0, cy - h/2.0, w, h).  float64
+ * arithmetic, int() truncation, numpy slice assignment.  box4 [n,4] -> out [n, hs*hs]. */
+ORC_API void orc_heatmap_from_boxes(const float *box4, int n, int hs, float *out)
+{
+    for (int b = 0; b < n; ++b) {
+        const double cx = box4[b * 4 + 0], cy = box4[b * 4 + 1], w = box4[b * 4 + 2], h = box4[b * 4 + 3];
+        const int sx = (int)((cx - w / 2.0) * hs), sy = (int)((cy - h / 2.0) * hs);
+        const int sh = (int)(h * hs), sw = (int)(w * hs);
+        int y0, y1, x0, x1;
+        py_slice(sy, sy + sh + 1, hs, &y0, &y1);
+        py_slice(sx, sx + sw + 1, hs, &x0, &x1);
+        float *o = out + (size_t)b * hs * hs;
+        for (int y = 0; y < hs; ++y)
+            for (int x = 0; x < hs; ++x) o[y * hs + x] = (y >= y0 && y < y1 && x >= x0 && x < x1) ? 1.0f : 0.0f;
+    }
+}
+
+/* generate_rectangle_from_heatmap (utils.py:61-79): heat [n, hs*hs] -> rect [n,4] = x1,y1,x2,y2 */
+ORC_API void orc_rect_from_heatmap(const float *heat, int n, int hs, float thresh, int *rect)
+{
+    for (int b = 0; b < n; ++b) {
+        int x1 = hs, y1 = hs, y2 = -1, x2 = -1;
+        const float *hm = heat + (size_t)b * hs * hs;
+        for (int i = 0; i < hs; ++i)
+            for (int j = 0; j < hs; ++j)
+                if (hm[i * hs + j] >= thresh) {
+                    if (i < y1) y1 = i;
+                    if (i > y2) y2 = i;
+                    if (j < x1) x1 = j;
+                    if (j > x2) x2 = j;
+                }
+        rect[b * 4 + 0] = x1; rect[b * 4 + 1] = y1; rect[b * 4 + 2] = x2; rect[b * 4 + 3] = y2;
+    }
+}

@@ -256,15 +256,30 @@ def tracker_forward(frames, layers, trk):
     return trkout, det
 
 
+def heatmap_from_boxes(box4, hs):
+    box4 = _f(box4)
+    out = np.empty((box4.shape[0], hs * hs), dtype=np.float32)
+    lib().orc_heatmap_from_boxes(_p(box4), box4.shape[0], hs, _p(out))
+    return out
+
+
+def rect_from_heatmap(heat, hs, thresh=0.75):
+    heat = _f(heat)
+    out = np.empty((heat.shape[0], 4), dtype=np.int32)
+    lib().orc_rect_from_heatmap(_p(heat), heat.shape[0], hs, ctypes.c_float(thresh), _p(out))
+    return out
+
+
 def tinytracker_forward(feat, det, tt, pool="Global"):
-    """TinyTracker graph.  feat [B,T,w,h,c], det [B,T,4]; tt: dict(kernel
-    [D,4U], recurrent [U,4U], bias [4U], dense_kernel [U,4], dense_bias [4]).
-    Returns [B,T,4]."""
+    """TinyTracker / TinyHeatmapTracker graph (TinyTracker.py:25-41,
+    TinyHeatmapTracker.py:26-48).  feat [B,T,w,h,c], det [B,T,4 | hs*hs]; tt:
+    dict(kernel [D,4U], recurrent [U,4U], bias [4U], dense_kernel [U,O], dense_bias [O]).
+    Returns [B,T,O]."""
     B, T = feat.shape[:2]
     U = tt["recurrent"].shape[0]
     h = np.zeros((B, U), dtype=np.float32)
     c = np.zeros_like(h)
-    out = np.zeros((B, T, 4), dtype=np.float32)
+    out = np.zeros((B, T, tt["dense_kernel"].shape[1]), dtype=np.float32)
     for t in range(T):
         f = feat[:, t]
         v = global_maxpool(f) if pool == "Global" else maxpool4_flatten(f)

@@ -461,3 +461,38 @@ sys.exit(0 if ok else 1)
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o[-2000:]
         assert "RANK %d OK" % r in o, o[-2000:]
+
+
+def test_heatmap_kernels_match_reference_golden(ctx, golden_dir):
+    d = np.load(os.path.join(golden_dir, "heatmap.npz"))
+    heat = ctx.heatmap_from_boxes(dev(d["box4"], ctx), 32).cpu().numpy()
+    assert np.array_equal(heat, d["heat"])
+    rects = ctx.rect_from_heatmap(dev(d["soft"].reshape(64, -1), ctx), 32, 0.75).cpu().numpy()
+    assert np.array_equal(rects, d["rects"])
+    from utility.utils import generate_heatmap_feat, generate_rectangle_from_heatmap
+    cx, cy, w, h = [float(v) for v in d["box4"][0]]
+    assert np.array_equal(generate_heatmap_feat(cx - w / 2.0, cy - h / 2.0, w, h, 32), d["heat"][0])
+    assert generate_rectangle_from_heatmap(d["soft"][5], 0.75, 32) == tuple(d["rects"][5].tolist())
+
+
+def test_tinyheatmap_forward_vs_oracle(ctx):
+    """TinyHeatmapTracker graph: D = 512 + 1024, Dense(1024, sigmoid) through the MFMA head."""
+    from models_tracking.TinyHeatmapTracker import TinyHeatmapTracker
+    n_seq, T, hs = 5, 4, 32
+    tw = synth.synth_heatmap_weights(512, hs)
+    cfg = {"model_tracker": {"name": "TinyHeatmapTracker", "lstm_units": 512, "sequence_length": T, "heatmap_size": hs},
+           "train": {"pool": "Global", "batch_size": 4}}
+    tt = TinyHeatmapTracker(cfg, feature_dims=(13, 13, 512), weights=tw, ctx=ctx)
+    rs = np.random.RandomState(21)
+    feat = rs.randn(n_seq, T, 13, 13, 512).astype(np.float32)
+    box = rs.rand(n_seq * T, 4).astype(np.float32) * [0.8, 0.8, 0.4, 0.4] + [0.1, 0.1, 0.05, 0.05]
+    det = orc.heatmap_from_boxes(box.astype(np.float32), hs).reshape(n_seq, T, hs * hs)
+    got = tt.model_tracker.predict([feat, det])
+    ref = orc.tinytracker_forward(feat, det, tw, pool="Global")
+    assert got.shape == (n_seq, T, hs * hs)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5)
+    # rectangles read back from the predicted maps agree with the oracle where no cell sits on the threshold
+    r_got = ctx.rect_from_heatmap(dev(got.reshape(n_seq * T, -1), ctx), hs, 0.75).cpu().numpy()
+    r_ref = orc.rect_from_heatmap(ref.reshape(n_seq * T, -1), hs, 0.75)
+    safe = np.all(np.abs(ref.reshape(n_seq * T, -1) - 0.75) > 1e-4, axis=1)
+    assert np.array_equal(r_got[safe], r_ref[safe]) and safe.any()

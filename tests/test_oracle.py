@@ -145,3 +145,10 @@ def test_oracle_associate_spec():
     assert ids[1, :3].tolist() == [1, 0, 2]
     assert ids[2, :2].tolist() == [3, 2]
     assert n == 4 and ids[0, 2] == -1
+
+
+def test_oracle_heatmap_helpers_match_reference_golden(golden_dir):
+    """utility/utils.py:53-79 incl. numpy's negative-slice semantics for boxes off the top/left"""
+    d = np.load(os.path.join(golden_dir, "heatmap.npz"))
+    assert np.array_equal(orc.heatmap_from_boxes(d["box4"], 32), d["heat"])
+    assert np.array_equal(orc.rect_from_heatmap(d["soft"].reshape(64, -1), 32, 0.75), d["rects"])

@@ -142,6 +142,26 @@ def main():
         iou[i] = ns["bbox_iou"](BB(*p[:4]), BB(*p[4:]))
     np.savez_compressed(os.path.join(OUT, "bbox_iou.npz"), pairs=pairs, iou=iou)
 
+    # --- heatmap helpers (utils.py:53-79), exec'd from their own line range ---
+    with open(os.path.join(REF, "utility", "utils.py")) as f:
+        lines = f.read().split("\n")
+    hns = {"np": np}
+    exec(compile("\n".join(lines[52:79]), "utils.py[53-79]", "exec"), hns)
+    rs = np.random.RandomState(9)
+    box4 = rs.rand(96, 4).astype(np.float32)
+    box4[:, 2:] *= 0.6
+    box4[:8] = [[0.5, 0.5, 0.2, 0.3], [0.05, 0.05, 0.3, 0.3], [0.98, 0.97, 0.2, 0.2], [0.5, 0.5, 0.0, 0.0],
+                [0.5, 0.5, 1.5, 1.5], [0.0, 0.0, 0.0, 0.0], [0.25, 0.75, 0.5, 0.5], [1.0, 1.0, 0.1, 0.1]]
+    heat = np.zeros((96, 32 * 32), dtype=np.float32)
+    for i, (cx, cy, w, h) in enumerate(box4):
+        cx, cy, w, h = float(cx), float(cy), float(w), float(h)
+        heat[i] = hns["generate_heatmap_feat"](cx - w / 2.0, cy - h / 2.0, w, h, hmap_size=32)   # preprocessing.py:455
+    soft = rs.rand(64, 32, 32).astype(np.float32)
+    soft[0] = 0.0
+    soft[1, 5, 7] = 0.9
+    rects = np.array([hns["generate_rectangle_from_heatmap"](m, 0.75, 32) for m in soft], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, "heatmap.npz"), box4=box4, heat=heat, soft=soft, rects=rects)
+
     # --- WeightReader known answer (utils.py:138-148): offset starts at 4 ---
     blob = np.arange(64, dtype=np.float32)
     p = os.path.join(OUT, "_tmp.weights")
