@@ -80,6 +80,14 @@ DT_API int dt_detect_forward(dt_ctx *ctx, const void *d_frames, int frames_dtype
  * dt_detect_forward of the same batch; copies into d_out. */
 DT_API int dt_detector_tap(dt_ctx *ctx, const char *name, int batch, float *d_out);
 
+/* ---- frame ingest ----------------------------------------------------- */
+/* Replaces cv2.resize(image, (IMAGE_H, IMAGE_W)) on decoded uint8 frames
+ * (KerasYOLO.py:526, MultiObjDetTracker.py:302); the /255. of normalize() is fused into
+ * conv_1.  OpenCV's 8-bit INTER_LINEAR scheme (half-pixel centres, 11-bit coefficients).
+ *   d_src [n, src_h, src_w, 3] uint8  ->  d_dst [n, dst_h, dst_w, 3] uint8 */
+DT_API int dt_ingest_resize(dt_ctx *ctx, const uint8_t *d_src, int n, int src_h, int src_w,
+                     uint8_t *d_dst, int dst_h, int dst_w);
+
 /* ---- decode_netout + NMS (utility/utils.py:208-257) -------------------- */
 /*   d_netout  [batch, GH, GW, NB, 5+NC]  raw logits (NOT modified)
  *   d_boxes   [batch, cap, DT_BOX_FLOATS] surviving boxes in (row,col,b) order

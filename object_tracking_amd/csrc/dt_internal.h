@@ -83,6 +83,9 @@ int launch_associate(hipStream_t st, const float *boxes, const int *counts, int 
 
 int launch_heatmap_from_boxes(hipStream_t st, const float *box4, const double *xywh64, int n, int hs, float *out);
 int launch_rect_from_heatmap(hipStream_t st, const float *heat, int n, int hs, float thresh, int *rect);
+void ingest_tables(int src, int dst, int *tab);
+int launch_ingest_resize(hipStream_t st, const unsigned char *src, int n, int Hs, int Ws, unsigned char *dst, int Hd,
+                         int Wd, const int *xt, const int *yt);
 int launch_top_box(hipStream_t st, const float *boxes, const int *counts, int n_frames, int cap, float *out4);
 
 int launch_convlstm_gates_only(hipStream_t st, const float *xproj, long long xp_bs, int xp_ld, float *cstate,
@@ -150,6 +153,7 @@ struct dt_ctx {
     // workspaces (grown on demand)
     std::map<std::string, DevBuf> ws;
     int last_batch = 0;
+    int ing_key[4] = {0, 0, 0, 0};   // (Hs, Ws, Hd, Wd) of the cached ingest tables
     // profiling
     bool prof = false;
     std::map<std::string, ProfEntry> prof_tab;

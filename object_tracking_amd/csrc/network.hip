@@ -397,6 +397,32 @@ extern "C" int dt_detector_tap(dt_ctx *ctx, const char *name, int batch, float *
 }
 
 // ---------------------------------------------------------------------------
+// frame ingest
+// ---------------------------------------------------------------------------
+extern "C" int dt_ingest_resize(dt_ctx *ctx, const uint8_t *d_src, int n, int src_h, int src_w, uint8_t *d_dst,
+                                int dst_h, int dst_w)
+{
+    if (!ctx || !d_src || !d_dst) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (n <= 0 || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0 || n > 65535 || dst_h > 65535)
+        return dt_fail(ctx, DT_ERR_ARG, "bad ingest shape");
+    int *tabs = reinterpret_cast<int *>(ws_get(ctx, "ingest_tabs", sizeof(int) * 4 * ((size_t)dst_w + dst_h)));
+    if (!tabs) return DT_ERR_DEVICE;
+    const int key[4] = {src_h, src_w, dst_h, dst_w};
+    if (memcmp(key, ctx->ing_key, sizeof(key)) != 0) {
+        std::vector<int> h(4 * ((size_t)dst_w + dst_h));
+        ingest_tables(src_w, dst_w, h.data());
+        ingest_tables(src_h, dst_h, h.data() + 4 * (size_t)dst_w);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(tabs, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+        memcpy(ctx->ing_key, key, sizeof(key));
+    }
+    ProfScope ps(ctx, "ingest", 0.0, 3.0 * n * ((double)src_h * src_w + (double)dst_h * dst_w));
+    if (launch_ingest_resize(ctx->stream, d_src, n, src_h, src_w, d_dst, dst_h, dst_w, tabs, tabs + 4 * (size_t)dst_w))
+        return dt_fail(ctx, DT_ERR_DEVICE, "ingest launch failed");
+    return DT_OK;
+}
+
+// ---------------------------------------------------------------------------
 // decode / iou / associate
 // ---------------------------------------------------------------------------
 extern "C" int dt_decode(dt_ctx *ctx, const float *d_netout, int batch, int GH, int GW, int NB, int NC,

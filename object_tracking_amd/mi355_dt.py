@@ -22,7 +22,7 @@ DT_BOX_FLOATS = 8
 
 SYMBOLS = [
     "dt_create", "dt_destroy", "dt_last_error", "dt_set_stream", "dt_abi_version",
-    "dt_detector_config", "dt_load_darknet_weights", "dt_detect_forward", "dt_detector_tap",
+    "dt_detector_config", "dt_load_darknet_weights", "dt_detect_forward", "dt_detector_tap", "dt_ingest_resize",
     "dt_decode", "dt_bbox_iou", "dt_tracker_load", "dt_track_forward", "dt_associate",
     "dt_tiny_load", "dt_tiny_forward", "dt_tiny_features", "dt_tiny_sequence", "dt_top_box", "dt_heatmap_from_boxes", "dt_heatmap_from_xywh64", "dt_rect_from_heatmap", "dt_conv2d", "dt_convlstm_step",
     "dt_profile_enable", "dt_profile_reset", "dt_profile_read", "dt_profile_names",
@@ -57,6 +57,7 @@ def load_library():
     L.dt_load_darknet_weights.argtypes = [vp, vp, csz, ctypes.POINTER(csz)]
     L.dt_detect_forward.argtypes = [vp, vp, ci, ci, vp, vp]
     L.dt_detector_tap.argtypes = [vp, ctypes.c_char_p, ci, vp]
+    L.dt_ingest_resize.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci]
     L.dt_decode.argtypes = [vp, vp, ci, ci, ci, ci, ci, cf, cf, vp, ci, vp, vp, vp, vp]
     L.dt_bbox_iou.argtypes = [vp, vp, ci, vp]
     L.dt_tracker_load.argtypes = [vp, ci, vp, vp, vp, vp, vp]
@@ -188,6 +189,18 @@ class Context(object):
         out = self._f32(*shape)
         self._sync_stream()
         self._check(self.lib.dt_detector_tap(self.h, name.encode(), batch, _dptr(out)), "dt_detector_tap")
+        return out
+
+    # ---- frame ingest -------------------------------------------------
+    def ingest_resize(self, frames, out_h, out_w):
+        """frames uint8 [n,Hs,Ws,3] device tensor -> uint8 [n,out_h,out_w,3] (cv2.resize INTER_LINEAR)."""
+        t = self.torch
+        assert frames.is_cuda and frames.dtype == t.uint8 and frames.is_contiguous() and frames.dim() == 4
+        n, Hs, Ws, _ = frames.shape
+        out = t.empty((n, out_h, out_w, 3), dtype=t.uint8, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.dt_ingest_resize(self.h, _dptr(frames), n, Hs, Ws, _dptr(out), out_h, out_w),
+                    "dt_ingest_resize")
         return out
 
     # ---- decode -------------------------------------------------------

@@ -2,9 +2,9 @@
 
 The reference does  cv2.imread -> cv2.resize(image,(IMAGE_H,IMAGE_W)) -> /255.
 (models_detection/KerasYOLO.py:525-528).  OpenCV is not part of this image, so
-decoding uses PIL and the resize is this file's own bilinear with half-pixel
-centres and no anti-aliasing (cv2.INTER_LINEAR's definition).  Parity with
-OpenCV itself is unpinned (cv2 absent).  Frames stay
+decoding uses PIL; the resize runs on the device (csrc/ingest.hip: OpenCV's 8-bit
+INTER_LINEAR scheme -- half-pixel centres, no anti-aliasing, 11-bit fixed-point
+coefficients).  Parity with OpenCV itself is unpinned (cv2 absent).  Frames stay
 uint8 BGR (cv2.imread's channel order; the reference's predict path never flips
 to RGB); the /255. happens on the device, fused into conv_1.
 """
@@ -23,25 +23,17 @@ def imwrite_bgr(path, image):
     Image.fromarray(np.ascontiguousarray(image[..., ::-1])).save(path)
 
 
-def resize_bilinear_u8(image, out_h, out_w):
-    """HxWx3 uint8 -> out_h x out_w x3 uint8, half-pixel-centre bilinear."""
-    H, W = image.shape[:2]
-    if (H, W) == (out_h, out_w):
-        return np.ascontiguousarray(image)
-    ys = (np.arange(out_h, dtype=np.float64) + 0.5) * (H / float(out_h)) - 0.5
-    xs = (np.arange(out_w, dtype=np.float64) + 0.5) * (W / float(out_w)) - 0.5
-    y0 = np.floor(ys).astype(np.int64); x0 = np.floor(xs).astype(np.int64)
-    fy = (ys - y0)[:, None, None]; fx = (xs - x0)[None, :, None]
-    y0c = np.clip(y0, 0, H - 1); y1c = np.clip(y0 + 1, 0, H - 1)
-    x0c = np.clip(x0, 0, W - 1); x1c = np.clip(x0 + 1, 0, W - 1)
-    im = image.astype(np.float64)
-    top = im[y0c][:, x0c] * (1 - fx) + im[y0c][:, x1c] * fx
-    bot = im[y1c][:, x0c] * (1 - fx) + im[y1c][:, x1c] * fx
-    out = top * (1 - fy) + bot * fy
-    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+def resize_bilinear_u8(image, out_h, out_w, ctx=None):
+    """HxWx3 uint8 -> out_h x out_w x3 uint8 on the device (dt_ingest_resize: OpenCV's 8-bit
+    INTER_LINEAR scheme, half-pixel centres, no anti-aliasing)."""
+    import torch
+    import mi355_dt
+    ctx = ctx if ctx is not None else mi355_dt.default_context()
+    d = torch.from_numpy(np.ascontiguousarray(image, dtype=np.uint8)[None]).to(ctx.device)
+    return ctx.ingest_resize(d, out_h, out_w)[0].cpu().numpy()
 
 
-def load_frame(path, image_h, image_w):
+def load_frame(path, image_h, image_w, ctx=None):
     """Returns (original BGR image, resized uint8 BGR frame)."""
     image = imread_bgr(path)
-    return image, resize_bilinear_u8(image, image_h, image_w)
+    return image, resize_bilinear_u8(image, image_h, image_w, ctx)

@@ -529,3 +529,52 @@ ORC_API void orc_rect_from_heatmap(const float *heat, int n, int hs, float thres
         rect[b * 4 + 0] = x1; rect[b * 4 + 1] = y1; rect[b * 4 + 2] = x2; rect[b * 4 + 3] = y2;
     }
 }
+
+/* ---------------------------------------------------------------------------
+ * Frame ingest: cv2.resize(image, (IMAGE_H, IMAGE_W)) on uint8 frames
+ * (models_detection/KerasYOLO.py:526; interpolation defaults to INTER_LINEAR).
+ * PARITY UNPINNED versus OpenCV (cv2 is not part of this image): this is
+ * the build's definition -- OpenCV's published 8-bit bilinear scheme: half-pixel centres,
+ * no anti-aliasing, coefficients quantised to 11 bits (round-half-even), horizontal pass
+ * into 32-bit integers, vertical pass ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2.
+ * Integer arithmetic only, so the HIP kernel can be (and is) bit-exact against it.
+ * ------------------------------------------------------------------------- */
+ORC_API void orc_resize_tables(int src, int dst, int *i0, int *i1, int *c0, int *c1)
+{
+    const double scale = (double)src / (double)dst;
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)(((double)d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (s < 0) { f = 0.0f; s = 0; }
+        if (s >= src - 1) { f = 0.0f; s = src - 1; }
+        i0[d] = s;
+        i1[d] = s + 1 < src ? s + 1 : src - 1;
+        c0[d] = (int)lrintf((1.0f - f) * 2048.0f);
+        c1[d] = (int)lrintf(f * 2048.0f);
+    }
+}
+
+ORC_API void orc_resize_bilinear_u8(const uint8_t *src, int n, int Hs, int Ws, uint8_t *dst, int Hd, int Wd)
+{
+    int *x0 = (int *)malloc(sizeof(int) * 4 * (size_t)Wd), *x1 = x0 + Wd, *a0 = x1 + Wd, *a1 = a0 + Wd;
+    int *y0 = (int *)malloc(sizeof(int) * 4 * (size_t)Hd), *y1 = y0 + Hd, *b0 = y1 + Hd, *b1 = b0 + Hd;
+    orc_resize_tables(Ws, Wd, x0, x1, a0, a1);
+    orc_resize_tables(Hs, Hd, y0, y1, b0, b1);
+    for (int f = 0; f < n; ++f) {
+        const uint8_t *s = src + (size_t)f * Hs * Ws * 3;
+        uint8_t *o = dst + (size_t)f * Hd * Wd * 3;
+        for (int y = 0; y < Hd; ++y) {
+            const uint8_t *r0 = s + (size_t)y0[y] * Ws * 3, *r1 = s + (size_t)y1[y] * Ws * 3;
+            for (int x = 0; x < Wd; ++x)
+                for (int c = 0; c < 3; ++c) {
+                    const int S0 = r0[x0[x] * 3 + c] * a0[x] + r0[x1[x] * 3 + c] * a1[x];
+                    const int S1 = r1[x0[x] * 3 + c] * a0[x] + r1[x1[x] * 3 + c] * a1[x];
+                    const int v = (((b0[y] * (S0 >> 4)) >> 16) + ((b1[y] * (S1 >> 4)) >> 16) + 2) >> 2;
+                    o[((size_t)y * Wd + x) * 3 + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+                }
+        }
+    }
+    free(x0);
+    free(y0);
+}

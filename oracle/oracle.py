@@ -67,6 +67,15 @@ def normalize_u8(img):
     return out
 
 
+def resize_bilinear_u8(frames, out_h, out_w):
+    """frames uint8 [n,Hs,Ws,3] -> [n,out_h,out_w,3] (cv2.resize INTER_LINEAR restatement, see oracle.c)."""
+    f = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, Hs, Ws, _ = f.shape
+    out = np.empty((n, out_h, out_w, 3), dtype=np.uint8)
+    lib().orc_resize_bilinear_u8(_p(f), n, Hs, Ws, _p(out), out_h, out_w)
+    return out
+
+
 def conv2d(x, w_hwio, bias=None):
     x = _f(x); w = _f(w_hwio)
     B, H, W, Cin = x.shape

@@ -496,3 +496,67 @@ def test_tinyheatmap_forward_vs_oracle(ctx):
     r_ref = orc.rect_from_heatmap(ref.reshape(n_seq * T, -1), hs, 0.75)
     safe = np.all(np.abs(ref.reshape(n_seq * T, -1) - 0.75) > 1e-4, axis=1)
     assert np.array_equal(r_got[safe], r_ref[safe]) and safe.any()
+
+
+@pytest.mark.parametrize("n,Hs,Ws,Hd,Wd", [(3, 37, 53, 64, 64), (2, 480, 640, 416, 416), (1, 1080, 1920, 416, 416),
+                                           (2, 100, 60, 416, 416), (1, 416, 416, 416, 416)])
+def test_ingest_resize_bit_exact_vs_oracle(ctx, n, Hs, Ws, Hd, Wd):
+    rs = np.random.RandomState(Hs + Wd)
+    src = rs.randint(0, 256, size=(n, Hs, Ws, 3)).astype(np.uint8)
+    got = ctx.ingest_resize(dev(src, ctx), Hd, Wd).cpu().numpy()
+    assert np.array_equal(got, orc.resize_bilinear_u8(src, Hd, Wd))
+
+
+def test_predict_drop_in_on_image_files(ctx, tmp_path):
+    """KerasYOLO.predict(input_path, output_path): decode file -> device resize -> x/255 fused
+    conv stack -> decode/NMS -> annotated file written; boxes equal to the oracle chain."""
+    from PIL import Image
+    from models_detection.KerasYOLO import KerasYOLO
+    C = 12
+    blob = synth.synth_darknet_blob(C, head_std=0.3)
+    det = KerasYOLO({'LABELS': [str(i) for i in range(C)], 'BATCH_SIZE': 1, 'IMAGE_H': 96, 'IMAGE_W': 96,
+                     'GRID_H': 3, 'GRID_W': 3}, weights=blob)
+    det.OBJ_THRESHOLD = 0.2
+    rgb = np.random.RandomState(4).randint(0, 256, size=(120, 200, 3)).astype(np.uint8)
+    src, dst = str(tmp_path / "in.png"), str(tmp_path / "out.png")
+    Image.fromarray(rgb).save(src)
+    boxes = det.predict(src, dst)
+    assert os.path.exists(dst) and Image.open(dst).size == (200, 120)
+    bgr = np.ascontiguousarray(rgb[..., ::-1])
+    frame = orc.resize_bilinear_u8(bgr[None], 96, 96)
+    layers, _ = orc.parse_darknet_blob(blob, C)
+    net, _, _ = orc.yolov2_forward(orc.normalize_u8(frame), layers)
+    rows, _ = orc.decode_netout(net[0], 0.2, 0.45, ANCHORS, C)
+    assert len(boxes) == len(rows) and len(rows) > 0
+    got = np.array([[b.x, b.y, b.w, b.h] for b in boxes], dtype=np.float32)
+    assert [b.get_label() for b in boxes] == [int(v) for v in rows[:, 5]]
+    assert box_err(got, rows) < 1e-3
+
+
+def test_track_608_vs_oracle(ctx):
+    """BASELINE.json configs[4] shape: 608x608 -> 19x19 grid (1805 cells, the decode kernel's
+    largest supported grid), C=12, one 2-frame clip through detector + ConvLSTM + 1x1 + decode."""
+    H = W = 608
+    T, C = 2, 12
+    trk, blob, tw = _tracker(H, W, T, C)
+    tw = dict(tw)
+    tw["out_kernel"] = tw["out_kernel"] * 40.0
+    ob = tw["out_bias"].copy(); ob[4::17] = -1.0; tw["out_bias"] = ob
+    trk.model.set_weights(tw)
+    trk.OBJ_THRESHOLD = 0.3
+    layers, _ = orc.parse_darknet_blob(blob, C)
+    frames = synth.synth_clip(T, H, W, 4, seed=608)[None]
+    res = trk.track_clips(frames)
+    ref_trk, _ = orc.tracker_forward(orc.normalize_u8(frames[0]), layers, tw)
+    got = res["netout"][0].cpu().numpy()
+    assert got.shape == (T, 19, 19, 5, 17)
+    assert relerr(got, ref_trk) < 1e-3
+    cnt = res["counts"][0].cpu().numpy()
+    for t in range(T):
+        rows, _ = orc.decode_netout(ref_trk[t], 0.3, 0.45, ANCHORS, C)
+        gb = res["boxes"][0, t, :cnt[t]].cpu().numpy()
+        if len(rows) == cnt[t] and np.array_equal(gb[:, 7], rows[:, 7]):
+            assert box_err(gb, rows) < 1e-3
+        else:   # a score within float noise of the threshold may flip membership; sets must still nearly agree
+            assert abs(len(rows) - int(cnt[t])) <= max(2, len(rows) // 50)
+    assert cnt.sum() > 0

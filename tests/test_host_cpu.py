@@ -101,15 +101,25 @@ def test_class_surface_defaults():
         assert callable(getattr(trainer, f))
 
 
-def test_resize_bilinear_identity_and_shape():
-    from utility.frames import resize_bilinear_u8
+def test_oracle_resize_properties():
+    """the ingest restatement: identity at equal size, constants stay constant, and it stays
+    within one grey level of exact (float64) half-pixel-centre bilinear interpolation"""
+    from oracle import oracle as orc
     rs = np.random.RandomState(0)
-    img = rs.randint(0, 256, size=(20, 30, 3)).astype(np.uint8)
-    assert np.array_equal(resize_bilinear_u8(img, 20, 30), img)
-    up = resize_bilinear_u8(img, 40, 60)
-    assert up.shape == (40, 60, 3)
-    const = np.full((7, 9, 3), 77, dtype=np.uint8)
-    assert np.all(resize_bilinear_u8(const, 32, 32) == 77)
+    img = rs.randint(0, 256, size=(2, 20, 30, 3)).astype(np.uint8)
+    assert np.array_equal(orc.resize_bilinear_u8(img, 20, 30), img)
+    assert orc.resize_bilinear_u8(img, 40, 60).shape == (2, 40, 60, 3)
+    const = np.full((1, 7, 9, 3), 77, dtype=np.uint8)
+    assert np.all(orc.resize_bilinear_u8(const, 32, 32) == 77)
+    H, W, oh, ow = 20, 30, 13, 17
+    ys = (np.arange(oh) + .5) * (H / oh) - .5; xs = (np.arange(ow) + .5) * (W / ow) - .5
+    y0 = np.floor(ys).astype(int); x0 = np.floor(xs).astype(int)
+    fy = np.where(y0 < 0, 0, ys - y0)[:, None, None]; fx = np.where(x0 < 0, 0, xs - x0)[None, :, None]
+    y0c, y1c = np.clip(y0, 0, H - 1), np.clip(y0 + 1, 0, H - 1)
+    x0c, x1c = np.clip(x0, 0, W - 1), np.clip(x0 + 1, 0, W - 1)
+    im = img[0].astype(np.float64)
+    ref = (im[y0c][:, x0c] * (1 - fx) + im[y0c][:, x1c] * fx) * (1 - fy) + (im[y1c][:, x0c] * (1 - fx) + im[y1c][:, x1c] * fx) * fy
+    assert np.abs(orc.resize_bilinear_u8(img[:1], oh, ow)[0].astype(np.float64) - ref).max() <= 1.0
 
 
 def test_shard_range_partitions():
