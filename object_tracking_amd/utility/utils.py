@@ -168,10 +168,12 @@ def draw_boxes(image, boxes, labels):
     d = ImageDraw.Draw(im)
     H, W = image.shape[:2]
     for box in boxes:
-        xmin = int((box.x - box.w / 2) * W)
-        xmax = int((box.x + box.w / 2) * W)
-        ymin = int((box.y - box.h / 2) * H)
-        ymax = int((box.y + box.h / 2) * H)
+        # w,h = anchor*exp(t)/G are unbounded; PIL (unlike cv2) rejects huge coordinates
+        lim = lambda v, n: int(min(max(v, -4.0 * n), 5.0 * n))
+        xmin = lim((box.x - box.w / 2) * W, W)
+        xmax = lim((box.x + box.w / 2) * W, W)
+        ymin = lim((box.y - box.h / 2) * H, H)
+        ymax = lim((box.y + box.h / 2) * H, H)
         d.rectangle([xmin, ymin, max(xmax, xmin), max(ymax, ymin)], outline=(0, 255, 0), width=3)
         text = labels[box.get_label()] + ' ' + str(box.get_score())
         if getattr(box, "track_id", None) is not None:
