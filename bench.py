@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--batch", type=int, default=8, help="frames per step (detect)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--h2d", action="store_true", help="also copy the frames from pinned host memory every step (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--cpu-frames", type=int, default=30)
     ap.add_argument("--layer-report", default=None, help="write a per-layer table (HIP-event times) to this file")
     args = ap.parse_args()
@@ -161,8 +162,13 @@ def main():
         frames_per_step = args.clips * args.T
         gflop_per_frame = GFLOP_TRACK_416 * (H * W) / (416.0 * 416.0)
 
+        host_frames = frames.cpu().pin_memory() if args.h2d else None
+
         def step():
-            res = trk.track_clips(frames, cap=128)
+            src = frames
+            if host_frames is not None:
+                frames.copy_(host_frames, non_blocking=True)     # same stream: serialised in front of the step
+            res = trk.track_clips(src, cap=128)
             if world > 1:
                 res = gather_detections(res)
             return res
@@ -272,7 +278,7 @@ def main():
                         "+ act_13 global max-pool + decode/top box per frame, LSTM(512)+Dense(4) over T" % (args.seqs, world)),
                        "frames_per_step_per_gpu": frames_per_step, "parallelism": "clip-shard x%d" % world,
                        "gflop_per_frame": gflop_per_frame, "boxes_per_frame": boxes_per_frame},
-            "whole_path_tflops": fps * gflop_per_frame / 1e3,
+            "whole_path_tflops": fps * gflop_per_frame / 1e3, "h2d_included": bool(args.h2d),
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32 implicit GEMM)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,

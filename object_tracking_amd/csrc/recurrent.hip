@@ -186,24 +186,34 @@ __global__ __launch_bounds__(128) void lstm_step_kernel(const float *xproj, long
     for (int b0 = 0; b0 < B; b0 += 64) {
         float keep[4] = {0.f, 0.f, 0.f, 0.f};
         const int bn = min(64, B - b0);
-        for (int bb = 0; bb < bn; ++bb) {
-            const float *hp = h_prev + (long long)(b0 + bb) * h_bs + lane * 8;
-            const f32x4 x0 = *reinterpret_cast<const f32x4 *>(hp);
-            const f32x4 x1 = *reinterpret_cast<const f32x4 *>(hp + 4);
-            float s[4];
+        // tracks in groups of 8: the sixteen 16-byte loads of a group are issued back to back
+        // (one L2 round trip per group instead of one per track), then reduced
+        for (int g0 = 0; g0 < bn; g0 += 8) {
+            f32x4 x0[8], x1[8];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float a = x0[0] * w[g][0];
-                a = __fmaf_rn(x0[1], w[g][1], a);
-                a = __fmaf_rn(x0[2], w[g][2], a);
-                a = __fmaf_rn(x0[3], w[g][3], a);
-                a = __fmaf_rn(x1[0], w[g][4], a);
-                a = __fmaf_rn(x1[1], w[g][5], a);
-                a = __fmaf_rn(x1[2], w[g][6], a);
-                a = __fmaf_rn(x1[3], w[g][7], a);
-                s[g] = wave_sum(a);
+            for (int u = 0; u < 8; ++u) {
+                const int bb = min(g0 + u, bn - 1);     // clamp: tail lanes re-read the last row
+                const float *hp = h_prev + (long long)(b0 + bb) * h_bs + lane * 8;
+                x0[u] = *reinterpret_cast<const f32x4 *>(hp);
+                x1[u] = *reinterpret_cast<const f32x4 *>(hp + 4);
             }
-            if (lane == bb) { keep[0] = s[0]; keep[1] = s[1]; keep[2] = s[2]; keep[3] = s[3]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float s[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float a = x0[u][0] * w[g][0];
+                    a = __fmaf_rn(x0[u][1], w[g][1], a);
+                    a = __fmaf_rn(x0[u][2], w[g][2], a);
+                    a = __fmaf_rn(x0[u][3], w[g][3], a);
+                    a = __fmaf_rn(x1[u][0], w[g][4], a);
+                    a = __fmaf_rn(x1[u][1], w[g][5], a);
+                    a = __fmaf_rn(x1[u][2], w[g][6], a);
+                    a = __fmaf_rn(x1[u][3], w[g][7], a);
+                    s[g] = wave_sum(a);
+                }
+                if (lane == g0 + u) { keep[0] = s[0]; keep[1] = s[1]; keep[2] = s[2]; keep[3] = s[3]; }
+            }
         }
         if (lane < bn) {
             const int b = b0 + lane;
