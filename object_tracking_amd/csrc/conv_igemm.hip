@@ -37,11 +37,25 @@
 #ifndef DT_GLDS
 #define DT_GLDS 1   // 1: async global->LDS DMA staging (global_load_lds), XOR-swizzled unpadded tiles
 #endif              // 0: register staging (global_load -> VGPR -> ds_write), rows padded to 36 floats
+#ifndef DT_BK
+#define DT_BK 32    // floats of K per chunk (one barrier per chunk): 32 -> 2 LDS stages, 2 workgroups/CU;
+#endif              // 16 -> 3 LDS stages of 16 KiB (48 KiB), <= 168 registers, 3 workgroups/CU
+#define KCH DT_BK
+#define SLOTS (KCH / 4)     // 16-byte slots per LDS row
+#define RPP (64 / SLOTS)    // rows covered by one 1 KiB DMA piece (64 lanes x 16 B)
+#define KKC (KCH / 8)       // fragment reads (8 k each) per chunk
 #if DT_GLDS
-#define LDK 32
+#define LDK KCH
+#define NSTAGE (DT_BK == 16 ? 3 : 2)
+#define SWZ(r) (SLOTS == 8 ? (((r) >> 1) & 7) : (((r) >> 2) & 3))   // rows sharing a 256 B bank row get distinct slots
 #else
-#define LDK 36  // LDS row stride in floats (32 + 4 pad)
+#if DT_BK != 32
+#error "register staging is only built for DT_BK=32"
 #endif
+#define LDK 36  // LDS row stride in floats (32 + 4 pad)
+#define NSTAGE 2
+#endif
+#define WAVES_PER_SIMD (DT_BK == 16 ? 3 : 2)
 
 #ifndef DT_DMA_AUX
 #define DT_DMA_AUX 0   // cache-policy bits of the global_load_lds instructions (0 = default)
@@ -80,16 +94,21 @@ __device__ __forceinline__ void decode_row(int m, int H, int W, int &b, int &h, 
 }
 
 template <int KS, int BM, int BN, int WGM, int WGN, int ORDER, int EPI>
-__global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv_igemm_f32(ConvArgs p)
 {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;    // MFMA tiles per wave
-    constexpr int PA = BM / 32, PB = BN / 32;      // loader passes (32 rows / pass)
+#if DT_GLDS
+    constexpr int RPASS = 4 * RPP;                 // rows filled per pass of the 4 waves
+#else
+    constexpr int RPASS = 32;
+#endif
+    constexpr int PA = BM / RPASS, PB = BN / RPASS;   // loader passes
     constexpr int TAPS = KS * KS;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sA = smem;                  // [2][BM][LDK]
-    float *sB = smem + 2 * BM * LDK;   // [2][BN][LDK]
+    float *sA = smem;                       // [NSTAGE][BM][LDK]
+    float *sB = smem + NSTAGE * BM * LDK;   // [NSTAGE][BN][LDK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -132,8 +151,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
     // the XOR swizzle is applied on the source side and again on the fragment reads, which makes
     // the unpadded 128-byte rows conflict-free for ds_read_b128.
 #if DT_GLDS
-    const int lr = wave * 8 + (lane >> 3);                 // + 32*i
-    const int lc = ((lane & 7) ^ ((lr >> 1) & 7)) * 4;     // (row>>1)&7 does not depend on i (32*i)
+    const int lr = wave * RPP + lane / SLOTS;              // + RPASS*i
+    const int lc = ((lane % SLOTS) ^ SWZ(lr)) * 4;         // SWZ(row) does not depend on i (RPASS*i)
 #else
     const int lr = tid >> 3;        // 0..31 row within pass
     const int lc = (tid & 7) * 4;   // float offset within the 32-float chunk
@@ -142,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
     unsigned a_mask[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int m = m0 + lr + 32 * i;
+        const int m = m0 + lr + RPASS * i;
         unsigned mask = 0;
         const float *ptr = p.in;
         if (m < p.M) {
@@ -164,9 +183,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
     }
     const float *b_ptr[PB];
 #pragma unroll
-    for (int i = 0; i < PB; ++i) b_ptr[i] = p.wt + (long long)(n0 + lr + 32 * i) * p.K + lc;
+    for (int i = 0; i < PB; ++i) b_ptr[i] = p.wt + (long long)(n0 + lr + RPASS * i) * p.K + lc;
 
-    const int cpt = p.Cin >> 5;     // 32-float chunks per tap
+    const int cpt = p.Cin / KCH;    // K chunks per tap
     // split-K: blockIdx.y owns chunks [k0, k0+nk) of the TAPS*cpt chunks of K
     const int nk_all = TAPS * cpt;
     const int k0 = (int)(((long long)nk_all * blockIdx.y) / gridDim.y);
@@ -178,20 +197,20 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
     auto dma = [&](int buf, int tap, int cc, int kc) {
         int aoff;
         if (KS == 1)
-            aoff = cc * 32;
+            aoff = cc * KCH;
         else
-            aoff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.in_ld + cc * 32;
+            aoff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.in_ld + cc * KCH;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const bool ok = (a_mask[i] >> tap) & 1u;
             const float *src = ok ? a_ptr[i] + aoff : p.zeros;   // branch-free 'same' padding
-            float *dst = sA + (buf * BM + (4 * i + wave_u) * 8) * LDK;
+            float *dst = sA + (buf * BM + (4 * i + wave_u) * RPP) * LDK;
             __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 0, DT_DMA_AUX);
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            float *dst = sB + (buf * BN + (4 * i + wave_u) * 8) * LDK;
-            __builtin_amdgcn_global_load_lds((gptr_t *)(b_ptr[i] + kc * 32), (lptr_t *)dst, 16, 0, DT_DMA_AUX);
+            float *dst = sB + (buf * BN + (4 * i + wave_u) * RPP) * LDK;
+            __builtin_amdgcn_global_load_lds((gptr_t *)(b_ptr[i] + kc * KCH), (lptr_t *)dst, 16, 0, DT_DMA_AUX);
         }
     };
 #endif
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
     };
     auto lfrag = [&](Frag &f, int buf, int kk) {
 #if DT_GLDS
-        const int ko = (((kk * 2 + (lane >> 5)) ^ ((fr >> 1) & 7)) * 4);   // swizzled 16-byte slot
+        const int ko = (((kk * 2 + (lane >> 5)) ^ SWZ(fr)) * 4);   // swizzled 16-byte slot
         const float *cA = sA + (buf * BM + wm * WTM + fr) * LDK + ko;
         const float *cB = sB + (buf * BN + wn * WTN + fr) * LDK + ko;
 #else
@@ -296,7 +315,54 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs p)
     constexpr bool AB_BARRIER = (DT_ABLATE & 1) != 0, AB_GLOAD = (DT_ABLATE & 2) != 0;
     constexpr bool AB_LSTORE = (DT_ABLATE & 4) != 0, AB_LFRAG = (DT_ABLATE & 8) != 0;
     Frag f0, f1;
-#if DT_GLDS
+#if DT_GLDS && DT_BK == 16
+    // 16-deep chunks, THREE 16 KiB LDS stages (48 KiB -> three workgroups per CU, three waves per
+    // SIMD within 168 registers).  The DMA of chunk t+2 is issued while chunk t is multiplied and
+    // stays in flight across the barrier (raw s_barrier + counted vmcnt: only chunk t+1's pieces
+    // are waited for), so every DMA has a whole chunk of MFMAs of cover.
+    (void)ra; (void)rb; (void)gload; (void)lstore; (void)AB_LSTORE;
+    constexpr int NPIECE = PA + PB;                       // DMA pieces per wave per chunk
+    static_assert(NPIECE >= 1 && NPIECE <= 15, "vmcnt(NPIECE) must fit the 4 low bits of the immediate");
+    constexpr int WAIT_PREV = 0x0f70 | NPIECE;            // s_waitcnt vmcnt(NPIECE): all but the newest chunk landed
+    dma(0, gtap, gcc, gk);
+    gadvance();
+    {
+        const bool in = gk < k_end;
+        dma(1, in ? gtap : last_tap, in ? gcc : last_cc, in ? gk : k_end - 1);
+        gadvance();
+    }
+    __builtin_amdgcn_s_waitcnt(WAIT_PREV);   // chunk 0 landed, chunk 1 may still fly
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    lfrag(f0, 0, 0);
+    int b_cur = 0, b_nxt = 1, b_nn = 2;
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    for (int kc = 0; kc < nk; ++kc) {
+        mma_part(f0, 0, 1);
+        SB();
+        if (!AB_LFRAG) lfrag(f1, b_cur, 1);
+        if (!AB_GLOAD) {
+            const bool in = gk < k_end;          // past the end: re-fetch the last chunk into a dead buffer
+            dma(b_nn, in ? gtap : last_tap, in ? gcc : last_cc, in ? gk : k_end - 1);
+            gadvance();
+        }
+        __builtin_amdgcn_sched_barrier(0x16);
+        mma_part(f0, 1, 4);
+        SB();
+        __builtin_amdgcn_s_waitcnt(WAIT_PREV);  // everything but the newest chunk has landed -> chunk t+1 ready
+        __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): my reads of buffer b_cur are done (it is refilled next chunk)
+        if (!AB_BARRIER) __builtin_amdgcn_s_barrier();
+        SB();
+        mma_part(f1, 0, 1);
+        SB();
+        if (!AB_LFRAG) lfrag(f0, b_nxt, 0);
+        SB();
+        mma_part(f1, 1, 4);
+        const int t = b_cur; b_cur = b_nxt; b_nxt = b_nn; b_nn = t;
+    }
+#undef SB
+    __builtin_amdgcn_s_waitcnt(0x0f70);    // drain the dead trailing DMAs before the LDS is released
+#elif DT_GLDS
     // DMA variant: chunk t+1 streams straight into the other LDS buffer while chunk t is
     // multiplied; no staging registers, no ds_write.  The drain (vmcnt(0)) sits right before
     // the one barrier of the iteration, a full chunk of MFMAs after the DMA was issued.
@@ -468,7 +534,7 @@ template <int KS, int BM, int BN, int WGM, int WGN, int ORDER, int EPI>
 static int launch_one(hipStream_t st, const ConvArgs &a, int ksplit = 1)
 {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    const size_t lds = (size_t)NSTAGE * (BM + BN) * LDK * sizeof(float);
     auto kern = conv_igemm_f32<KS, BM, BN, WGM, WGN, ORDER, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -506,7 +572,7 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
         if (hipMemset(zeros_dev, 0, 256) != hipSuccess) return 1;
     }
     a.zeros = zeros_dev;
-    if (a.Cin % 32 != 0 || a.K != ks * ks * a.Cin) return 2;
+    if (a.Cin % KCH != 0 || a.K != ks * ks * a.Cin) return 2;
     if (epi == EPI_GATES) {
         if (order != ORD_LINEAR) return 2;
         if (ks == 3) return launch_one<3, 128, 128, 4, 1, ORD_LINEAR, EPI_GATES>(st, a);
@@ -575,11 +641,11 @@ void pack_conv_weights(const float *hwio, int ks, int cin_src, int cout_src, con
             continue;
         }
         const float sc = scale ? scale[ns] : 1.0f;
-        // k = ((ci/32)*taps + t)*32 + ci%32  (channel-chunk outer, tap inner; cin_dst % 32 == 0)
+        // k = ((ci/KCH)*taps + t)*KCH + ci%KCH  (channel-chunk outer, tap inner; cin_dst % KCH == 0)
         for (int t = 0; t < taps; ++t)
             for (int ci = 0; ci < cin_dst; ++ci) {
                 const int cs = cin_map ? cin_map[ci] : (ci < cin_src ? ci : -1);
-                row[((size_t)(ci >> 5) * taps + t) * 32 + (ci & 31)] =
+                row[((size_t)(ci / KCH) * taps + t) * KCH + (ci % KCH)] =
                     cs < 0 ? 0.0f : hwio[((size_t)t * cin_src + cs) * cout_src + ns] * sc;
             }
     }

@@ -272,17 +272,26 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
                                 (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0));
     char tag[32];
     snprintf(tag, sizeof(tag), L.idx == 102 ? "tconv_2" : "conv_%d", L.idx);
-    // Small-M layers (few frames at 13x13/26x26) cannot fill 256 CUs with output tiles:
-    // split K over grid.y into a slab and combine deterministically.
+    // Wave quantisation for small batches (few frames at 13x13 / 26x26): with 512 resident
+    // workgroup slots (256 CUs x 2) a layer of a few hundred output tiles leaves the chip
+    // partly idle or spills a nearly empty last round.  Split K over grid.y into a slab and
+    // combine deterministically; the split count minimises a simple round model
+    //   time(s) ~ rounds(tiles*s) / s + 0.003*s,  rounds(n) = full rounds + cost of the partial one
+    // (a half-empty round still costs ~0.6 of a full one: single workgroups per CU run faster).
     int ksplit = 1;
     if (epi == EPI_PLAIN && order == ORD_LINEAR && cfg == CFG_128x128) {
         const int tiles = ((a.M + 127) / 128) * ((L.cout + 127) / 128);
         const int nk = a.K / 32;
-        if (tiles < 384) {
-            ksplit = (512 + tiles - 1) / tiles;
-            if (ksplit > nk / 6) ksplit = nk / 6;       // keep >= 6 chunks (192 of K) per split
-            if (ksplit > 32) ksplit = 32;
-            if (ksplit < 1) ksplit = 1;
+        if (tiles < 2 * 512) {
+            int smax = nk / 6;                           // keep >= 6 chunks (192 of K) per split
+            if (smax > 32) smax = 32;
+            double best = 1e30;
+            for (int sp = 1; sp <= (smax < 1 ? 1 : smax); ++sp) {
+                const int n = tiles * sp, full = n / 512, part = n % 512;
+                const double rounds = full + (part == 0 ? 0.0 : (part <= 256 ? 0.6 : 0.6 + 0.4 * (part - 256) / 256.0));
+                const double t = rounds / sp + 0.003 * sp;   // + slab write/read and combine launch per split
+                if (t < best - 1e-9) { best = t; ksplit = sp; }
+            }
         }
         static const int ks_env = [] { const char *e = getenv("DT_KSPLIT"); return e ? atoi(e) : 0; }();
         if (ks_env > 0) ksplit = ks_env < nk ? ks_env : nk;
