@@ -7,22 +7,29 @@
 //
 //     Out[M = B*H*W, N = Cout] = A[M, K = k*k*Cin] * Wt[N, K]^T
 //
-// A is never materialised: a row m is an output pixel, column k = tap*Cin + ci
-// is read straight from the NHWC activation tensor (zero outside the image).
+// A is never materialised: a row m is an output pixel, column k is read straight
+// from the NHWC activation tensor (zero outside the image).
 //
 // MI355X design notes
 //   * v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak): 64-lane wavefront
 //     tiles of 32x32; each wave owns TM x TN such tiles, 4 waves per workgroup.
 //   * K is consumed in chunks of 32 floats of ONE tap, so a chunk of A is 32
-//     contiguous floats per pixel (128 B -> coalesced float4 loads, 8 lanes/row);
-//     chunk order is channel-slice outer / tap inner for L2 reuse of the 3x3 halo.
-//   * LDS tiles are [rows][32+4] floats: k contiguous so one ds_read_b128 feeds
-//     four MFMA k-steps; the +4 pad makes the 16-lane b128 groups conflict-free.
-//     Lanes 0-31 take k-slots {0..3}, lanes 32-63 {4..7} of every 8 -- A and B
-//     use the same permutation of K so the contraction is unchanged.
-//   * global -> VGPR -> LDS double buffering: next chunk's loads are issued
-//     before the current chunk's MFMAs, written to the other LDS buffer after
-//     them; one barrier per chunk.
+//     contiguous floats per pixel (128 B, coalesced); chunk order is channel-slice
+//     outer / tap inner (k = ((ci/32)*taps + tap)*32 + ci%32) so the nine shifted
+//     re-reads of a slice hit L1/L2.
+//   * Staging (default, DT_GLDS=1): asynchronous global->LDS DMA, 1 KiB per
+//     wave-instruction, no staging registers and no ds_write.  LDS tiles are
+//     unpadded [rows][32] floats; the DMA writes LDS lane-linearly, so the bank
+//     conflict fix is an XOR swizzle of the 16-byte slot applied on the SOURCE
+//     address and again on the fragment reads.  'same' padding is branch-free:
+//     out-of-image taps read a block of zeros.
+//   * One ds_read_b128 feeds four MFMA k-steps: lanes 0-31 take k-slots {0..3},
+//     lanes 32-63 {4..7} of every 8 -- A and B use the same permutation of K, so
+//     the contraction is unchanged.
+//   * Rotated software pipeline, one barrier per chunk; every block of reads /
+//     DMA issues sits after the first k-step of an MFMA group (see the main loop).
+//   * XCD-aware tile order: contiguous tile ranges per XCD, column-grouped, so the
+//     workgroups resident on an XCD share weight and activation panels in its L2.
 //   * ORD_QUAD row order m = ((b*H/2+h2)*W/2+w2)*4 + dy*2+dx puts the four
 //     pixels of a 2x2 pooling window in four consecutive accumulator registers
 //     of one lane (C/D layout row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)), so
@@ -30,6 +37,12 @@
 //   * EPI_GATES: the N axis is packed [j/32][gate][j%32]; a wave's four 32-wide
 //     column tiles are the i,f,c,o pre-activations of the same 32 hidden
 //     channels, so the LSTM cell update happens in registers.
+//   * EPI_PARTIAL: split-K partial sums for small-M layers, combined in split
+//     order by splitk_reduce_kernel (deterministic, no atomics).
+// Build options kept for A/B (profiles/README.md): -DDT_GLDS=0 register staging
+// (global_load -> VGPR -> ds_write, rows padded to 36 floats), -DDT_BK=16 16-deep
+// chunks with three LDS stages and three workgroups per CU (same speed), and the
+// timing-only -DDT_ABLATE=mask builds of tools/ablate.sh.
 #include <cstdlib>
 
 #include "dt_internal.h"
@@ -551,7 +564,6 @@ template <int KS, int ORDER, int EPI>
 static int launch_cfg(hipStream_t st, const ConvArgs &a, int cfg)
 {
     if (cfg == CFG_128x64) return launch_one<KS, 128, 64, 4, 1, ORDER, EPI>(st, a);
-    if (cfg == CFG_256x128) return launch_one<KS, 256, 128, 4, 1, ORDER, EPI>(st, a);
     return launch_one<KS, 128, 128, 2, 2, ORDER, EPI>(st, a);
 }
 
@@ -564,8 +576,6 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
     // layers (all ~64 workgroups resident on an XCD share ONE weight panel) and 2 for 1x1 / gates
     static const int gn_env = [] { const char *e = getenv("DT_TILE_GN"); return e ? atoi(e) : -1; }();
     a.tile_gn = gn_env >= 0 ? gn_env : ((ks == 3 && epi != EPI_GATES) ? 1 : 2);
-    static const int cfg_env = [] { const char *e = getenv("DT_CONV_CFG"); return e ? atoi(e) : -1; }();
-    if (cfg_env >= 0 && cfg == CFG_128x128) cfg = cfg_env;   // A/B experiments
     static float *zeros_dev = nullptr;   // process-wide 256 B of zeros for the padding taps
     if (!zeros_dev) {
         if (hipMalloc(reinterpret_cast<void **>(&zeros_dev), 256) != hipSuccess) return 1;
