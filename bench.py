@@ -133,6 +133,15 @@ def load_traffic(clips, T, size):
 
 
 def main():
+    # the classes print a model summary like Keras does; stdout must carry ONLY the JSON line
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        out = _run()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def _run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -301,10 +310,12 @@ def main():
                                    "sample": "CPU restatement (oracle/, C + OpenMP; NOT Keras/TF, which cannot run "
                                              "here): 1 clip x %d frames %dx%d through detector+ConvLSTM+1x1+decode+"
                                              "association, %.1f s" % (args.cpu_frames, H, W, cpu_s)}
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":
