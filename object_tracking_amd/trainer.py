@@ -1,50 +1,64 @@
-"""Entry points with the reference's names (trainer.py:8,18,22).
+"""Entry points under the reference's names (trainer.py:8, :18, :22 upstream).
 
-The reference's three functions construct a model and call `.train()`; training
-is outside the hot path this build covers, so each function here constructs the
-model and runs the inference part of the same entry point.  Weight files are
-looked up where the reference looks (darknet/yolov2.weights,
-models/MultiObjDetTracker-CHKPNT-*.hdf5|.npz); when absent an IOError explains
-what is missing.
+Upstream each entry point builds a model and calls `.train()`.  Training is not
+part of the path this build covers, so each one builds the corresponding
+MI355X-native model and (for the detector) runs the inference half that the
+upstream function also contains.  Weight files are looked up exactly where the
+reference looks for them; a missing file raises IOError naming it.
+
+    python trainer.py [multi|single|detect]
 """
 import importlib
 import json
 import os
+import sys
 
 from models_detection.KerasYOLO import KerasYOLO
 from models_tracking.MultiObjDetTracker import MultiObjDetTracker
 
+SAMPLE_DIR = os.path.join('darknet', 'data')
+SAMPLE_IMAGES = ('dog.jpg', 'eagle.jpg', 'giraffe.jpg', 'horses.jpg', 'person.jpg')
+
+
+def _tracker_name(default="TinyTracker"):
+    if not os.path.isfile("config.json"):
+        return default
+    with open("config.json") as fh:
+        return json.load(fh)["model_tracker"]["name"]
+
 
 def single_object_tracking():
-    """trainer.py:8-16: instantiate the tracker class named in config.json."""
-    name = "TinyTracker"
-    if os.path.isfile("config.json"):
-        with open("config.json") as config_buffer:
-            name = json.loads(config_buffer.read())["model_tracker"]["name"]
-    tracker_class = getattr(importlib.import_module("models_tracking." + name), name)
-    return tracker_class()
+    """Instantiate the single-object tracker class config.json names
+    (TinyTracker or TinyHeatmapTracker)."""
+    name = _tracker_name()
+    module = importlib.import_module("models_tracking." + name)
+    return getattr(module, name)()
 
 
 def simult_multi_obj_detection_tracking():
-    """trainer.py:18-20."""
+    """Build the simultaneous detect-and-track model (loads its checkpoint)."""
     return MultiObjDetTracker()
 
 
 def keras_yolo_obj_detection():
-    """trainer.py:22-30: detect on darknet's sample images."""
-    prefix = 'darknet/data/'
-    inputs = ['dog.jpg', 'eagle.jpg', 'giraffe.jpg', 'horses.jpg', 'person.jpg']
-    model = KerasYOLO()
-    results = {}
-    for input_instance in inputs:
-        if os.path.isfile(prefix + input_instance):
-            results[input_instance] = model.predict(prefix + input_instance, input_instance)
-    return results
+    """Detect on darknet's sample images that are present; returns {image: boxes}."""
+    detector = KerasYOLO()
+    found = {}
+    for image_name in SAMPLE_IMAGES:
+        source = os.path.join(SAMPLE_DIR, image_name)
+        if os.path.isfile(source):
+            found[image_name] = detector.predict(source, image_name)
+    return found
 
+
+ENTRY_POINTS = {
+    "multi": simult_multi_obj_detection_tracking,
+    "single": single_object_tracking,
+    "detect": keras_yolo_obj_detection,
+}
 
 if __name__ == '__main__':
-    if not os.path.exists('logs'):
-        os.mkdir('logs/')
-    if not os.path.exists('models'):
-        os.mkdir('models/')
-    simult_multi_obj_detection_tracking()
+    for folder in ('logs', 'models'):
+        if not os.path.isdir(folder):
+            os.makedirs(folder)
+    ENTRY_POINTS[sys.argv[1] if len(sys.argv) > 1 else "multi"]()
