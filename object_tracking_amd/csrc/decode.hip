@@ -97,6 +97,7 @@ struct DecodeArgs {
     float *post;        // [batch][ncell][S] (user buffer or internal scratch)
     int chunk_cells;
     int mc;             // ncell rounded up to 64: stride of the LDS candidate / sort arrays
+    int ncp;            // NC rounded up to 4: per-class candidate counters in LDS
 };
 
 __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
@@ -116,17 +117,37 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
     float *s_bx = smem + MC;                                  // [4][MC]
     float *s_red = s_bx + 4 * MC;                             // [16]
     int *s_tot = reinterpret_cast<int *>(s_red + 8);          // [4] (+pad)
-    float *s_dyn = s_red + 16;                                // chunk / sort lists
+    int *s_ccnt = reinterpret_cast<int *>(s_red + 16);        // [ncp] candidates with a non-zero score per class
+    float *s_dyn = s_red + 16 + p.ncp;                        // chunk / sort lists
 
     // ---- phase 1: global max / min of the class logits (utils.py:263-264) ----
     float vmax = -INFINITY, vmin = INFINITY;
     const int nelem = ncell * S;
-    for (int e = tid; e < nelem; e += DEC_THREADS) {
-        const int ch = e % S;
-        if (ch >= 5) {
-            const float v = net[e];
-            vmax = fmaxf(vmax, v);
-            vmin = fminf(vmin, v);
+    for (int c = tid; c < p.ncp; c += DEC_THREADS) s_ccnt[c] = 0;
+    {
+        // channel of element e is e % S; advance it incrementally (DEC_THREADS % S per step) and keep
+        // four independent loads in flight instead of one dependent load + integer modulo per element
+        const int step = DEC_THREADS % S;
+        int ch = tid % S;
+        int e = tid;
+        for (; e + 3 * DEC_THREADS < nelem; e += 4 * DEC_THREADS) {
+            float v[4];
+            int c4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = net[e + u * DEC_THREADS];
+                c4[u] = ch;
+                ch += step;
+                if (ch >= S) ch -= S;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c4[u] >= 5) { vmax = fmaxf(vmax, v[u]); vmin = fminf(vmin, v[u]); }
+        }
+        for (; e < nelem; e += DEC_THREADS) {
+            if (ch >= 5) { const float v = net[e]; vmax = fmaxf(vmax, v); vmin = fminf(vmin, v); }
+            ch += step;
+            if (ch >= S) ch -= S;
         }
     }
     vmax = wave_max(vmax);
@@ -164,7 +185,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
                     const float pr = conf * (r[5 + c] / sum);   // :215
                     const float keep = pr > p.obj_thr ? pr : 0.0f;   // :216
                     r[5 + c] = keep;
-                    any = any || (keep != 0.0f);
+                    if (keep != 0.0f) { any = true; atomicAdd(&s_ccnt[c], 1); }
                 }
                 if (any) {   // :227-231
                     const int cell = c0 + lc;
@@ -201,6 +222,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
         volatile float *u_sc = s_dyn + wave * (4 * MC) + 2 * MC;
         volatile int *u_id = reinterpret_cast<volatile int *>(s_dyn + wave * (4 * MC) + 3 * MC);
         for (int c = wave; c < p.NC; c += DEC_THREADS / 64) {
+            if (s_ccnt[c] < 2) continue;   // fewer than two boxes carry this class: nothing to suppress (wave-uniform)
             // gather candidates with a non-zero score for class c
             int n = 0;
             for (int k0 = 0; k0 < ncand; k0 += 64) {
@@ -312,7 +334,8 @@ int launch_decode(hipStream_t st, const float *netout, long long frame_stride, i
     a.mc = mc;
     const size_t sort_bytes = (size_t)(DEC_THREADS / 64) * 4 * mc * sizeof(float);
     const size_t chunk_bytes = (size_t)chunk * S * sizeof(float);
-    const size_t lds = (size_t)(5 * mc + 16) * sizeof(float) + (sort_bytes > chunk_bytes ? sort_bytes : chunk_bytes);
+    a.ncp = (NC + 3) / 4 * 4;
+    const size_t lds = (size_t)(5 * mc + 16 + a.ncp) * sizeof(float) + (sort_bytes > chunk_bytes ? sort_bytes : chunk_bytes);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(decode_nms_kernel),
