@@ -560,3 +560,50 @@ def test_track_608_vs_oracle(ctx):
         else:   # a score within float noise of the threshold may flip membership; sets must still nearly agree
             assert abs(len(rows) - int(cnt[t])) <= max(2, len(rows) // 50)
     assert cnt.sum() > 0
+
+
+def test_decode_nonsquare_grid_and_three_anchors(ctx):
+    """GH != GW and NB = 3: row/col/anchor decomposition of the cell index"""
+    rs = np.random.RandomState(77)
+    GH, GW, NB, C = 5, 9, 3, 7
+    g = rs.randn(GH, GW, NB, 5 + C).astype(np.float32)
+    g[..., 4] -= 3.0
+    for k in range(14):
+        r, c, b = rs.randint(GH), rs.randint(GW), rs.randint(NB)
+        g[r, c, b, 4] = 4.0 + rs.rand()
+        g[r, c, b, 5 + rs.randint(C)] += 10.0 + rs.rand()
+    anchors = [1.0, 1.5, 2.5, 2.0, 4.0, 6.0]
+    rows, _ = orc.decode_netout(g, 0.4, 0.45, anchors, C)
+    r = ctx.decode(dev(g[None], ctx), 0.4, 0.45, anchors, C)
+    n = int(r["counts"][0])
+    assert n == len(rows) and n > 5
+    got = r["boxes"][0, :n].cpu().numpy()
+    assert np.array_equal(got[:, 7], rows[:, 7]) and np.array_equal(got[:, 5], rows[:, 5])
+    np.testing.assert_allclose(got[:, :7], rows[:, :7], rtol=2e-6, atol=1e-6)
+
+
+def test_error_paths_fail_loudly(ctx):
+    import mi355_dt
+    x = torch.zeros((1, 8, 8, 48), dtype=torch.float32, device=ctx.device)          # Cin not a multiple of 32
+    with pytest.raises(mi355_dt.NativeError):
+        ctx.conv2d(x, np.zeros((3, 3, 48, 32), dtype=np.float32))
+    x = torch.zeros((1, 7, 8, 32), dtype=torch.float32, device=ctx.device)          # odd H with pooling
+    with pytest.raises(mi355_dt.NativeError):
+        ctx.conv2d(x, np.zeros((3, 3, 32, 32), dtype=np.float32), pool=1)
+    big = torch.zeros((1, 26, 26, 5, 17), dtype=torch.float32, device=ctx.device)   # 3380 cells > LDS-resident limit
+    with pytest.raises(mi355_dt.NativeError):
+        ctx.decode(big, 0.5, 0.45, ANCHORS, 12)
+    c2 = mi355_dt.Context()
+    with pytest.raises(mi355_dt.NativeError):                                       # image side not a multiple of 32
+        c2.detector_config(100, 416, 5, 12, ANCHORS)
+    c2.detector_config(64, 64, 5, 12, ANCHORS)
+    frames = torch.zeros((1, 64, 64, 3), dtype=torch.uint8, device=ctx.device)
+    with pytest.raises(mi355_dt.NativeError):                                       # weights not loaded
+        c2.detect_forward(frames)
+    with pytest.raises(mi355_dt.NativeError):                                       # short weight stream
+        c2.load_darknet_weights(np.zeros(1000, dtype=np.float32))
+    with pytest.raises(mi355_dt.NativeError):                                       # tracker head not loaded
+        c2.track_forward(torch.zeros((1, 2, 64, 64, 3), dtype=torch.uint8, device=ctx.device))
+    with pytest.raises(mi355_dt.NativeError):                                       # unsupported frame dtype
+        c2.detect_forward(torch.zeros((1, 64, 64, 3), dtype=torch.float16, device=ctx.device))
+    c2.close()
