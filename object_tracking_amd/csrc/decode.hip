@@ -377,32 +377,35 @@ int launch_bbox_iou(hipStream_t st, const float *pairs, int n, float *iou)
 __global__ __launch_bounds__(64) void associate_kernel(const float *boxes, const int *counts, int T, int cap,
                                                        float thr, int *ids, int *nids)
 {
+    // LDS: the previous and the current frame's boxes (x,y,w,h,label) and ids, so the
+    // strictly sequential greedy loop runs on LDS latency, not on L2 round trips
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    volatile int *claimed = reinterpret_cast<volatile int *>(smem);   // [cap]
+    float *pb = smem;                                   // [5][cap] previous frame (SoA)
+    float *cb = pb + 5 * cap;                           // [5][cap] current frame
+    volatile int *pid = reinterpret_cast<volatile int *>(cb + 5 * cap);   // [cap] previous ids (-1 once claimed)
+    volatile int *cid = pid + cap;                      // [cap] current ids
     const int clip = blockIdx.x, lane = threadIdx.x;
     const float *bx = boxes + (long long)clip * T * cap * DT_BOX_FLOATS;
     const int *cnt = counts + (long long)clip * T;
     int *id = ids + (long long)clip * T * cap;
     int next_id = 0;
+    int np = 0;
     for (int t = 0; t < T; ++t) {
         const int n = min(cnt[t], cap);
-        const int np = t > 0 ? min(cnt[t - 1], cap) : 0;
-        for (int j = lane; j < cap; j += 64) {
-            claimed[j] = 0;
-            id[t * cap + j] = -1;
-        }
         const float *cur = bx + (long long)t * cap * DT_BOX_FLOATS;
-        const float *prv = bx + (long long)(t - 1) * cap * DT_BOX_FLOATS;
+        for (int j = lane; j < n; j += 64) {
+            const float *q = cur + j * 8;
+            cb[j] = q[0]; cb[cap + j] = q[1]; cb[2 * cap + j] = q[2]; cb[3 * cap + j] = q[3]; cb[4 * cap + j] = q[5];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
         for (int i = 0; i < n; ++i) {
-            const float ax = cur[i * 8 + 0], ay = cur[i * 8 + 1], aw = cur[i * 8 + 2], ah = cur[i * 8 + 3];
-            const float al = cur[i * 8 + 5];
+            const float ax = cb[i], ay = cb[cap + i], aw = cb[2 * cap + i], ah = cb[3 * cap + i], al = cb[4 * cap + i];
             float best = -1.0f;
             int bj = 0x7fffffff;
             for (int j = lane; j < np; j += 64) {
-                if (claimed[j]) continue;
-                const float *q = prv + j * 8;
-                if (q[5] != al) continue;
-                const float iou = bbox_iou_ref(ax, ay, aw, ah, q[0], q[1], q[2], q[3]);
+                if (pid[j] < 0 || pb[4 * cap + j] != al) continue;      // claimed, or another label
+                const float iou = bbox_iou_ref(ax, ay, aw, ah, pb[j], pb[cap + j], pb[2 * cap + j], pb[3 * cap + j]);
                 if (iou >= thr && iou > best) { best = iou; bj = j; }   // ascending j per lane: keeps lowest j on ties
             }
 #pragma unroll
@@ -413,15 +416,25 @@ __global__ __launch_bounds__(64) void associate_kernel(const float *boxes, const
             }
             int my_id;
             if (best >= 0.0f) {
-                my_id = id[(t - 1) * cap + bj];
-                if (lane == 0) claimed[bj] = 1;
+                my_id = pid[bj];
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) pid[bj] = -1;            // claimed
             } else {
                 my_id = next_id++;
             }
-            if (lane == 0) id[t * cap + i] = my_id;
+            if (lane == 0) cid[i] = my_id;
             __builtin_amdgcn_wave_barrier();
         }
-        __threadfence_block();
+        // publish this frame's ids, then it becomes the previous frame
+        for (int j = lane; j < cap; j += 64) id[t * cap + j] = j < n ? cid[j] : -1;
+        for (int j = lane; j < n; j += 64) {
+            pb[j] = cb[j]; pb[cap + j] = cb[cap + j]; pb[2 * cap + j] = cb[2 * cap + j];
+            pb[3 * cap + j] = cb[3 * cap + j]; pb[4 * cap + j] = cb[4 * cap + j];
+            pid[j] = cid[j];
+        }
+        np = n;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) nids[clip] = next_id;
 }
@@ -430,8 +443,15 @@ int launch_associate(hipStream_t st, const float *boxes, const int *counts, int 
                      int *ids, int *nids)
 {
     if (n_clips <= 0) return 0;
-    const size_t lds = (size_t)cap * sizeof(int);
-    if (lds > 64 * 1024) return 2;
+    const size_t lds = (size_t)cap * 12 * sizeof(float);   // 2 x 5 box fields + 2 id arrays
+    if (lds > 160 * 1024) return 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(associate_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return 1;
+        attr_done = true;
+    }
     hipLaunchKernelGGL(associate_kernel, dim3((unsigned)n_clips), dim3(64), lds, st, boxes, counts, T, cap, thr, ids,
                        nids);
     return hipGetLastError() == hipSuccess ? 0 : 1;

@@ -192,14 +192,14 @@ __global__ __launch_bounds__(128) void lstm_step_kernel(const float *xproj, long
             f32x4 x0[8], x1[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int bb = min(g0 + u, bn - 1);     // clamp: tail lanes re-read the last row
+                const int bb = min(g0 + u, bn - 1);     // clamp: tail slots re-read the last row
                 const float *hp = h_prev + (long long)(b0 + bb) * h_bs + lane * 8;
                 x0[u] = *reinterpret_cast<const f32x4 *>(hp);
                 x1[u] = *reinterpret_cast<const f32x4 *>(hp + 4);
             }
+            float v[8][4];                               // per-lane partial dot products: 8 tracks x 4 gates
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                float s[4];
+            for (int u = 0; u < 8; ++u)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float a = x0[u][0] * w[g][0];
@@ -210,10 +210,40 @@ __global__ __launch_bounds__(128) void lstm_step_kernel(const float *xproj, long
                     a = __fmaf_rn(x1[u][1], w[g][5], a);
                     a = __fmaf_rn(x1[u][2], w[g][6], a);
                     a = __fmaf_rn(x1[u][3], w[g][7], a);
-                    s[g] = wave_sum(a);
+                    v[u][g] = a;
                 }
-                if (lane == g0 + u) { keep[0] = s[0]; keep[1] = s[1]; keep[2] = s[2]; keep[3] = s[3]; }
+            // Wavefront reduce-scatter: three halving exchanges (lane^32, ^16, ^8) leave each lane with
+            // ONE track's four gate sums over 8 lanes (16+8+4 shuffles instead of 32 butterflies of 6),
+            // three butterfly steps (^4, ^2, ^1) finish them.  Track held by a lane: bits 5,4,3 of its id.
+#define HALVE(OFF, N)                                                        \
+    {                                                                        \
+        const bool up = (lane & (OFF)) != 0;                                 \
+        _Pragma("unroll") for (int u = 0; u < (N); ++u)                      \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                  \
+                const float send = up ? v[u][g] : v[u + (N)][g];             \
+                const float keep = up ? v[u + (N)][g] : v[u][g];             \
+                v[u][g] = keep + __shfl_xor(send, (OFF));                    \
+            }                                                                \
+    }
+            HALVE(32, 4)
+            HALVE(16, 2)
+            HALVE(8, 1)
+#undef HALVE
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v[0][g] += __shfl_xor(v[0][g], o);
+            const int tr = g0 + (((lane >> 5) & 1) << 2 | ((lane >> 4) & 1) << 1 | ((lane >> 3) & 1));
+            // hand the sums to lane `tr` (the lane that owns this track in the update below)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // source lane for track t of this group: bits 5,4,3 = t, low bits 0
+                const int t = (lane - g0) & 7;
+                const int src = ((t >> 2) & 1) << 5 | ((t >> 1) & 1) << 4 | (t & 1) << 3;
+                const float r = __shfl(v[0][g], src);
+                if (lane >= g0 && lane < g0 + 8) keep[g] = r;
             }
+            (void)tr;
         }
         if (lane < bn) {
             const int b = b0 + lane;
