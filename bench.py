@@ -151,6 +151,7 @@ def _run():
     ap.add_argument("--clips", type=int, default=48, help="clips per GPU per step (track)")
     ap.add_argument("--T", type=int, default=30)
     ap.add_argument("--size", type=int, default=416)
+    ap.add_argument("--boxes", type=int, default=32, help="boxes/frame the synthetic tracker head is calibrated to (track)")
     ap.add_argument("--batch", type=int, default=8, help="frames per step (detect)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--h2d", action="store_true", help="also copy the frames from pinned host memory every step (PCIe-inclusive rate; never the headline value)")
@@ -166,7 +167,7 @@ def _run():
 
     if args.workload == "track":
         frames = make_frames(args.clips, args.T, H, W, device, seed0=42 + 100 * rank)
-        trk, blob, tw = build_tracker(H, W, args.T, 32, frames)
+        trk, blob, tw = build_tracker(H, W, args.T, args.boxes, frames)
         ctx = trk.model.ctx
         frames_per_step = args.clips * args.T
         gflop_per_frame = GFLOP_TRACK_416 * (H * W) / (416.0 * 416.0)
@@ -177,7 +178,7 @@ def _run():
             src = frames
             if host_frames is not None:
                 frames.copy_(host_frames, non_blocking=True)     # same stream: serialised in front of the step
-            res = trk.track_clips(src, cap=128)
+            res = trk.track_clips(src, cap=max(128, 2 * args.boxes))
             if world > 1:
                 res = gather_detections(res)
             return res
