@@ -107,14 +107,15 @@ __device__ __forceinline__ void decode_row(int m, int H, int W, int &b, int &h, 
 }
 
 template <int KS, int BM, int BN, int WGM, int WGN, int ORDER, int EPI>
-__global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv_igemm_f32(ConvArgs p)
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : WAVES_PER_SIMD)) void conv_igemm_f32(ConvArgs p)
 {
+    constexpr int NW = WGM * WGN;                  // wavefronts per workgroup (4, or 8 for the 256x128 tile)
     constexpr int WTM = BM / WGM, WTN = BN / WGN;  // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;    // MFMA tiles per wave
 #if DT_GLDS
-    constexpr int RPASS = 4 * RPP;                 // rows filled per pass of the 4 waves
+    constexpr int RPASS = NW * RPP;                // rows filled per pass of the NW waves
 #else
-    constexpr int RPASS = 32;
+    constexpr int RPASS = NW * 8;
 #endif
     constexpr int PA = BM / RPASS, PB = BN / RPASS;   // loader passes
     constexpr int TAPS = KS * KS;
@@ -217,12 +218,12 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void conv_igemm_f32(ConvArgs p
         for (int i = 0; i < PA; ++i) {
             const bool ok = (a_mask[i] >> tap) & 1u;
             const float *src = ok ? a_ptr[i] + aoff : p.zeros;   // branch-free 'same' padding
-            float *dst = sA + (buf * BM + (4 * i + wave_u) * RPP) * LDK;
+            float *dst = sA + (buf * BM + (NW * i + wave_u) * RPP) * LDK;
             __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)dst, 16, 0, DT_DMA_AUX);
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            float *dst = sB + (buf * BN + (4 * i + wave_u) * RPP) * LDK;
+            float *dst = sB + (buf * BN + (NW * i + wave_u) * RPP) * LDK;
             __builtin_amdgcn_global_load_lds((gptr_t *)(b_ptr[i] + kc * KCH), (lptr_t *)dst, 16, 0, DT_DMA_AUX);
         }
     };
@@ -556,7 +557,7 @@ static int launch_one(hipStream_t st, const ConvArgs &a, int ksplit = 1)
             return 1;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ntn), (unsigned)ksplit), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ntn), (unsigned)ksplit), dim3(64 * WGM * WGN), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -564,6 +565,8 @@ template <int KS, int ORDER, int EPI>
 static int launch_cfg(hipStream_t st, const ConvArgs &a, int cfg)
 {
     if (cfg == CFG_128x64) return launch_one<KS, 128, 64, 4, 1, ORDER, EPI>(st, a);
+    if (cfg == CFG_256x128) return launch_one<KS, 256, 128, 4, 2, ORDER, EPI>(st, a);   // 8 waves, 1 workgroup per CU
+    if (cfg == CFG_256x256) return launch_one<KS, 256, 256, 4, 4, ORDER, EPI>(st, a);   // 16 waves, 1 workgroup per CU
     return launch_one<KS, 128, 128, 2, 2, ORDER, EPI>(st, a);
 }
 
@@ -576,6 +579,16 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
     // layers (all ~64 workgroups resident on an XCD share ONE weight panel) and 2 for 1x1 / gates
     static const int gn_env = [] { const char *e = getenv("DT_TILE_GN"); return e ? atoi(e) : -1; }();
     a.tile_gn = gn_env >= 0 ? gn_env : ((ks == 3 && epi != EPI_GATES) ? 1 : 2);
+    // DT_CONV_CFG forces a tile configuration for the 128-wide-or-wider layers (A/B runs and the
+    // tests that exercise every configuration at small shapes); read per call on purpose
+    if (const char *e = getenv("DT_CONV_CFG")) {
+        const int forced = atoi(e);
+        if (forced >= 0 && cfg != CFG_128x64 && epi != EPI_PARTIAL) cfg = forced;
+    }
+    if (cfg == CFG_256x256) {   // the column tile may only read weight rows that exist
+        const int have = a.npad ? a.npad : (a.N + 127) / 128 * 128;
+        if (have < (a.N + 255) / 256 * 256) cfg = CFG_256x128;
+    }
     static float *zeros_dev = nullptr;   // process-wide 256 B of zeros for the padding taps
     if (!zeros_dev) {
         if (hipMalloc(reinterpret_cast<void **>(&zeros_dev), 256) != hipSuccess) return 1;
@@ -585,6 +598,7 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
     if (a.Cin % KCH != 0 || a.K != ks * ks * a.Cin) return 2;
     if (epi == EPI_GATES) {
         if (order != ORD_LINEAR) return 2;
+        if (ks == 3 && cfg == CFG_256x256) return launch_one<3, 256, 256, 8, 2, ORD_LINEAR, EPI_GATES>(st, a);   // 16 waves
         if (ks == 3) return launch_one<3, 128, 128, 4, 1, ORD_LINEAR, EPI_GATES>(st, a);
         return launch_one<1, 128, 128, 4, 1, ORD_LINEAR, EPI_GATES>(st, a);
     }

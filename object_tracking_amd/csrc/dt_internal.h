@@ -43,6 +43,7 @@ struct ConvArgs {
     long long c_bs;
     int c_ld;
     int B, H, W, Cin, N, M, K;
+    int npad;     // rows of wt that exist (0 = N rounded up to 128); 256-wide column tiles need N rounded up to 256
     float slope;  // LeakyReLU slope; 1.0f = linear
     int act;      // 0: LeakyReLU(slope), 1: sigmoid (Dense heads)
     const float *zeros; // >= 16 B of device zeros: source of out-of-image taps (set by launch_conv_igemm)
@@ -52,7 +53,7 @@ struct ConvArgs {
 };
 
 // Tile configurations of the MFMA kernel
-enum { CFG_128x128 = 0, CFG_128x64 = 1 };
+enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_256x128 = 2, CFG_256x256 = 3 };
 
 int launch_conv_igemm(hipStream_t st, const ConvArgs &a, int ks, int order, int epi, int cfg);
 int launch_splitk_reduce(hipStream_t st, const float *slab, int S, long long M, int N, const float *bias, float slope,

@@ -607,3 +607,36 @@ def test_error_paths_fail_loudly(ctx):
     with pytest.raises(mi355_dt.NativeError):                                       # unsupported frame dtype
         c2.detect_forward(torch.zeros((1, 64, 64, 3), dtype=torch.float16, device=ctx.device))
     c2.close()
+
+
+@pytest.mark.parametrize("cfg", ["2", "3"])
+def test_conv_tile_configurations_forced(ctx, cfg, monkeypatch):
+    """The 8-wave 256x128 and 16-wave 256x256 tiles are chosen by a batch-size heuristic; force
+    them here (DT_CONV_CFG) so that plain / pooled / pooled+skip / ConvLSTM-gate epilogues, M and N
+    edges are checked at small shapes."""
+    monkeypatch.setenv("DT_CONV_CFG", cfg)
+    rs = np.random.RandomState(int(cfg))
+    for (B, H, W, Cin, k, Cout, pool) in [(2, 20, 18, 32, 3, 256, 0), (1, 26, 26, 64, 3, 512, 1), (2, 12, 8, 64, 3, 256, 2),
+                                          (3, 13, 13, 96, 1, 300, 0)]:
+        x = rs.randn(B, H, W, Cin).astype(np.float32)
+        w = (rs.randn(k, k, Cin, Cout) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float32)
+        b = rs.randn(Cout).astype(np.float32)
+        ref = orc.conv2d(x, w, b)
+        ref = np.where(ref > 0, ref, 0.1 * ref).astype(np.float32)
+        got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=pool)
+        if pool == 0:
+            assert relerr(got.cpu().numpy(), ref) < 2e-5
+        elif pool == 1:
+            assert relerr(got.cpu().numpy(), orc.maxpool2(ref)) < 2e-5
+        else:
+            assert relerr(got[0].cpu().numpy(), ref) < 2e-5 and relerr(got[1].cpu().numpy(), orc.maxpool2(ref)) < 2e-5
+    # ConvLSTM gates epilogue on the forced tile (U = 64 -> N = 256)
+    B, H, W, Cx, U = 2, 9, 7, 32, 64
+    x = rs.randn(B, H, W, Cx).astype(np.float32)
+    h = (rs.randn(B, H, W, U) * .5).astype(np.float32); c = rs.randn(B, H, W, U).astype(np.float32)
+    Wk = (rs.randn(3, 3, Cx, 4 * U) * .05).astype(np.float32); Uk = (rs.randn(3, 3, U, 4 * U) * .05).astype(np.float32)
+    bb = (rs.randn(4 * U) * .1).astype(np.float32)
+    rh, rc = orc.convlstm_step(x, h, c, Wk, Uk, bb)
+    gh, gc = ctx.convlstm_step(dev(x, ctx), dev(h, ctx), dev(c, ctx), Wk, Uk, bb)
+    np.testing.assert_allclose(gh.cpu().numpy(), rh, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(gc.cpu().numpy(), rc, rtol=1e-4, atol=2e-5)
