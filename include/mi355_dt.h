@@ -171,6 +171,23 @@ DT_API int dt_rect_from_heatmap(dt_ctx *ctx, const float *d_heat, int n, int hma
 DT_API int dt_top_box(dt_ctx *ctx, const float *d_boxes, const int *d_counts, int n_frames,
                int cap, float *d_out4);
 
+/* ---- training-target encoding (the step before the path when fine-tuning) ----
+ * Replaces the object-coordinate fix at the end of BaseBatchGenerator.aug_image
+ * (utility/preprocessing.py:171-188) + BatchGenerator.output_from_instance's y / b construction
+ * (:214-293).  float64 like the reference's Python floats; bit-exact.
+ *   d_objs   [n_frames, cap, 5] int32   xmin, ymin, xmax, ymax, LABELS index (-1: name not in LABELS)
+ *   d_counts [n_frames] int32           objects per frame
+ *   d_dims   [n_frames, 2] int32        original image (width, height)
+ *   d_aug    [n_frames, 4] float64      the augmentation draw (scale, offx, offy, flip) of
+ *                                       aug_image :150-166, or NULL for augment=False
+ *   h_anchors [2*nb_box] float64 (host) ANCHORS
+ *   d_y [n_frames, grid_h, grid_w, nb_box, 5+nb_class] float64, d_b [n_frames, true_box_buffer, 4] float64
+ *   (b is the reference's (1,1,1,TRUE_BOX_BUFFER,4) block without the unit axes) */
+DT_API int dt_encode_targets(dt_ctx *ctx, const int *d_objs, const int *d_counts, const int *d_dims,
+                      const double *d_aug, int n_frames, int cap, int grid_h, int grid_w, int nb_box,
+                      int nb_class, int image_h, int image_w, int true_box_buffer,
+                      const double *h_anchors, double *d_y, double *d_b);
+
 /* ---- layer-level entry points (used by the parity tests) --------------- */
 /* Conv2D 'same' stride 1 (+ optional folded bias, LeakyReLU slope, fused 2x2
  * maxpool) through the MFMA implicit-GEMM kernel.  h_kernel is Keras HWIO

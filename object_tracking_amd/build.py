@@ -15,12 +15,13 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmi355_dt.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-# decode.hip restates numpy float32 arithmetic op for op: no FMA contraction there.
+# decode.hip / targets.hip restate numpy / Python float arithmetic op for op: no FMA contraction there.
 SOURCES = {
     "conv_igemm.hip": [],
     "conv1.hip": [],
     "ingest.hip": [],
     "decode.hip": ["-ffp-contract=off"],
+    "targets.hip": ["-ffp-contract=off"],
     "recurrent.hip": [],
     "network.hip": [],
 }

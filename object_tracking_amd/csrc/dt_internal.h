@@ -87,6 +87,10 @@ int launch_rect_from_heatmap(hipStream_t st, const float *heat, int n, int hs, f
 void ingest_tables(int src, int dst, int *tab);
 int launch_ingest_resize(hipStream_t st, const unsigned char *src, int n, int Hs, int Ws, unsigned char *dst, int Hd,
                          int Wd, const int *xt, const int *yt);
+#define DT_MAX_ANCHOR_BOXES 16
+int launch_encode_targets(hipStream_t st, const int *objs, const int *counts, const int *dims, const double *aug,
+                          int n, int cap, int GH, int GW, int NB, int C, int IH, int IW, int TBB,
+                          const double *anchors_host, double *y, double *b);
 int launch_top_box(hipStream_t st, const float *boxes, const int *counts, int n_frames, int cap, float *out4);
 
 int launch_convlstm_gates_only(hipStream_t st, const float *xproj, long long xp_bs, int xp_ld, float *cstate,

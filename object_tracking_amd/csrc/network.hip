@@ -772,6 +772,24 @@ extern "C" int dt_heatmap_from_xywh64(dt_ctx *ctx, const double *d_xywh, int n, 
     return DT_OK;
 }
 
+extern "C" int dt_encode_targets(dt_ctx *ctx, const int *d_objs, const int *d_counts, const int *d_dims,
+                                 const double *d_aug, int n_frames, int cap, int grid_h, int grid_w, int nb_box,
+                                 int nb_class, int image_h, int image_w, int true_box_buffer,
+                                 const double *h_anchors, double *d_y, double *d_b)
+{
+    if (!ctx || !d_objs || !d_counts || !d_dims || !h_anchors || !d_y || !d_b || n_frames < 0)
+        return dt_fail(ctx, DT_ERR_ARG, "bad argument");
+    ProfScope ps(ctx, "encode_targets", 0.0,
+                 8.0 * n_frames * ((double)grid_h * grid_w * nb_box * (5 + nb_class) + 4.0 * true_box_buffer) +
+                     20.0 * n_frames * cap,
+                 nullptr);
+    const int rc = launch_encode_targets(ctx->stream, d_objs, d_counts, d_dims, d_aug, n_frames, cap, grid_h, grid_w,
+                                         nb_box, nb_class, image_h, image_w, true_box_buffer, h_anchors, d_y, d_b);
+    if (rc == 2) return dt_fail(ctx, DT_ERR_ARG, "encode_targets: unsupported shape (nb_box <= %d)", DT_MAX_ANCHOR_BOXES);
+    if (rc) return dt_fail(ctx, DT_ERR_DEVICE, "encode_targets launch failed");
+    return DT_OK;
+}
+
 extern "C" int dt_rect_from_heatmap(dt_ctx *ctx, const float *d_heat, int n, int hmap_size, float thresh, int *d_rect)
 {
     if (!ctx || !d_heat || !d_rect || hmap_size < 1) return dt_fail(ctx, DT_ERR_ARG, "bad argument");

@@ -24,7 +24,7 @@ SYMBOLS = [
     "dt_create", "dt_destroy", "dt_last_error", "dt_set_stream", "dt_abi_version",
     "dt_detector_config", "dt_load_darknet_weights", "dt_detect_forward", "dt_detector_tap", "dt_ingest_resize",
     "dt_decode", "dt_bbox_iou", "dt_tracker_load", "dt_track_forward", "dt_associate",
-    "dt_tiny_load", "dt_tiny_forward", "dt_tiny_features", "dt_tiny_sequence", "dt_top_box", "dt_heatmap_from_boxes", "dt_heatmap_from_xywh64", "dt_rect_from_heatmap", "dt_conv2d", "dt_convlstm_step",
+    "dt_tiny_load", "dt_tiny_forward", "dt_tiny_features", "dt_tiny_sequence", "dt_top_box", "dt_heatmap_from_boxes", "dt_heatmap_from_xywh64", "dt_rect_from_heatmap", "dt_encode_targets", "dt_conv2d", "dt_convlstm_step",
     "dt_profile_enable", "dt_profile_reset", "dt_profile_read", "dt_profile_names",
 ]
 
@@ -67,6 +67,7 @@ def load_library():
     L.dt_heatmap_from_boxes.argtypes = [vp, vp, ci, ci, vp]
     L.dt_heatmap_from_xywh64.argtypes = [vp, vp, ci, ci, vp]
     L.dt_rect_from_heatmap.argtypes = [vp, vp, ci, ci, cf, vp]
+    L.dt_encode_targets.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp]
     L.dt_tiny_forward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     L.dt_tiny_features.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
     L.dt_tiny_sequence.argtypes = [vp, vp, ci, ci, vp]
@@ -287,6 +288,28 @@ class Context(object):
         self._sync_stream()
         self._check(self.lib.dt_heatmap_from_xywh64(self.h, _dptr(xywh), n, hmap_size, _dptr(out)), "dt_heatmap_from_xywh64")
         return out
+
+    def encode_targets(self, objs, counts, dims, aug, grid_h, grid_w, nb_box, nb_class, image_h, image_w,
+                       true_box_buffer, anchors):
+        """objs int32 [n,cap,5], counts int32 [n], dims int32 [n,2], aug float64 [n,4] or None ->
+        (y float64 [n,GH,GW,NB,5+C], b float64 [n,TBB,4])  (preprocessing.py:171-188, 214-293)."""
+        t = self.torch
+        assert objs.dtype == t.int32 and counts.dtype == t.int32 and dims.dtype == t.int32
+        assert objs.is_cuda and objs.is_contiguous() and counts.is_contiguous() and dims.is_contiguous()
+        n, cap = objs.shape[0], objs.shape[1]
+        if aug is not None:
+            assert aug.dtype == t.float64 and aug.is_cuda and aug.is_contiguous() and aug.shape == (n, 4)
+        an = np.ascontiguousarray(anchors, dtype=np.float64)
+        assert an.size == 2 * nb_box
+        y = t.empty((n, grid_h, grid_w, nb_box, 5 + nb_class), dtype=t.float64, device=self.device)
+        b = t.empty((n, true_box_buffer, 4), dtype=t.float64, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.dt_encode_targets(self.h, _dptr(objs), _dptr(counts), _dptr(dims),
+                                               _dptr(aug) if aug is not None else None, n, cap, grid_h, grid_w,
+                                               nb_box, nb_class, image_h, image_w, true_box_buffer,
+                                               an.ctypes.data_as(ctypes.c_void_p), _dptr(y), _dptr(b)),
+                    "dt_encode_targets")
+        return y, b
 
     def rect_from_heatmap(self, heat, hmap_size, thresh=0.75):
         """heat [n, hs*hs] -> int32 [n,4] (x1,y1,x2,y2) (utils.generate_rectangle_from_heatmap)."""

@@ -531,6 +531,90 @@ ORC_API void orc_rect_from_heatmap(const float *heat, int n, int hs, float thres
 }
 
 /* ---------------------------------------------------------------------------
+ * Training-target encoding: the coordinate fix at the end of
+ * BaseBatchGenerator.aug_image (utility/preprocessing.py:171-188) followed by
+ * BatchGenerator.output_from_instance's y / b construction (:214-293).  Python
+ * float (= float64) arithmetic, int() truncation toward zero, bbox_iou (utils.py:155-173)
+ * in float64 on BoundBox(0,0,w,h) vs the anchors, strict `max_iou < iou` (first best wins),
+ * later objects overwrite x,y,w,h,conf in a shared (cell, anchor) slot while class bits
+ * accumulate, true_box_index wraps modulo TRUE_BOX_BUFFER.  PINNED by
+ * tests/golden/targets.npz (the reference's own statements exec'd by tools/make_goldens.py).
+ *   objs   [n, cap, 5] int32  xmin, ymin, xmax, ymax, label index (-1: name not in LABELS)
+ *   counts [n]; dims [n,2] = original image (w, h); aug [n,4] = scale, offx, offy, flip or NULL
+ *   y [n, GH, GW, NB, 5+C] float64, b [n, TBB, 4] float64 (both fully written)
+ * ------------------------------------------------------------------------- */
+static double interval_overlap_d(double x1, double x2, double x3, double x4)
+{
+    if (x3 < x1) {
+        if (x4 < x1) return 0.0;
+        return (x2 < x4 ? x2 : x4) - x1;
+    } else {
+        if (x2 < x3) return 0.0;
+        return (x2 < x4 ? x2 : x4) - x3;
+    }
+}
+
+static double bbox_iou_d(double x1, double y1, double w1, double h1, double x2, double y2, double w2, double h2)
+{
+    const double iw = interval_overlap_d(x1 - w1 / 2, x1 + w1 / 2, x2 - w2 / 2, x2 + w2 / 2);
+    const double ih = interval_overlap_d(y1 - h1 / 2, y1 + h1 / 2, y2 - h2 / 2, y2 + h2 / 2);
+    const double inter = iw * ih;
+    return inter / (w1 * h1 + w2 * h2 - inter);
+}
+
+static int fix_coord(int v, int use_aug, double scale, int off, int image, int orig)
+{
+    if (use_aug) v = (int)(v * scale - off);              /* preprocessing.py:174,180 */
+    v = (int)(v * (double)image / orig);                  /* :176,182 */
+    v = v < image ? v : image;                            /* :177,183  max(min(v, IMAGE), 0) */
+    return v > 0 ? v : 0;
+}
+
+ORC_API void orc_encode_targets(const int *objs, const int *counts, const int *dims, const double *aug, int n,
+                                int cap, int GH, int GW, int NB, int C, int IH, int IW, int TBB,
+                                const double *anchors, double *y, double *b)
+{
+    const int S = 5 + C;
+    for (int f = 0; f < n; ++f) {
+        double *yf = y + (size_t)f * GH * GW * NB * S;
+        double *bf = b + (size_t)f * TBB * 4;
+        memset(yf, 0, sizeof(double) * (size_t)GH * GW * NB * S);
+        memset(bf, 0, sizeof(double) * (size_t)TBB * 4);
+        const int w = dims[f * 2], h = dims[f * 2 + 1];
+        const int use_aug = aug != NULL;
+        const double scale = use_aug ? aug[f * 4] : 1.0;
+        const int offx = use_aug ? (int)aug[f * 4 + 1] : 0, offy = use_aug ? (int)aug[f * 4 + 2] : 0;
+        const int flip = use_aug && aug[f * 4 + 3] > 0.5;
+        int tbi = 0;
+        for (int k = 0; k < counts[f]; ++k) {
+            const int *o = objs + ((size_t)f * cap + k) * 5;
+            int xmin = fix_coord(o[0], use_aug, scale, offx, IW, w), xmax = fix_coord(o[2], use_aug, scale, offx, IW, w);
+            const int ymin = fix_coord(o[1], use_aug, scale, offy, IH, h), ymax = fix_coord(o[3], use_aug, scale, offy, IH, h);
+            if (flip) { const int t = xmin; xmin = IW - xmax; xmax = IW - t; }       /* :185-188 */
+            if (!(xmax > xmin && ymax > ymin && o[4] >= 0)) continue;                  /* :224 */
+            const double cx = (.5 * (xmin + xmax)) / ((double)IW / GW);
+            const double cy = (.5 * (ymin + ymax)) / ((double)IH / GH);
+            const int gx = (int)floor(cx), gy = (int)floor(cy);
+            if (!(gx < GW && gy < GH)) continue;                                        /* :233 */
+            const double cw = (xmax - xmin) / ((double)IW / GW), ch = (ymax - ymin) / ((double)IH / GH);
+            int best = -1;
+            double best_iou = -1;
+            for (int a = 0; a < NB; ++a) {                                              /* :246-252 */
+                const double iou = bbox_iou_d(0, 0, cw, ch, 0, 0, anchors[2 * a], anchors[2 * a + 1]);
+                if (best_iou < iou) { best = a; best_iou = iou; }
+            }
+            if (best < 0) best += NB;                                                   /* python index -1 */
+            double *cell = yf + (((size_t)gy * GW + gx) * NB + best) * S;
+            cell[0] = cx; cell[1] = cy; cell[2] = cw; cell[3] = ch; cell[4] = 1.0;      /* :255-256 */
+            cell[5 + o[4]] = 1.0;                                                       /* :257 */
+            double *tb = bf + (size_t)tbi * 4;                                          /* :260 */
+            tb[0] = cx; tb[1] = cy; tb[2] = cw; tb[3] = ch;
+            tbi = (tbi + 1) % TBB;                                                      /* :262-263 */
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------
  * Frame ingest: cv2.resize(image, (IMAGE_H, IMAGE_W)) on uint8 frames
  * (models_detection/KerasYOLO.py:526; interpolation defaults to INTER_LINEAR).
  * PARITY UNPINNED versus OpenCV (cv2 is not part of this image): this is

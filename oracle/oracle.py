@@ -279,6 +279,36 @@ def rect_from_heatmap(heat, hs, thresh=0.75):
     return out
 
 
+def encode_targets(objs, counts, dims, aug, grid_h, grid_w, nb_box, nb_class, image_h, image_w, true_box_buffer,
+                   anchors):
+    """preprocessing.py:171-188 + :214-293 -> (y [n,GH,GW,NB,5+C], b [n,TBB,4]) float64."""
+    objs = np.ascontiguousarray(objs, dtype=np.int32)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    dims = np.ascontiguousarray(dims, dtype=np.int32)
+    n, cap, _ = objs.shape
+    anchors = np.ascontiguousarray(anchors, dtype=np.float64)
+    y = np.empty((n, grid_h, grid_w, nb_box, 5 + nb_class), dtype=np.float64)
+    b = np.empty((n, true_box_buffer, 4), dtype=np.float64)
+    a = None if aug is None else np.ascontiguousarray(aug, dtype=np.float64)
+    lib().orc_encode_targets(_p(objs), _p(counts), _p(dims), _p(a) if a is not None else None, n, cap, grid_h,
+                             grid_w, nb_box, nb_class, image_h, image_w, true_box_buffer, _p(anchors), _p(y), _p(b))
+    return y, b
+
+
+def sequence_windows(folders, seq_len):
+    """create_sequences_from_parsed_annotations (preprocessing.py:79-89) on folder ids: returns the
+    start index of every emitted window, in order -- including the reference's behaviour at folder
+    boundaries (the skipped-forward start is re-emitted for each loop index that lands before it)
+    and its IndexError when the forward skip runs off the end.  Pinned by tests/golden/windows.npz."""
+    folders = list(folders)
+    starts = []
+    for i in range(len(folders) - seq_len + 1):
+        while folders[i] != folders[i + seq_len - 1]:      # IndexError propagates, like the reference
+            i += 1
+        starts.append(i)
+    return starts
+
+
 def tinytracker_forward(feat, det, tt, pool="Global"):
     """TinyTracker / TinyHeatmapTracker graph (TinyTracker.py:25-41,
     TinyHeatmapTracker.py:26-48).  feat [B,T,w,h,c], det [B,T,4 | hs*hs]; tt:

@@ -640,3 +640,111 @@ def test_conv_tile_configurations_forced(ctx, cfg, monkeypatch):
     gh, gc = ctx.convlstm_step(dev(x, ctx), dev(h, ctx), dev(c, ctx), Wk, Uk, bb)
     np.testing.assert_allclose(gh.cpu().numpy(), rh, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(gc.cpu().numpy(), rc, rtol=1e-4, atol=2e-5)
+
+
+# ---- training-target encoding + sequence generators ----------------------
+TARGET_CASES = ["g13_c12", "g13_c12_aug", "g19_c20_wrap", "g13_dense_cell"]
+
+
+def _encode_on_device(ctx, objs, counts, dims, aug, G, C, IM, TBB, anchors):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(ctx.device)
+    y, b = ctx.encode_targets(t(objs), t(counts), t(dims), None if aug is None else t(aug), G, G, 5, C, IM, IM, TBB,
+                              anchors)
+    return y.cpu().numpy(), b.cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", TARGET_CASES)
+def test_encode_targets_bit_exact_vs_reference_golden(ctx, golden_dir, name):
+    """dt_encode_targets against the reference's own statements (preprocessing.py:171-188,214-293)."""
+    z = np.load(os.path.join(golden_dir, "targets.npz"))
+    G, IM, C, TBB = [int(v) for v in z[name + "/cfg"]]
+    aug = z[name + "/aug"] if (name + "/aug") in z.files else None
+    y, b = _encode_on_device(ctx, z[name + "/objs"], z[name + "/counts"], z[name + "/dims"], aug, G, C, IM, TBB,
+                             z["anchors"])
+    assert np.array_equal(y, z[name + "/y"])
+    assert np.array_equal(b, z[name + "/b"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,cap,G,C,TBB,use_aug", [(64, 600, 13, 12, 50, True), (7, 3, 19, 80, 10, False),
+                                                   (1, 1, 13, 1, 1, False), (480, 20, 13, 80, 50, True)])
+def test_encode_targets_bit_exact_vs_oracle(ctx, n, cap, G, C, TBB, use_aug):
+    """Larger and ragged batches (more objects than one pass of the kernel holds, empty frames; the
+    480-frame case is above the size where the zero fill moves from the kernel to memsets)."""
+    rs = np.random.RandomState(n * 7 + cap)
+    IM = 32 * G
+    dims = np.stack([rs.randint(200, 2000, n), rs.randint(200, 1200, n)], 1).astype(np.int32)
+    counts = rs.randint(0, cap + 1, n).astype(np.int32)
+    counts[0] = cap
+    if n > 2:
+        counts[1] = 0
+    objs = np.zeros((n, cap, 5), dtype=np.int32)
+    for i in range(n):
+        w, h = dims[i]
+        x0 = rs.randint(-20, w, cap); y0 = rs.randint(-20, h, cap)
+        objs[i, :, 0] = x0; objs[i, :, 1] = y0
+        objs[i, :, 2] = x0 + rs.randint(-5, w // 2, cap); objs[i, :, 3] = y0 + rs.randint(-5, h // 2, cap)
+        objs[i, :, 4] = rs.randint(-1, C, cap)
+    aug = None
+    if use_aug:
+        sc = rs.uniform(size=n) / 10. + 1.
+        aug = np.stack([sc, np.floor(rs.uniform(size=n) * (sc - 1) * dims[:, 0]),
+                        np.floor(rs.uniform(size=n) * (sc - 1) * dims[:, 1]), rs.binomial(1, .5, n)], 1).astype(np.float64)
+    anchors = np.asarray(ANCHORS, dtype=np.float64)
+    y, b = _encode_on_device(ctx, objs, counts, dims, aug, G, C, IM, TBB, anchors)
+    yo, bo = orc.encode_targets(objs, counts, dims, aug, G, G, 5, C, IM, IM, TBB, anchors)
+    assert np.array_equal(y, yo) and np.array_equal(b, bo)
+    assert (y[..., 4] == 1).sum() > 0 or cap == 1
+
+
+@pytest.mark.gpu
+def test_batch_generators_on_image_files(ctx, tmp_path):
+    """BatchGenerator / BatchSequenceGenerator1 (preprocessing.py:195-371, augment=False): frames through
+    the device resize, targets through dt_encode_targets; checked against the oracle chain."""
+    from PIL import Image
+    from utility.preprocessing import BatchGenerator, BatchSequenceGenerator1
+    from utility.utils import normalize
+    labels = ["car", "person"]
+    cfg = dict(IMAGE_H=96, IMAGE_W=96, GRID_H=3, GRID_W=3, BOX=5, CLASS=2, LABELS=labels, ANCHORS=ANCHORS,
+               BATCH_SIZE=2, TRUE_BOX_BUFFER=6, SEQUENCE_LENGTH=2)
+    rs = np.random.RandomState(12)
+    recs, raw = [], []
+    for folder, n in (("a/", 3), ("b/", 2)):
+        for k in range(n):
+            h, w = int(rs.randint(100, 180)), int(rs.randint(120, 260))
+            rgb = rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+            path = str(tmp_path / ("%s_%d.png" % (folder[0], k)))
+            Image.fromarray(rgb).save(path)
+            raw.append(np.ascontiguousarray(rgb[..., ::-1]))
+            objs = [{"name": labels[int(rs.randint(0, 2))] if j else "tree", "xmin": int(rs.randint(0, w // 2)),
+                     "ymin": int(rs.randint(0, h // 2)), "xmax": int(rs.randint(w // 2, w)),
+                     "ymax": int(rs.randint(h // 2, h))} for j in range(int(rs.randint(1, 5)))]
+            recs.append({"folder": folder, "filename": path, "width": w, "height": h, "object": objs})
+
+    def expect(rec_list):
+        x = np.stack([orc.resize_bilinear_u8(raw[recs.index(r)][None], 96, 96)[0][:, :, ::-1] for r in rec_list])
+        from utility.preprocessing import pack_objects
+        o, c, d = pack_objects(rec_list, labels)
+        y, b = orc.encode_targets(o, c, d, None, 3, 3, 5, 2, 96, 96, 6, np.asarray(ANCHORS, dtype=np.float64))
+        return normalize(x), b, y
+
+    gen = BatchGenerator(list(recs), cfg, shuffle=False, augment=False, norm=normalize, ctx=ctx)
+    assert len(gen) == 3
+    for idx in range(len(gen)):
+        (x, b), y = gen[idx]
+        lo, hi = (idx * 2, idx * 2 + 2) if idx * 2 + 2 <= len(recs) else (len(recs) - 2, len(recs))
+        ex, eb, ey = expect(recs[lo:hi])
+        assert x.shape == (2, 96, 96, 3) and x.dtype == np.float64 and np.array_equal(x, ex)
+        assert b.shape == (2, 1, 1, 1, 6, 4) and np.array_equal(b.reshape(2, 6, 4), eb)
+        assert y.shape == (2, 3, 3, 5, 7) and np.array_equal(y, ey)
+    seq = BatchSequenceGenerator1(list(recs), cfg, shuffle=False, augment=False, norm=normalize, ctx=ctx)
+    # windows of 2 inside one folder: a0a1, a1a2, (a2b0 slides to) b0b1, b0b1
+    assert [[recs.index(r) for r in win] for win in seq.images] == [[0, 1], [1, 2], [3, 4], [3, 4]]
+    (x, b), (y1, y2) = seq[0]
+    ex, eb, ey = expect([recs[0], recs[1], recs[1], recs[2]])
+    assert x.shape == (2, 2, 96, 96, 3) and np.array_equal(x.reshape(4, 96, 96, 3), ex)
+    assert b.shape == (2, 2, 1, 1, 1, 6, 4) and np.array_equal(b.reshape(4, 6, 4), eb)
+    assert y1 is y2 and y1.shape == (2, 2, 3, 3, 5, 7) and np.array_equal(y1.reshape(4, 3, 3, 5, 7), ey)
+    with pytest.raises(NotImplementedError):
+        BatchGenerator(list(recs), cfg, augment=True, ctx=ctx)

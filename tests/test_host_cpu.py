@@ -212,3 +212,52 @@ def test_gather_frame_rows_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "RANK %d OK" % r in o, o
+
+
+# ---- data-side host logic (utility/preprocessing.py) ----------------------
+def test_parse_annotation_matches_reference_golden(golden_dir):
+    """preprocessing.py:12-77 exec'd on tests/golden/ann/ by tools/make_goldens.py.  os.walk's
+    directory order is the file system's, so images are compared keyed by file name."""
+    import json
+    from utility.preprocessing import parse_annotation
+    want = json.load(open(os.path.join(golden_dir, "parse_annotation.json")))
+    cwd = os.getcwd()
+    os.chdir(golden_dir)
+    try:
+        for key, labels in [("all", []), ("car_person", ["car", "person"]), ("none", ["zebra"])]:
+            imgs, seen = parse_annotation("ann/", "frames/", labels)
+            assert seen == want[key]["seen"]
+            by_name = lambda lst: sorted(lst, key=lambda r: r["filename"])
+            assert by_name(imgs) == by_name(want[key]["images"])
+    finally:
+        os.chdir(cwd)
+    assert len(want["all"]["images"]) == 4 and want["none"]["images"] == []
+
+
+def test_sequence_windows_match_reference_golden(golden_dir):
+    from utility.preprocessing import create_sequences_from_parsed_annotations, sequence_window_starts
+    z = np.load(os.path.join(golden_dir, "windows.npz"))
+    for i in range(int(z["n"])):
+        folders, T = z["folders_%d" % i].tolist(), int(z["T_%d" % i])
+        data = [{"folder": "f%d/" % f, "i": k} for k, f in enumerate(folders)]
+        if int(z["err_%d" % i]):
+            with pytest.raises(IndexError):
+                create_sequences_from_parsed_annotations(data, T)
+            continue
+        assert sequence_window_starts(folders, T) == z["starts_%d" % i].tolist()
+        seqs = create_sequences_from_parsed_annotations(data, T)
+        assert [s[0]["i"] for s in seqs] == z["starts_%d" % i].tolist()
+        assert all(len(s) == T and len({d["folder"] for d in s}) == 1 for s in seqs)
+
+
+def test_pack_objects_layout():
+    from utility.preprocessing import pack_objects
+    recs = [{"width": 640, "height": 480, "object": [{"name": "b", "xmin": 1, "ymin": 2, "xmax": 3, "ymax": 4},
+                                                      {"name": "zz", "xmin": 5, "ymin": 6, "xmax": 7, "ymax": 8}]},
+            {"width": 320, "height": 240, "object": []}]
+    objs, counts, dims = pack_objects(recs, ["a", "b", "b"])
+    assert objs.shape == (2, 2, 5) and objs.dtype == np.int32
+    assert objs[0].tolist() == [[1, 2, 3, 4, 1], [5, 6, 7, 8, -1]]      # first index of a repeated label
+    assert counts.tolist() == [2, 0] and dims.tolist() == [[640, 480], [320, 240]]
+    with pytest.raises(ValueError):
+        pack_objects(recs, ["a"], cap=1)

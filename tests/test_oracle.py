@@ -152,3 +152,40 @@ def test_oracle_heatmap_helpers_match_reference_golden(golden_dir):
     d = np.load(os.path.join(golden_dir, "heatmap.npz"))
     assert np.array_equal(orc.heatmap_from_boxes(d["box4"], 32), d["heat"])
     assert np.array_equal(orc.rect_from_heatmap(d["soft"].reshape(64, -1), 32, 0.75), d["rects"])
+
+
+TARGET_CASES = ["g13_c12", "g13_c12_aug", "g19_c20_wrap", "g13_dense_cell"]
+
+
+def load_target_case(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, "targets.npz"))
+    G, IM, C, TBB = [int(v) for v in z[name + "/cfg"]]
+    aug = z[name + "/aug"] if (name + "/aug") in z.files else None
+    return dict(objs=z[name + "/objs"], counts=z[name + "/counts"], dims=z[name + "/dims"], aug=aug, G=G, IM=IM,
+                C=C, TBB=TBB, anchors=z["anchors"], y=z[name + "/y"], b=z[name + "/b"])
+
+
+@pytest.mark.parametrize("name", TARGET_CASES)
+def test_oracle_encode_targets_matches_reference_golden(golden_dir, name):
+    """preprocessing.py:171-188,214-293 (exec'd by tools/make_goldens.py): float64, bit-exact."""
+    c = load_target_case(golden_dir, name)
+    y, b = orc.encode_targets(c["objs"], c["counts"], c["dims"], c["aug"], c["G"], c["G"], 5, c["C"], c["IM"],
+                              c["IM"], c["TBB"], c["anchors"])
+    assert np.array_equal(y, c["y"])
+    assert np.array_equal(b, c["b"])
+    assert (c["y"][..., 4] == 1).sum() > 0
+
+
+def test_oracle_sequence_windows_match_reference_golden(golden_dir):
+    """preprocessing.py:79-89, including its duplicated windows and IndexError at folder boundaries."""
+    z = np.load(os.path.join(golden_dir, "windows.npz"))
+    seen_err = False
+    for i in range(int(z["n"])):
+        folders, T = z["folders_%d" % i], int(z["T_%d" % i])
+        if int(z["err_%d" % i]):
+            seen_err = True
+            with pytest.raises(IndexError):
+                orc.sequence_windows(folders, T)
+        else:
+            assert orc.sequence_windows(folders, T) == z["starts_%d" % i].tolist()
+    assert seen_err

@@ -77,6 +77,20 @@ def main():
     ms = timeit(lambda: ctx.associate(boxes, counts, 0.3))
     row("associate", "8 clips x 30 frames, ~%d boxes" % int(counts.float().mean()), ms, boxes.numel() * 4 * 2.0,
         "(sequential in t and box: latency-bound)")
+    # training-target encoding (8f.3): the kernel writes y and b in full, float64
+    for (n, cap, G, C, TBB) in ((1024, 50, 13, 12, 50), (1024, 50, 13, 80, 50), (256, 128, 19, 12, 50)):
+        rs = np.random.RandomState(3)
+        IM = 32 * G
+        dims = np.stack([rs.randint(400, 2000, n), rs.randint(300, 1200, n)], 1).astype(np.int32)
+        objs = np.zeros((n, cap, 5), dtype=np.int32)
+        objs[:, :, 0] = rs.randint(0, 400, (n, cap)); objs[:, :, 1] = rs.randint(0, 300, (n, cap))
+        objs[:, :, 2] = objs[:, :, 0] + rs.randint(1, 300, (n, cap)); objs[:, :, 3] = objs[:, :, 1] + rs.randint(1, 300, (n, cap))
+        objs[:, :, 4] = rs.randint(0, C, (n, cap))
+        counts = rs.randint(0, cap + 1, n).astype(np.int32)
+        d_o, d_c, d_d = [torch.from_numpy(a).to(dev) for a in (objs, counts, dims)]
+        ms = timeit(lambda: ctx.encode_targets(d_o, d_c, d_d, None, G, G, 5, C, IM, IM, TBB, ANCHORS))
+        row("encode_targets", "%d x %dx%dx5x%d f64, <=%d obj" % (n, G, G, 5 + C, cap), ms,
+            8.0 * n * (G * G * 5 * (5 + C) + 4 * TBB) + 20.0 * n * cap, "(write-only: y and b are produced in full)")
     # TinyTracker pieces
     tw = synth.synth_tiny_weights(512)
     ctx.tiny_load(516, 512, tw["kernel"], tw["recurrent"], tw["bias"], tw["dense_kernel"], tw["dense_bias"])

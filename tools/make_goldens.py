@@ -66,6 +66,149 @@ def run_case(ns, netout, obj_thr, nms_thr, nb_class):
     return rows, cls, work
 
 
+def make_preprocessing_goldens(ns):
+    """SURVEY.md 8f.3.  preprocessing.py cannot be imported (py2 print at l.334, cv2/imgaug/keras
+    imports), so three of its statement ranges are exec'd from the file at run time:
+      79-89   create_sequences_from_parsed_annotations (as is)
+      172-188 the `for obj in all_objs` coordinate fix of aug_image (loop body run with the
+              augmentation draw (scale, offx, offy, flip) given instead of sampled; image I/O skipped)
+      214-293 BatchGenerator.output_from_instance (as a method of a stand-in `self` whose
+              aug_image runs the 172-188 range)
+    BoundBox / bbox_iou come from the utils.py slice above."""
+    import copy
+    import textwrap
+    path = os.path.join(REF, "utility", "preprocessing.py")
+    with open(path) as f:
+        lines = f.read().split("\n")
+    wns = {}
+    exec(compile("\n".join(lines[78:89]), path + "[79-89]", "exec"), wns)
+    make_windows = wns["create_sequences_from_parsed_annotations"]
+    fix_src = compile(textwrap.dedent("\n".join(lines[171:188])), path + "[172-188]", "exec")
+    mns = {"np": np, "os": os, "BoundBox": ns["BoundBox"], "bbox_iou": ns["bbox_iou"]}
+    exec(compile(textwrap.dedent("\n".join(lines[213:293])), path + "[214-293]", "exec"), mns)
+    encode = mns["output_from_instance"]
+
+    # windows: folder id per frame -> list of start indices (or IndexError)
+    rs = np.random.RandomState(21)
+    wcases = []
+    for k, (runs, T) in enumerate([([7], 4), ([5, 6, 4], 4), ([3, 9, 2, 8], 4), ([4, 4], 4), ([10, 1, 10], 3),
+                                   ([2, 2, 2, 12], 5), ([6, 3], 4), ([4], 4), ([3], 4), ([9, 9, 9], 1)]):
+        folders = np.concatenate([np.full(r, i, dtype=np.int32) for i, r in enumerate(runs)])
+        data = [{"folder": "f%d/" % f, "i": i} for i, f in enumerate(folders)]
+        try:
+            seqs = make_windows(data, T)
+            starts = np.array([s[0]["i"] for s in seqs], dtype=np.int32)
+            assert all([d["i"] for d in s] == list(range(s[0]["i"], s[0]["i"] + T)) for s in seqs)
+            err = 0
+        except IndexError:
+            starts, err = np.zeros(0, dtype=np.int32), 1
+        wcases.append((folders, T, starts, err))
+    np.savez_compressed(os.path.join(OUT, "windows.npz"), n=np.int32(len(wcases)),
+                        **{"folders_%d" % i: c[0] for i, c in enumerate(wcases)},
+                        **{"T_%d" % i: np.int32(c[1]) for i, c in enumerate(wcases)},
+                        **{"starts_%d" % i: c[2] for i, c in enumerate(wcases)},
+                        **{"err_%d" % i: np.int32(c[3]) for i, c in enumerate(wcases)})
+
+
+    # parse_annotation (preprocessing.py:12-77) on the XML fixtures under tests/golden/ann/
+    import json
+    import xml.etree.ElementTree as ET
+    pns = {"os": os, "ET": ET}
+    exec(compile("\n".join(lines[11:77]), path + "[12-77]", "exec"), pns)
+    cwd = os.getcwd()
+    os.chdir(OUT)                      # keep the recorded paths relative
+    try:
+        parsed = {}
+        for key, labels in [("all", []), ("car_person", ["car", "person"]), ("none", ["zebra"])]:
+            imgs, seen = pns["parse_annotation"]("ann/", "frames/", labels)
+            parsed[key] = {"images": imgs, "seen": seen}
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(OUT, "parse_annotation.json"), "w") as f:
+        json.dump(parsed, f, indent=1, sort_keys=True)
+    print("parse_annotation: %s" % {k: len(v["images"]) for k, v in parsed.items()})
+
+    class Stub(object):
+        pass
+
+    def run_encode(cfg, objs_list, dims, aug):
+        n = len(objs_list)
+        y = np.zeros((n, cfg["GRID_H"], cfg["GRID_W"], cfg["BOX"], 5 + cfg["CLASS"]))
+        b = np.zeros((n, cfg["TRUE_BOX_BUFFER"], 4))
+        for i in range(n):
+            st = Stub()
+            st.config, st.debug, st.norm = cfg, False, None
+            st.augment = aug is not None
+            st.anchors = [ns["BoundBox"](0, 0, cfg["ANCHORS"][2 * a], cfg["ANCHORS"][2 * a + 1])
+                          for a in range(len(cfg["ANCHORS"]) // 2)]
+
+            def aug_image(train_instance, augment, i=i, st=st):
+                env = {"self": st, "all_objs": copy.deepcopy(train_instance["object"]), "augment": augment,
+                       "resize": True, "w": int(dims[i][0]), "h": int(dims[i][1]), "int": int, "float": float,
+                       "max": max, "min": min}
+                if augment:
+                    env.update(scale=float(aug[i][0]), offx=int(aug[i][1]), offy=int(aug[i][2]), flip=float(aug[i][3]))
+                exec(fix_src, env)
+                return np.zeros((2, 2, 3)), env["all_objs"]
+            st.aug_image = aug_image
+            (_, bi), yi = encode(st, {"object": objs_list[i], "filename": "x/y.jpg"}, 0)
+            y[i] = yi
+            b[i] = bi[0, 0, 0]
+        return y, b
+
+    labels12 = ["l%d" % i for i in range(12)]
+    labels20 = ["l%d" % i for i in range(20)]
+    out = {}
+    for name, G, IM, labels, TBB, n, max_obj, use_aug, seed in [
+            ("g13_c12", 13, 416, labels12, 50, 12, 40, False, 31),
+            ("g13_c12_aug", 13, 416, labels12, 50, 12, 40, True, 32),
+            ("g19_c20_wrap", 19, 608, labels20, 4, 8, 24, False, 33),
+            ("g13_dense_cell", 13, 416, labels12, 50, 6, 30, False, 34)]:
+        rs = np.random.RandomState(seed)
+        cfg = dict(IMAGE_H=IM, IMAGE_W=IM, GRID_H=G, GRID_W=G, BOX=5, CLASS=len(labels), LABELS=labels,
+                   ANCHORS=ANCHORS, TRUE_BOX_BUFFER=TBB)
+        objs = np.full((n, max_obj, 5), -1, dtype=np.int32)
+        counts = np.zeros(n, dtype=np.int32)
+        dims = np.zeros((n, 2), dtype=np.int32)
+        aug = np.zeros((n, 4)) if use_aug else None
+        objs_list = []
+        for i in range(n):
+            w, h = int(rs.randint(320, 1920)), int(rs.randint(240, 1080))
+            dims[i] = (w, h)
+            if use_aug:
+                scale = rs.uniform() / 10. + 1.
+                aug[i] = (scale, int(rs.uniform() * (scale - 1.) * w), int(rs.uniform() * (scale - 1.) * h),
+                          float(rs.binomial(1, .5)))
+            k = int(rs.randint(0, max_obj + 1)) if i else max_obj
+            counts[i] = k
+            lst = []
+            for j in range(k):
+                if name == "g13_dense_cell":        # many objects in few cells: overwrite + class-bit residue
+                    cx, cy = w * (0.3 + 0.1 * rs.rand()), h * (0.3 + 0.1 * rs.rand())
+                else:
+                    cx, cy = w * rs.rand(), h * rs.rand()
+                bw, bh = w * (0.02 + 0.5 * rs.rand() ** 2), h * (0.02 + 0.5 * rs.rand() ** 2)
+                xmin, xmax = int(round(cx - bw / 2)), int(round(cx + bw / 2))
+                ymin, ymax = int(round(cy - bh / 2)), int(round(cy + bh / 2))
+                kind = rs.randint(0, 12)
+                if kind == 0:
+                    xmax = xmin                        # degenerate -> skipped
+                if kind == 1:
+                    xmin, xmax = w - 3, w + 40         # clamps at the right edge
+                lab = int(rs.randint(0, len(labels))) if kind != 2 else -1     # -1: name not in LABELS
+                objs[i, j] = (xmin, ymin, xmax, ymax, lab)
+                lst.append({"name": labels[lab] if lab >= 0 else "other", "xmin": xmin, "ymin": ymin,
+                            "xmax": xmax, "ymax": ymax})
+            objs_list.append(lst)
+        y, b = run_encode(cfg, objs_list, dims, aug)
+        out.update({name + "/objs": objs, name + "/counts": counts, name + "/dims": dims,
+                    name + "/cfg": np.array([G, IM, len(labels), TBB], dtype=np.int32), name + "/y": y, name + "/b": b})
+        if use_aug:
+            out[name + "/aug"] = aug
+        print("targets %-16s frames %d  objects set %d" % (name, n, int((y[..., 4] == 1).sum())))
+    np.savez_compressed(os.path.join(OUT, "targets.npz"), anchors=np.asarray(ANCHORS, dtype=np.float64), **out)
+
+
 def main():
     ns = load_reference_slice()
     os.makedirs(OUT, exist_ok=True)
@@ -175,6 +318,10 @@ def main():
     # --- normalize known answer (utils.py:150-153) ---
     img = np.arange(256, dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, "normalize.npz"), img=img, out=ns["normalize"](img))
+
+
+    # --- sequence windows + YOLO target encoding (utility/preprocessing.py:79-89, 171-188, 214-293) ---
+    make_preprocessing_goldens(ns)
 
     for s in summary:
         print("%-18s grid %-18s -> %d boxes" % (s[0], s[1], s[2]))
