@@ -19,6 +19,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = {
     "conv_igemm.hip": [],
     "conv1.hip": [],
+    "winograd.hip": [],
     "ingest.hip": [],
     "decode.hip": ["-ffp-contract=off"],
     "targets.hip": ["-ffp-contract=off"],

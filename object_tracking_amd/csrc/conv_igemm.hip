@@ -156,6 +156,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
         tile_n = grp * gn + (rem - tile_m * gw);
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // batched GEMMs (the 16 Winograd positions of csrc/winograd.hip): one problem per blockIdx.z
+    p.in += (long long)blockIdx.z * p.z_in;
+    p.wt += (long long)blockIdx.z * p.z_wt;
+    p.out += (long long)blockIdx.z * p.z_out;
 
     // ---- loader set-up ----------------------------------------------------
     // Register staging: thread -> row lr + 32*i, 16-byte slot tid&7 of the 128-byte chunk row.
@@ -557,7 +561,8 @@ static int launch_one(hipStream_t st, const ConvArgs &a, int ksplit = 1)
             return 1;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ntn), (unsigned)ksplit), dim3(64 * WGM * WGN), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ntn), (unsigned)ksplit, (unsigned)(a.zbatch > 1 ? a.zbatch : 1)),
+                       dim3(64 * WGM * WGN), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -578,7 +583,8 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
     // column tiles per group of the tile order: measured FETCH_SIZE optimum is 1 for the 3x3
     // layers (all ~64 workgroups resident on an XCD share ONE weight panel) and 2 for 1x1 / gates
     static const int gn_env = [] { const char *e = getenv("DT_TILE_GN"); return e ? atoi(e) : -1; }();
-    a.tile_gn = gn_env >= 0 ? gn_env : ((ks == 3 && epi != EPI_GATES) ? 1 : 2);
+    if (a_in.tile_gn < 0) a.tile_gn = -a_in.tile_gn - 1;   // caller-chosen width, encoded as -(gn+1)
+    else a.tile_gn = gn_env >= 0 ? gn_env : ((ks == 3 && epi != EPI_GATES) ? 1 : 2);
     // DT_CONV_CFG forces a tile configuration for the 128-wide-or-wider layers (A/B runs and the
     // tests that exercise every configuration at small shapes); read per call on purpose
     if (const char *e = getenv("DT_CONV_CFG")) {

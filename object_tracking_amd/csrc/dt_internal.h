@@ -50,6 +50,9 @@ struct ConvArgs {
     int ksplit;    // EPI_PARTIAL: number of K splits (grid.y); out = slab [ksplit][M][out_ld]
     int tile_gn;   // column tiles per group in the tile order (0 = all)
     int xcd_remap; // 1: give each XCD a contiguous range of tiles (set by launch_conv_igemm)
+    // batched GEMMs (Winograd positions): grid.z problems, blockIdx.z advances in / wt / out by these (floats)
+    int zbatch;
+    long long z_in, z_wt, z_out;
 };
 
 // Tile configurations of the MFMA kernel
@@ -65,6 +68,40 @@ int launch_splitk_reduce(hipStream_t st, const float *slab, int S, long long M, 
 //   channel (folded BatchNorm) or null.
 void pack_conv_weights(const float *hwio, int ks, int cin_src, int cout_src, const int *cin_map,
                        int cin_dst, const int *n_map, int npad, const float *scale, float *dst);
+
+// ---------------------------------------------------------------------------
+// Winograd F(2x2,3x3) transforms around the batched MFMA GEMM (winograd.hip)
+// ---------------------------------------------------------------------------
+struct WinoArgs {
+    // geometry: B images of H x W; th x tw tiles of 2x2 outputs per image; Mt = B*th*tw
+    int B, H, W, th, tw, Mt;
+    // input transform: in (NHWC, pixel stride in_ld, image stride in_bs), C channels -> v [16][Mt][C]
+    const float *in;
+    long long in_bs;
+    int in_ld, C;
+    float *v;
+    // output transform: m [16][Mt][m_ld], N columns -> out (full resolution, may be null) / out2 (2x2 pooled, may be null)
+    const float *m;
+    int m_ld, N;
+    const float *bias;
+    float slope;
+    float *out;
+    long long out_bs;
+    int out_ld;
+    float *out2;
+    int out2_ld;
+    // gate variant (ConvLSTM2D): xproj / cstate as in ConvArgs
+    const float *xproj;
+    long long xp_bs;
+    int xp_ld;
+    float *cstate;
+    long long c_bs;
+    int c_ld;
+};
+int launch_wino_input(hipStream_t st, const WinoArgs &a);
+int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates);
+void wino_pack_weights(const float *hwio, int cin_src, int cout_src, const int *cin_map, int cin_dst, const int *n_map,
+                       int npad, const float *scale, float *dst);
 
 // ---------------------------------------------------------------------------
 // other kernels
@@ -130,6 +167,7 @@ struct DevBuf {
 struct ConvLayer {
     int idx, ks, cin, cout, npad, pool;  // pool: reference MaxPooling2D after this layer
     float *wt = nullptr;                 // device, packed
+    float *wino = nullptr;               // device, [16][npad][cin] Winograd-domain weights (wide 3x3 layers) or null
     float *bias = nullptr;               // device, [npad]
 };
 
@@ -149,6 +187,7 @@ struct dt_ctx {
     int trk_units = 0, trk_cx = 0 /*padded z channels*/;
     float *trk_wx = nullptr, *trk_bx = nullptr;   // input conv, N gate-interleaved
     float *trk_wh = nullptr;                      // recurrent conv
+    float *trk_wx_wino = nullptr, *trk_wh_wino = nullptr;   // their Winograd-domain forms
     float *trk_wo = nullptr, *trk_bo = nullptr;   // tconv_2 1x1
     int trk_wo_npad = 0;
     // tiny tracker

@@ -133,9 +133,10 @@ extern "C" void dt_destroy(dt_ctx *ctx)
     for (int i = 0; i <= 23; ++i) {
         if (ctx->layers[i].wt) (void)hipFree(ctx->layers[i].wt);
         if (ctx->layers[i].bias) (void)hipFree(ctx->layers[i].bias);
+        if (ctx->layers[i].wino) (void)hipFree(ctx->layers[i].wino);
     }
     float *singles[] = {ctx->conv1_w, ctx->conv1_b, ctx->lut255, ctx->anchors_dev, ctx->trk_wx, ctx->trk_bx,
-                        ctx->trk_wh,  ctx->trk_wo,  ctx->trk_bo, ctx->tiny_wx,     ctx->tiny_bx, ctx->tiny_ur,
+                        ctx->trk_wh,  ctx->trk_wo,  ctx->trk_bo, ctx->trk_wx_wino, ctx->trk_wh_wino, ctx->tiny_wx,     ctx->tiny_bx, ctx->tiny_ur,
                         ctx->tiny_wd, ctx->tiny_bd};
     for (float *p : singles)
         if (p) (void)hipFree(p);
@@ -184,6 +185,10 @@ static void oihw_to_hwio(const float *src, int O, int I, int k, std::vector<floa
                     dst[(((size_t)y * k + x) * I + i) * O + o] = src[(((size_t)o * I + i) * k + y) * k + x];
 }
 
+static bool wino_wanted(int ks, int cin, int cout);
+static int upload_wino(dt_ctx *ctx, float **dst, const float *hwio, int cin_src, int cout_src, const int *cin_map,
+                       int cin_dst, const int *n_map, int npad, const float *scale);
+
 static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, const float *hwio, const float *scale,
                            const float *bias_src)
 {
@@ -196,6 +201,11 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
     for (int c = 0; c < cout; ++c) bias[c] = bias_src[c];
     int rc = upload(ctx, &L.wt, packed);
     if (rc) return rc;
+    if (L.wino) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino); L.wino = nullptr; }
+    if (wino_wanted(ks, cin, cout)) {
+        rc = upload_wino(ctx, &L.wino, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale);
+        if (rc) return rc;
+    }
     return upload(ctx, &L.bias, bias);
 }
 
@@ -253,6 +263,124 @@ extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t 
     return DT_OK;
 }
 
+// "conv_direct_form": direct-form FLOPs (2*M*K*N of the reference's convolution) of every layer a
+// conv_igemm launch computes, whichever form it runs in -- bench.py divides it by the kernel family's
+// time for the algorithmic-equivalent rate next to the executed one.
+static void prof_direct_form(dt_ctx *ctx, double flops)
+{
+    if (ctx->prof) ctx->prof_tab["conv_direct_form"].flops += flops;
+}
+
+// ---------------------------------------------------------------------------
+// Winograd F(2x2,3x3) path for the wide 3x3 layers (winograd.hip)
+// ---------------------------------------------------------------------------
+// DT_WINO: 1 (default) = wide layers (Cin, Cout >= 256) when a launch has >= 1024 tiles;
+//          0 = never (direct MFMA form everywhere); 2 = every 3x3 layer the transforms support,
+//          at any size (parity tests of the path at small shapes).  Read when weights are loaded.
+static int wino_mode()
+{
+    const char *e = getenv("DT_WINO");
+    return e ? atoi(e) : 1;
+}
+
+static bool wino_wanted(int ks, int cin, int cout)
+{
+    const int mode = wino_mode();
+    if (ks != 3 || mode == 0 || cin % 32 || cout % 4) return false;
+    return mode == 2 || (cin >= 256 && cout >= 256);
+}
+
+static bool wino_runs(const float *wino_wt, int B, int H, int W)
+{
+    if (!wino_wt) return false;
+    const long long mt = (long long)B * ((H + 1) / 2) * ((W + 1) / 2);
+    if (mt >= (1ll << 31) / 16) return false;
+    return wino_mode() == 2 || mt >= 1024;
+}
+
+static int upload_wino(dt_ctx *ctx, float **dst, const float *hwio, int cin_src, int cout_src, const int *cin_map,
+                       int cin_dst, const int *n_map, int npad, const float *scale)
+{
+    std::vector<float> u((size_t)16 * npad * cin_dst);
+    wino_pack_weights(hwio, cin_src, cout_src, cin_map, cin_dst, n_map, npad, scale, u.data());
+    return upload(ctx, dst, u);
+}
+
+// Tile configuration of the 16 batched GEMMs [Mt x Cin] x [Cin x N]
+// Measured (tools/wino_ab.sh): with K = Cin >= 512 a tile lasts >= 16 chunks and the 4-wave 128x128 tile
+// wins (128.6 vs 121.4 TFLOP/s at K=1024) -- two workgroups per CU overlap one's epilogue / next prologue
+// with the other's MFMAs, which the single resident 256x256 workgroup cannot; at K = 256 the 256x256
+// tile's lower staging cost still wins (116.7 vs 112.7).
+static int pick_cfg_gemm(int Mt, int N, int K)
+{
+    if (N % 256 == 0 && K < 512) {
+        const long long t256 = 16ll * ((Mt + 255) / 256) * (N / 256);
+        const long long t128 = 16ll * ((Mt + 127) / 128) * (N / 128);
+        const double e256 = (double)Mt / (((Mt + 255) / 256) * 256.0) * (double)t256 / (double)(((t256 + 255) / 256) * 256);
+        const double e128 = (double)Mt / (((Mt + 127) / 128) * 128.0) * (double)t128 / (double)(((t128 + 511) / 512) * 512);
+        if (e256 * 1.05 > e128) return CFG_256x256;
+    }
+    return CFG_128x128;
+}
+
+struct WinoIO {
+    const float *in; long long in_bs; int in_ld;      // NHWC input
+    float *out; long long out_bs; int out_ld;         // full-resolution output (null: pooled only)
+    float *out2; int out2_ld;                         // 2x2 pooled output or null
+    const float *xproj; long long xp_bs; int xp_ld;   // gates variant (cstate != null)
+    float *cstate; long long c_bs; int c_ld;
+};
+
+static int run_wino(dt_ctx *ctx, const float *wino_wt, const float *bias, int cin, int N, int npad, int B, int H,
+                    int W, const WinoIO &io, float slope, const char *tag)
+{
+    WinoArgs w;
+    memset(&w, 0, sizeof(w));
+    w.B = B; w.H = H; w.W = W; w.th = (H + 1) / 2; w.tw = (W + 1) / 2; w.Mt = B * w.th * w.tw;
+    const size_t mt = (size_t)w.Mt;
+    float *V = ws_get(ctx, "wino_v", 16 * mt * cin * sizeof(float));
+    float *Mp = ws_get(ctx, "wino_m", 16 * mt * N * sizeof(float));
+    if (!V || !Mp) return DT_ERR_DEVICE;
+    w.in = io.in; w.in_bs = io.in_bs; w.in_ld = io.in_ld; w.C = cin; w.v = V;
+    w.m = Mp; w.m_ld = N; w.N = N; w.bias = bias; w.slope = slope;
+    w.out = io.out; w.out_bs = io.out_bs; w.out_ld = io.out_ld; w.out2 = io.out2; w.out2_ld = io.out2_ld;
+    w.xproj = io.xproj; w.xp_bs = io.xp_bs; w.xp_ld = io.xp_ld;
+    w.cstate = io.cstate; w.c_bs = io.c_bs; w.c_ld = io.c_ld;
+    {
+        ProfScope ps(ctx, "wino_input", 0.0, 4.0 * ((double)B * H * W * cin + 16.0 * mt * cin), tag);
+        const int rc = launch_wino_input(ctx->stream, w);
+        if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: Winograd input transform launch failed", tag);
+    }
+    {
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = V; a.in_ld = cin; a.in_bs = (long long)mt * cin;
+        a.wt = wino_wt; a.bias = nullptr;
+        a.out = Mp; a.out_ld = N; a.out_bs = (long long)mt * N;
+        a.B = 1; a.H = 1; a.W = w.Mt; a.Cin = cin; a.N = N; a.M = w.Mt; a.K = cin;
+        a.npad = npad; a.slope = 1.0f;
+        a.zbatch = 16; a.z_in = (long long)mt * cin; a.z_wt = (long long)npad * cin; a.z_out = (long long)mt * N;
+        // flops = executed MFMA work of the 16 GEMMs (the direct form of the same layer would be 2.25x
+        // that, 1.94x at 13x13); bytes = V + U + M'
+        ProfScope ps(ctx, "conv_igemm", 32.0 * mt * (double)cin * N,
+                     4.0 * 16.0 * ((double)mt * cin + (double)cin * N + (double)mt * N), tag);
+        prof_direct_form(ctx, 2.0 * B * H * W * 9.0 * cin * N);
+        int cfg = pick_cfg_gemm(w.Mt, N, cin);
+        if (const char *e = getenv("DT_WINO_CFG")) cfg = atoi(e);     // A/B runs
+        if (const char *e = getenv("DT_WINO_GN")) a.tile_gn = -atoi(e) - 1;   // A/B runs: column-group width (see launch_conv_igemm)
+        const int rc = launch_conv_igemm(ctx->stream, a, 1, ORD_LINEAR, EPI_PLAIN, cfg);
+        if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: Winograd GEMM launch failed (rc=%d)", tag, rc);
+    }
+    {
+        const double outb = (io.out ? (double)B * H * W * N : 0.0) + (io.out2 ? (double)B * H * W * N / 4.0 : 0.0) +
+                            (io.cstate ? 3.0 * B * H * W * N / 4.0 + (double)B * H * W * N : 0.0);
+        ProfScope ps(ctx, "wino_output", 0.0, 4.0 * (16.0 * mt * N + outb), tag);
+        const int rc = launch_wino_output(ctx->stream, w, io.cstate != nullptr);
+        if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: Winograd output transform launch failed", tag);
+    }
+    return DT_OK;
+}
+
 struct Dest { float *p; int ld; };
 
 // Tile configuration for a plain / pooled 3x3 or 1x1 layer.  The loss of the MFMA kernel scales
@@ -290,12 +418,21 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
                                 (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0));
     char tag[32];
     snprintf(tag, sizeof(tag), L.idx == 102 ? "tconv_2" : "conv_%d", L.idx);
+    if (wino_runs(L.wino, B, H, W) && ((epi == EPI_PLAIN && order == ORD_LINEAR) || epi == EPI_POOL || epi == EPI_POOL_BOTH)) {
+        WinoIO io;
+        memset(&io, 0, sizeof(io));
+        io.in = in; io.in_ld = in_ld; io.in_bs = a.in_bs;
+        if (epi == EPI_POOL) { io.out2 = out; io.out2_ld = out_ld; }
+        else { io.out = out; io.out_ld = out_ld; io.out_bs = a.out_bs; io.out2 = out2; io.out2_ld = out2_ld; }
+        return run_wino(ctx, L.wino, L.bias, L.cin, L.cout, L.npad, B, H, W, io, slope, tag);
+    }
     // Wave quantisation for small batches (few frames at 13x13 / 26x26): with 512 resident
     // workgroup slots (256 CUs x 2) a layer of a few hundred output tiles leaves the chip
     // partly idle or spills a nearly empty last round.  Split K over grid.y into a slab and
     // combine deterministically; the split count minimises a simple round model
     //   time(s) ~ rounds(tiles*s) / s + 0.003*s,  rounds(n) = full rounds + cost of the partial one
     // (a half-empty round still costs ~0.6 of a full one: single workgroups per CU run faster).
+    prof_direct_form(ctx, flops);
     int ksplit = 1;
     if (epi == EPI_PLAIN && order == ORD_LINEAR && cfg != CFG_128x64) {
         const int tiles = ((a.M + 127) / 128) * ((L.cout + 127) / 128);
@@ -535,6 +672,14 @@ extern "C" int dt_tracker_load(dt_ctx *ctx, int units, const float *h_kernel, co
     if ((rc = upload(ctx, &ctx->trk_bx, bx))) return rc;
     if ((rc = upload(ctx, &ctx->trk_wo, wo))) return rc;
     if ((rc = upload(ctx, &ctx->trk_bo, bo))) return rc;
+    for (float **w : {&ctx->trk_wx_wino, &ctx->trk_wh_wino})
+        if (*w) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(*w); *w = nullptr; }
+    if (wino_wanted(3, Cx, 4 * U) &&
+        (rc = upload_wino(ctx, &ctx->trk_wx_wino, h_kernel, Csrc, 4 * U, cin_map.data(), Cx, n_map.data(), 4 * U, nullptr)))
+        return rc;
+    if (wino_wanted(3, U, 4 * U) &&
+        (rc = upload_wino(ctx, &ctx->trk_wh_wino, h_recurrent, U, 4 * U, nullptr, U, n_map.data(), 4 * U, nullptr)))
+        return rc;
     ctx->trk_units = U; ctx->trk_cx = Cx; ctx->trk_wo_npad = npad;
     ctx->trk_loaded = true;
     return DT_OK;
@@ -542,13 +687,21 @@ extern "C" int dt_tracker_load(dt_ctx *ctx, int units, const float *h_kernel, co
 
 // xproj = conv3x3(z, Wx) + b for all frames; then the sequential recurrence
 static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, int T, int gh, int gw, int U,
-                             const float *wx, const float *bx, const float *wh, float *hseq /*[n_clips][T][GG][U]*/)
+                             const float *wx, const float *bx, const float *wh, float *hseq /*[n_clips][T][GG][U]*/,
+                             const float *wx_wino = nullptr, const float *wh_wino = nullptr)
 {
     const int GG = gh * gw, F = n_clips * T, N4 = 4 * U;
     float *xproj = ws_get(ctx, "trk_xproj", (size_t)F * GG * N4 * sizeof(float));
     float *cst = ws_get(ctx, "trk_c", (size_t)n_clips * GG * U * sizeof(float));
     if (!xproj || !cst) return DT_ERR_DEVICE;
-    {
+    if (wino_runs(wx_wino, F, gh, gw)) {
+        WinoIO io;
+        memset(&io, 0, sizeof(io));
+        io.in = z; io.in_ld = Cx; io.in_bs = (long long)GG * Cx;
+        io.out = xproj; io.out_ld = N4; io.out_bs = (long long)GG * N4;
+        const int rc = run_wino(ctx, wx_wino, bx, Cx, N4, N4, F, gh, gw, io, 1.0f, "convlstm_xproj");
+        if (rc) return rc;
+    } else {
         ConvArgs a;
         memset(&a, 0, sizeof(a));
         a.in = z; a.in_ld = Cx; a.in_bs = (long long)GG * Cx;
@@ -559,6 +712,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
         ProfScope ps(ctx, "conv_igemm", 2.0 * a.M * 9.0 * (ctx->cb + 1024) * N4,
                      4.0 * ((double)a.M * Cx + (double)a.K * N4 + (double)a.M * N4), "convlstm_xproj");
         a.npad = N4;
+        prof_direct_form(ctx, 2.0 * a.M * 9.0 * (ctx->cb + 1024) * N4);
         if (launch_conv_igemm(ctx->stream, a, 3, ORD_LINEAR, EPI_PLAIN, pick_cfg(a.M, N4, 3)))
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM input projection launch failed");
     }
@@ -569,6 +723,17 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM t=0 launch failed");
     }
     for (int t = 1; t < T; ++t) {
+        if (wino_runs(wh_wino, n_clips, gh, gw)) {
+            WinoIO io;
+            memset(&io, 0, sizeof(io));
+            io.in = hseq + (long long)(t - 1) * GG * U; io.in_ld = U; io.in_bs = h_bs;
+            io.out = hseq + (long long)t * GG * U; io.out_ld = U; io.out_bs = h_bs;
+            io.xproj = xproj + (long long)t * GG * N4; io.xp_ld = N4; io.xp_bs = xp_bs;
+            io.cstate = cst; io.c_ld = U; io.c_bs = c_bs;
+            const int rc = run_wino(ctx, wh_wino, nullptr, U, N4, N4, n_clips, gh, gw, io, 1.0f, "convlstm_step");
+            if (rc) return rc;
+            continue;
+        }
         ConvArgs a;
         memset(&a, 0, sizeof(a));
         a.in = hseq + (long long)(t - 1) * GG * U; a.in_ld = U; a.in_bs = h_bs;
@@ -581,6 +746,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
         ProfScope ps(ctx, "conv_igemm", 2.0 * a.M * (double)a.K * N4,
                      4.0 * ((double)a.M * U + (double)a.K * N4 + (double)a.M * N4 + 3.0 * a.M * U), "convlstm_step");
         a.npad = N4;
+        prof_direct_form(ctx, 2.0 * a.M * (double)a.K * N4);
         if (launch_conv_igemm(ctx->stream, a, 3, ORD_LINEAR, EPI_GATES, pick_cfg(a.M, N4, 3)))
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM step launch failed");
     }
@@ -600,7 +766,8 @@ extern "C" int dt_track_forward(dt_ctx *ctx, const void *d_frames, int frames_dt
     if (!z || !hseq) return DT_ERR_DEVICE;
     int rc = detect_internal(ctx, d_frames, frames_dtype, F, Dest{z, Cx}, Dest{z + 1024, Cx});
     if (rc) return rc;
-    rc = convlstm_sequence(ctx, z, Cx, n_clips, T, gh, gw, U, ctx->trk_wx, ctx->trk_bx, ctx->trk_wh, hseq);
+    rc = convlstm_sequence(ctx, z, Cx, n_clips, T, gh, gw, U, ctx->trk_wx, ctx->trk_bx, ctx->trk_wh, hseq, ctx->trk_wx_wino,
+                           ctx->trk_wh_wino);
     if (rc) return rc;
     float *trk = d_trk;
     if (!trk) {
@@ -854,6 +1021,27 @@ extern "C" int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int
     if ((rc = upload(ctx, &dwx, wx)) || (rc = upload(ctx, &dwh, wh)) || (rc = upload(ctx, &dbx, bx))) return rc;
     float *xproj = ws_get(ctx, "cl_xproj", (size_t)B * GG * N4 * sizeof(float));
     if (!xproj) return DT_ERR_DEVICE;
+    if (wino_mode() == 2 && wino_wanted(3, Cx, N4) && wino_wanted(3, U, N4)) {   // the same step through the Winograd path
+        float *uwx = nullptr, *uwh = nullptr;
+        if ((rc = upload_wino(ctx, &uwx, h_kernel, Cx, N4, nullptr, Cx, n_map.data(), N4, nullptr)) ||
+            (rc = upload_wino(ctx, &uwh, h_recurrent, U, N4, nullptr, U, n_map.data(), N4, nullptr)))
+            return rc;
+        WinoIO io;
+        memset(&io, 0, sizeof(io));
+        io.in = d_x; io.in_ld = Cx; io.in_bs = (long long)GG * Cx;
+        io.out = xproj; io.out_ld = N4; io.out_bs = (long long)GG * N4;
+        if ((rc = run_wino(ctx, uwx, dbx, Cx, N4, N4, B, H, W, io, 1.0f, "convlstm_xproj"))) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(d_c_out, d_c, (size_t)B * GG * U * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        memset(&io, 0, sizeof(io));
+        io.in = d_h; io.in_ld = U; io.in_bs = (long long)GG * U;
+        io.out = d_h_out; io.out_ld = U; io.out_bs = (long long)GG * U;
+        io.xproj = xproj; io.xp_ld = N4; io.xp_bs = (long long)GG * N4;
+        io.cstate = d_c_out; io.c_ld = U; io.c_bs = (long long)GG * U;
+        if ((rc = run_wino(ctx, uwh, nullptr, U, N4, N4, B, H, W, io, 1.0f, "convlstm_step"))) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(dwx); (void)hipFree(dwh); (void)hipFree(dbx); (void)hipFree(uwx); (void)hipFree(uwh);
+        return DT_OK;
+    }
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in = d_x; a.in_ld = Cx; a.in_bs = (long long)GG * Cx;

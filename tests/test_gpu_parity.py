@@ -748,3 +748,94 @@ def test_batch_generators_on_image_files(ctx, tmp_path):
     assert y1 is y2 and y1.shape == (2, 2, 3, 3, 5, 7) and np.array_equal(y1.reshape(4, 3, 3, 5, 7), ey)
     with pytest.raises(NotImplementedError):
         BatchGenerator(list(recs), cfg, augment=True, ctx=ctx)
+
+
+# ---- Winograd F(2x2,3x3) form of the wide 3x3 layers (csrc/winograd.hip) ------------------
+@pytest.fixture
+def wino_all(monkeypatch):
+    """DT_WINO=2: every 3x3 layer the transforms support goes through the Winograd path, at any size
+    (the default policy only takes it for Cin, Cout >= 256 and >= 1024 tiles per launch)."""
+    monkeypatch.setenv("DT_WINO", "2")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [
+    (2, 13, 13, 64, 128, 0),     # odd H, W: 7x7 tiles cover 14x14
+    (3, 8, 12, 32, 64, 1),       # pooled output only: a tile is a pooling window
+    (2, 6, 10, 64, 160, 2),      # pooled + full resolution (conv_13's skip tap)
+    (1, 7, 5, 96, 36, 0),        # ragged everything, N a multiple of 4 only
+    (5, 26, 26, 32, 32, 0),      # more tiles than one row tile of the GEMM
+    (1, 13, 13, 1280, 256, 0),   # conv_22's Cin, 256-wide column tile
+])
+def test_conv2d_winograd_vs_oracle(ctx, wino_all, B, H, W, Cin, Cout, pool):
+    rs = np.random.RandomState(B * 1000 + H + Cin + Cout)
+    x = rs.randn(B, H, W, Cin).astype(np.float32)
+    w = (rs.randn(3, 3, Cin, Cout) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32)
+    ref = orc.conv2d(x, w, b)
+    ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=pool)
+    ctx.profile_enable(False)
+    assert ctx.profile_read("wino_input")["launches"] == 1 and ctx.profile_read("wino_output")["launches"] == 1
+    tol = 2e-5
+    if pool == 0:
+        assert relerr(got.cpu().numpy(), ref) < tol
+    elif pool == 1:
+        assert relerr(got.cpu().numpy(), orc.maxpool2(ref)) < tol
+    else:
+        assert relerr(got[0].cpu().numpy(), ref) < tol
+        assert relerr(got[1].cpu().numpy(), orc.maxpool2(ref)) < tol
+
+
+def test_conv2d_winograd_detects_transpose(ctx, wino_all):
+    """one-hot taps: every Winograd position / tile offset / channel map must line up exactly
+    (values are small integers, the transforms are exact on them)."""
+    B, H, W, Cin, Cout = 2, 9, 11, 32, 96
+    x = (np.arange(B * H * W * Cin, dtype=np.float32).reshape(B, H, W, Cin) % 251)
+    w = np.zeros((3, 3, Cin, Cout), dtype=np.float32)
+    for n in range(Cout):
+        w[n % 3, (n // 3) % 3, (n * 7) % Cin, n] = 1.0
+    got = ctx.conv2d(dev(x, ctx), w, None, leaky_slope=1.0, pool=0).cpu().numpy()
+    assert np.array_equal(got, orc.conv2d(x, w))
+
+
+def test_convlstm_step_winograd_vs_oracle(ctx, wino_all):
+    ctx.profile_reset(); ctx.profile_enable(True)
+    test_convlstm_step_vs_oracle(ctx)
+    ctx.profile_enable(False)
+    assert ctx.profile_read("wino_output")["launches"] == 2      # input projection + gate step
+
+
+def test_detector_winograd_vs_oracle(ctx, wino_all):
+    test_detector_forward_vs_oracle_small(ctx, 64, 64, 12, 3)
+    test_detector_full_size_one_frame_vs_oracle(ctx)
+
+
+def test_tracker_winograd_boxes_and_ids_vs_oracle(ctx, wino_all):
+    test_track_forward_vs_oracle_small(ctx)
+    test_track_clips_boxes_and_ids_vs_oracle(ctx)
+
+
+def test_winograd_default_policy_engages_on_wide_layers(ctx):
+    """Default policy: 24 frames of 13x13x512 -> 1176 tiles >= 1024 takes the Winograd path and agrees
+    with the direct MFMA form of the same layer (DT_WINO=0) to rounding."""
+    rs = np.random.RandomState(77)
+    x = rs.randn(24, 13, 13, 512).astype(np.float32)
+    w = (rs.randn(3, 3, 512, 256) * np.sqrt(2.0 / (9 * 512))).astype(np.float32)
+    b = rs.randn(256).astype(np.float32)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=0)
+    ctx.profile_enable(False)
+    assert ctx.profile_read("wino_input")["launches"] == 1
+    os.environ["DT_WINO"] = "0"
+    try:
+        ctx.profile_reset(); ctx.profile_enable(True)
+        direct = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=0)
+        ctx.profile_enable(False)
+        assert ctx.profile_read("wino_input")["launches"] == 0
+    finally:
+        del os.environ["DT_WINO"]
+    assert relerr(got.cpu().numpy(), direct.cpu().numpy()) < 2e-5
+    ref = orc.conv2d(x[:2], w, b)
+    ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
+    assert relerr(got[:2].cpu().numpy(), ref) < 2e-5
