@@ -106,7 +106,7 @@ __device__ __forceinline__ void decode_row(int m, int H, int W, int &b, int &h, 
     }
 }
 
-template <int KS, int BM, int BN, int WGM, int WGN, int ORDER, int EPI>
+template <int KS, int BM, int BN, int WGM, int WGN, int ORDER, int EPI, bool PERSIST = false>
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : WAVES_PER_SIMD)) void conv_igemm_f32(ConvArgs p)
 {
     constexpr int NW = WGM * WGN;                  // wavefronts per workgroup (4, or 8 for the 256x128 tile)
@@ -129,37 +129,47 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
     const int wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
-    // XCD-aware tile order.  Workgroup b is dispatched to XCD b % 8 (observed; used
-    // for speed only).  Tiles are numbered n-fastest, and each XCD is given one
-    // CONTIGUOUS range of tile numbers, so the ntn column tiles that re-read the
-    // same activation rows (and neighbouring row panels that share the 3x3 halo)
-    // hit the same 4 MiB L2 instead of being fetched by all eight.
+    // Tile schedule.  The launch is PERSISTENT when there are more tiles than resident workgroup
+    // slots: workgroup b walks the linear indices L = b, b + gridDim.x, ... over
+    // total = (row tiles x column tiles) x (batched GEMMs, the 16 Winograd positions of
+    // winograd.hip), and the chunk-0 DMA of its next tile is issued inside the last chunk of the
+    // current one, so neither a workgroup relaunch nor a cold prologue sits between two tiles.
+    //
+    // XCD-aware order.  Workgroup b is dispatched to XCD b % 8 (observed; used for speed only) and
+    // gridDim.x is a multiple of 8 when persistent, so L % 8 is the XCD.  Each XCD is given one
+    // CONTIGUOUS range of tile numbers (n fastest), so the column tiles that re-read the same
+    // activation rows (and neighbouring row panels that share the 3x3 halo) hit the same 4 MiB L2
+    // instead of being fetched by all eight.
     const int ntn = (p.N + BN - 1) / BN;
-    int bid = blockIdx.x;
-    if (p.xcd_remap) {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, j = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;   // bijective for any nwg
-    }
-    // Within the range, tiles go GN column tiles at a time over ALL row tiles (then the next
-    // GN columns): the ~64 workgroups resident on an XCD then cover (64/GN) row tiles x GN
-    // column tiles, which minimises weight-panel + activation-panel traffic per MFMA.
-    int tile_n, tile_m;
-    {
+    const int ntm_all = (p.M + BM - 1) / BM;
+    const int ntiles = ntm_all * ntn;
+    const int total = ntiles * (p.zbatch > 1 ? p.zbatch : 1);
+    struct Tile {
+        int z, m0, n0;
+    };
+    auto tile_of = [&](int L) {
+        int t = L;
+        if (p.xcd_remap) {
+            const int q = total >> 3, r = total & 7;
+            const int xcd = L & 7, j = L >> 3;
+            t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;   // bijective for any total
+        }
+        Tile T;
+        T.z = t / ntiles;
+        const int bid = t - T.z * ntiles;
+        // Within a problem, tiles go GN column tiles at a time over ALL row tiles (then the next GN
+        // columns): the ~64 workgroups resident on an XCD then cover (64/GN) row tiles x GN column
+        // tiles, which minimises weight-panel + activation-panel traffic per MFMA.
         const int gn = p.tile_gn > 0 && p.tile_gn < ntn ? p.tile_gn : ntn;
-        const int ntm_all = gridDim.x / ntn;
         const int per_group = gn * ntm_all;                 // tiles in a full column group
         const int grp = bid / per_group;
         const int rem = bid - grp * per_group;
         const int gw = min(gn, ntn - grp * gn);             // width of this (possibly last, narrower) group
-        tile_m = rem / gw;
-        tile_n = grp * gn + (rem - tile_m * gw);
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    // batched GEMMs (the 16 Winograd positions of csrc/winograd.hip): one problem per blockIdx.z
-    p.in += (long long)blockIdx.z * p.z_in;
-    p.wt += (long long)blockIdx.z * p.z_wt;
-    p.out += (long long)blockIdx.z * p.z_out;
+        const int tile_m = rem / gw;
+        T.m0 = tile_m * BM;
+        T.n0 = (grp * gn + (rem - tile_m * gw)) * BN;
+        return T;
+    };
 
     // ---- loader set-up ----------------------------------------------------
     // Register staging: thread -> row lr + 32*i, 16-byte slot tid&7 of the 128-byte chunk row.
@@ -177,31 +187,44 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
 #endif
     const float *a_ptr[PA];
     unsigned a_mask[PA];
+    const float *b_ptr[PB];
+    auto setup = [&](const Tile &T) {
+        const float *in_z = p.in + (long long)T.z * p.z_in;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int m = m0 + lr + RPASS * i;
-        unsigned mask = 0;
-        const float *ptr = p.in;
-        if (m < p.M) {
-            int b, h, w;
-            decode_row<ORDER>(m, p.H, p.W, b, h, w);
-            ptr = p.in + (long long)b * p.in_bs + (long long)(h * p.W + w) * p.in_ld + lc;
-            if (KS == 1) {
-                mask = 1u;
-            } else {
+        for (int i = 0; i < PA; ++i) {
+            const int m = T.m0 + lr + RPASS * i;
+            unsigned mask = 0;
+            const float *ptr = in_z;
+            if (m < p.M) {
+                if (KS == 1 && ORDER == ORD_LINEAR) {
+                    // dense NHWC input (in_bs == H*W*in_ld, checked by the launcher): row m is pixel m
+                    ptr = in_z + (long long)m * p.in_ld + lc;
+                    mask = 1u;
+                } else {
+                int b, h, w;
+                decode_row<ORDER>(m, p.H, p.W, b, h, w);
+                ptr = in_z + (long long)b * p.in_bs + (long long)(h * p.W + w) * p.in_ld + lc;
+                if (KS == 1) {
+                    mask = 1u;
+                } else {
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int ih = h + t / 3 - 1, iw = w + t % 3 - 1;
-                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) mask |= 1u << t;
+                    for (int t = 0; t < 9; ++t) {
+                        const int ih = h + t / 3 - 1, iw = w + t % 3 - 1;
+                        if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) mask |= 1u << t;
+                    }
+                }
                 }
             }
+            a_ptr[i] = ptr;
+            a_mask[i] = mask;
         }
-        a_ptr[i] = ptr;
-        a_mask[i] = mask;
-    }
-    const float *b_ptr[PB];
+        const float *wt_z = p.wt + (long long)T.z * p.z_wt;
 #pragma unroll
-    for (int i = 0; i < PB; ++i) b_ptr[i] = p.wt + (long long)(n0 + lr + RPASS * i) * p.K + lc;
+        for (int i = 0; i < PB; ++i) b_ptr[i] = wt_z + (long long)(T.n0 + lr + RPASS * i) * p.K + lc;
+    };
+    int Lcur = blockIdx.x;
+    Tile cur_t = tile_of(Lcur);
+    setup(cur_t);
 
     const int cpt = p.Cin / KCH;    // K chunks per tap
     // split-K: blockIdx.y owns chunks [k0, k0+nk) of the TAPS*cpt chunks of K
@@ -259,12 +282,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
     };
 
     f32x16 acc[TM][TN];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    };
+    zero_acc();
 
     // ---- main loop ----------------------------------------------------------
     // Rotated software pipeline, one barrier per 32-deep K chunk:
@@ -332,6 +358,89 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
 #endif
     constexpr bool AB_BARRIER = (DT_ABLATE & 1) != 0, AB_GLOAD = (DT_ABLATE & 2) != 0;
     constexpr bool AB_LSTORE = (DT_ABLATE & 4) != 0, AB_LFRAG = (DT_ABLATE & 8) != 0;
+    // ---- epilogue (per tile) --------------------------------------------------
+    const int hi = lane >> 5;
+    auto epilogue = [&](const Tile &T) {
+        const int m0 = T.m0, n0 = T.n0;
+        float *outz = p.out + (long long)T.z * p.z_out;
+        if (EPI == EPI_GATES) {
+            // TN == 4: tile j = gate (i,f,c,o) of hidden channel jc
+            static_assert(EPI != EPI_GATES || TN == 4, "gates need 4 column tiles per wave");
+            const int colbase = n0 + wn * WTN;            // multiple of 128
+            const int jc = (colbase >> 2) + fr;           // hidden channel
+            const int hw = p.H * p.W;
+    #pragma unroll
+            for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (row < p.M) {
+                        const int b = row / hw;
+                        const int pix = row - b * hw;
+                        const float *xp = p.xproj + (long long)b * p.xp_bs + (long long)pix * p.xp_ld + colbase + fr;
+                        const float zi = acc[i][0][r] + xp[0];
+                        const float zf = acc[i][1][r] + xp[32];
+                        const float zc = acc[i][2][r] + xp[64];
+                        const float zo = acc[i][3][r] + xp[96];
+                        float *cp = p.cstate + (long long)b * p.c_bs + (long long)pix * p.c_ld + jc;
+                        const float gi = hard_sigmoid_f(zi), gf = hard_sigmoid_f(zf), go = hard_sigmoid_f(zo);
+                        const float cn = gf * (*cp) + gi * tanhf(zc);
+                        *cp = cn;
+                        outz[(long long)b * p.out_bs + (long long)pix * p.out_ld + jc] = go * tanhf(cn);
+                    }
+                }
+            return;
+        }
+    #pragma unroll
+        for (int i = 0; i < TM; ++i)
+    #pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * WTN + j * 32 + fr;
+                const bool cok = col < p.N;
+                const float bv = (p.bias != nullptr) ? p.bias[col] : 0.0f;  // bias is padded to Npad
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int rbase = m0 + wm * WTM + i * 32 + 8 * g + 4 * hi;
+                    float v[4];
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float z = acc[i][j][4 * g + q] + bv;
+                        v[q] = p.act == 1 ? 1.0f / (1.0f + expf(-z)) : leaky_act(z, p.slope);   // Dense(sigmoid) / LeakyReLU
+                    }
+                    if (!cok || rbase >= p.M) continue;
+                    if (EPI == EPI_PARTIAL) {
+                        // split-K partial sums: raw accumulators to slab [split][M][N]
+                        float *slab = outz + (long long)blockIdx.y * p.M * p.out_ld;
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (rbase + q < p.M) slab[(long long)(rbase + q) * p.out_ld + col] = acc[i][j][4 * g + q];
+                    } else if (EPI == EPI_PLAIN) {
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (rbase + q < p.M) outz[(long long)(rbase + q) * p.out_ld + col] = v[q];
+                    } else if (EPI == EPI_S2D) {
+                        // tf.space_to_depth(2): pixel m>>2, channel (m&3)*N + col
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            outz[(long long)(rbase >> 2) * p.out_ld + q * p.N + col] = v[q];
+                    } else {
+                        const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        if (EPI == EPI_POOL) {
+                            outz[(long long)(rbase >> 2) * p.out_ld + col] = mx;
+                        } else {  // EPI_POOL_BOTH: out = unpooled (standard NHWC), out2 = pooled
+                            p.out2[(long long)(rbase >> 2) * p.out2_ld + col] = mx;
+                            int b, h, w;
+                            decode_row<ORD_QUAD>(rbase, p.H, p.W, b, h, w);
+                            float *o = outz + ((long long)(b * p.H + h) * p.W + w) * p.out_ld + col;
+                            o[0] = v[0];
+                            o[p.out_ld] = v[1];
+                            o[(long long)p.W * p.out_ld] = v[2];
+                            o[(long long)(p.W + 1) * p.out_ld] = v[3];
+                        }
+                    }
+                }
+            }
+    };
     Frag f0, f1;
 #if DT_GLDS && DT_BK == 16
     // 16-deep chunks, THREE 16 KiB LDS stages (48 KiB -> three workgroups per CU, three waves per
@@ -380,54 +489,150 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
     }
 #undef SB
     __builtin_amdgcn_s_waitcnt(0x0f70);    // drain the dead trailing DMAs before the LDS is released
+    epilogue(cur_t);   // this staging variant is launched one tile per workgroup
 #elif DT_GLDS
     // DMA variant: chunk t+1 streams straight into the other LDS buffer while chunk t is
     // multiplied; no staging registers, no ds_write.  The drain (vmcnt(0)) sits right before
     // the one barrier of the iteration, a full chunk of MFMAs after the DMA was issued.
-    (void)ra; (void)rb; (void)gload; (void)lstore; (void)AB_LSTORE;
-    dma(0, gtap, gcc, gk);
-    gadvance();
-    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
-    __syncthreads();
-    lfrag(f0, 0, 0);
+    //
     // Every block of LDS reads / DMA issues sits AFTER the first k-step of an MFMA group and
     // BEFORE its other three (pinned with sched_barrier): hipcc waits lgkmcnt(0) ahead of the
     // first MFMA that consumes a fragment once LDS-DMA is in flight, so a read block placed in
     // front of a group would be waited for immediately; placed here it has 12 x TM x TN MFMAs of
     // cover and the wait in front of the next group finds nothing outstanding.
+    //
+    // Persistent tiles: the body of a tile's LAST chunk computes the loader addresses of the
+    // workgroup's next tile and issues ITS chunk-0 DMA (when there is none, this tile's chunk 0
+    // is re-fetched into the dead buffer, which keeps the body branch-free); the fragment read
+    // after the barrier is then already the next tile's first one, and the epilogue stores of this
+    // tile drain underneath the next tile's MFMAs.
+    (void)ra; (void)rb; (void)gload; (void)lstore; (void)AB_LSTORE; 
+    dma(0, gtap, gcc, gk);
+    gadvance();
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+    __syncthreads();
+    lfrag(f0, 0, 0);
 #define SB() __builtin_amdgcn_sched_barrier(0)
-    for (int kc = 0; kc < nk; ++kc) {
-        const int cur = kc & 1;
-        mma_part(f0, 0, 1);
-        SB();
-        if (!AB_LFRAG) lfrag(f1, cur, 1);
-        if (!AB_GLOAD) {
-            const bool in = gk < k_end;          // past the end: re-fetch the last chunk into the dead buffer
-            dma(cur ^ 1, in ? gtap : last_tap, in ? gcc : last_cc, in ? gk : k_end - 1);
-            gadvance();
+    if constexpr (!PERSIST) {
+        // one tile per workgroup
+        for (int kc = 0; kc < nk; ++kc) {
+            const int cur = kc & 1;
+            mma_part(f0, 0, 1);
+            SB();
+            if (!AB_LFRAG) lfrag(f1, cur, 1);
+            if (!AB_GLOAD) {
+                const bool in = gk < k_end;          // past the end: re-fetch the last chunk into the dead buffer
+                dma(cur ^ 1, in ? gtap : last_tap, in ? gcc : last_cc, in ? gk : k_end - 1);
+                gadvance();
+            }
+            __builtin_amdgcn_sched_barrier(0x16);   // DS reads and MFMAs stay put; the DMA issues and their address
+                                                    // VALU/SALU may sink in between the twelve MFMAs that follow
+            mma_part(f0, 1, 4);
+            mma_part(f1, 0, 1);
+            SB();
+            if (!AB_LFRAG) lfrag(f0, cur, 2);
+            SB();
+            mma_part(f1, 1, 4);
+            mma_part(f0, 0, 1);
+            SB();
+            if (!AB_LFRAG) lfrag(f1, cur, 3);
+            SB();
+            mma_part(f0, 1, 4);
+            SB();
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's DMA pieces of chunk t+1 have landed
+            if (!AB_BARRIER) __syncthreads();
+            SB();
+            mma_part(f1, 0, 1);
+            SB();
+            if (!AB_LFRAG) lfrag(f0, cur ^ 1, 0);
+            SB();
+            mma_part(f1, 1, 4);
         }
-        __builtin_amdgcn_sched_barrier(0x16);   // DS reads and MFMAs stay put; the DMA issues and their address
-                                                // VALU/SALU may sink in between the twelve MFMAs that follow
-        mma_part(f0, 1, 4);
-        mma_part(f1, 0, 1);
-        SB();
-        if (!AB_LFRAG) lfrag(f0, cur, 2);
-        SB();
-        mma_part(f1, 1, 4);
-        mma_part(f0, 0, 1);
-        SB();
-        if (!AB_LFRAG) lfrag(f1, cur, 3);
-        SB();
-        mma_part(f0, 1, 4);
-        SB();
-        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's DMA pieces of chunk t+1 have landed
-        if (!AB_BARRIER) __syncthreads();
-        SB();
-        mma_part(f1, 0, 1);
-        SB();
-        if (!AB_LFRAG) lfrag(f0, cur ^ 1, 0);
-        SB();
-        mma_part(f1, 1, 4);
+        if (AB_LFRAG) {   // keep the fragments formally live
+            lfrag(f1, 0, 1);
+            mma(f1);
+        }
+        epilogue(cur_t);
+    } else {
+        int cur = 0;
+        for (;;) {
+            for (int kc = 0; kc < nk - 1; ++kc) {
+                mma_part(f0, 0, 1);
+                SB();
+                if (!AB_LFRAG) lfrag(f1, cur, 1);
+                if (!AB_GLOAD) {
+                    dma(cur ^ 1, gtap, gcc, gk);
+                    gadvance();
+                }
+                __builtin_amdgcn_sched_barrier(0x16);   // DS reads and MFMAs stay put; the DMA issues and their address
+                                                        // VALU/SALU may sink in between the twelve MFMAs that follow
+                mma_part(f0, 1, 4);
+                mma_part(f1, 0, 1);
+                SB();
+                if (!AB_LFRAG) lfrag(f0, cur, 2);
+                SB();
+                mma_part(f1, 1, 4);
+                mma_part(f0, 0, 1);
+                SB();
+                if (!AB_LFRAG) lfrag(f1, cur, 3);
+                SB();
+                mma_part(f0, 1, 4);
+                SB();
+                __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's DMA pieces of chunk t+1 have landed
+                if (!AB_BARRIER) __syncthreads();
+                SB();
+                mma_part(f1, 0, 1);
+                SB();
+                if (!AB_LFRAG) lfrag(f0, cur ^ 1, 0);
+                SB();
+                mma_part(f1, 1, 4);
+                cur ^= 1;
+            }
+            // last chunk of this tile: same body, the DMA belongs to the next tile
+            const int Lnext = Lcur + (int)gridDim.x;
+            const bool more = Lnext < total;
+            const Tile next_t = tile_of(more ? Lnext : Lcur);
+            mma_part(f0, 0, 1);
+            SB();
+            if (!AB_LFRAG) lfrag(f1, cur, 1);
+            setup(next_t);
+            gtap = k0 % TAPS; gcc = k0 / TAPS; gk = k0;
+            if (!AB_GLOAD) {
+                dma(cur ^ 1, gtap, gcc, gk);
+                gadvance();
+            }
+            __builtin_amdgcn_sched_barrier(0x16);
+            mma_part(f0, 1, 4);
+            mma_part(f1, 0, 1);
+            SB();
+            if (!AB_LFRAG) lfrag(f0, cur, 2);
+            SB();
+            mma_part(f1, 1, 4);
+            mma_part(f0, 0, 1);
+            SB();
+            if (!AB_LFRAG) lfrag(f1, cur, 3);
+            SB();
+            mma_part(f0, 1, 4);
+            SB();
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            if (!AB_BARRIER) __syncthreads();
+            SB();
+            mma_part(f1, 0, 1);
+            SB();
+            if (!AB_LFRAG) lfrag(f0, cur ^ 1, 0);
+            SB();
+            mma_part(f1, 1, 4);
+            cur ^= 1;
+            if (AB_LFRAG) {   // keep the fragments formally live
+                lfrag(f1, 0, 1);
+                mma(f1);
+            }
+            epilogue(cur_t);
+            if (!more) break;
+            Lcur = Lnext;
+            cur_t = next_t;
+            zero_acc();
+        }
     }
 #undef SB
 #else
@@ -460,100 +665,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
         __builtin_amdgcn_sched_barrier(0);   // ...and keep those reads ABOVE them
         mma(f1);
     }
+    epilogue(cur_t);   // this staging variant is launched one tile per workgroup
 #endif
-    if (AB_LFRAG) {   // keep the fragments formally live
-        lfrag(f1, 0, 1);
-        mma(f1);
-    }
-
-    // ---- epilogue -----------------------------------------------------------
-    const int hi = lane >> 5;
-    if (EPI == EPI_GATES) {
-        // TN == 4: tile j = gate (i,f,c,o) of hidden channel jc
-        static_assert(EPI != EPI_GATES || TN == 4, "gates need 4 column tiles per wave");
-        const int colbase = n0 + wn * WTN;            // multiple of 128
-        const int jc = (colbase >> 2) + fr;           // hidden channel
-        const int hw = p.H * p.W;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (row < p.M) {
-                    const int b = row / hw;
-                    const int pix = row - b * hw;
-                    const float *xp = p.xproj + (long long)b * p.xp_bs + (long long)pix * p.xp_ld + colbase + fr;
-                    const float zi = acc[i][0][r] + xp[0];
-                    const float zf = acc[i][1][r] + xp[32];
-                    const float zc = acc[i][2][r] + xp[64];
-                    const float zo = acc[i][3][r] + xp[96];
-                    float *cp = p.cstate + (long long)b * p.c_bs + (long long)pix * p.c_ld + jc;
-                    const float gi = hard_sigmoid_f(zi), gf = hard_sigmoid_f(zf), go = hard_sigmoid_f(zo);
-                    const float cn = gf * (*cp) + gi * tanhf(zc);
-                    *cp = cn;
-                    p.out[(long long)b * p.out_bs + (long long)pix * p.out_ld + jc] = go * tanhf(cn);
-                }
-            }
-        return;
-    }
-
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * WTN + j * 32 + fr;
-            const bool cok = col < p.N;
-            const float bv = (p.bias != nullptr) ? p.bias[col] : 0.0f;  // bias is padded to Npad
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int rbase = m0 + wm * WTM + i * 32 + 8 * g + 4 * hi;
-                float v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float z = acc[i][j][4 * g + q] + bv;
-                    v[q] = p.act == 1 ? 1.0f / (1.0f + expf(-z)) : leaky_act(z, p.slope);   // Dense(sigmoid) / LeakyReLU
-                }
-                if (!cok || rbase >= p.M) continue;
-                if (EPI == EPI_PARTIAL) {
-                    // split-K partial sums: raw accumulators to slab [split][M][N]
-                    float *slab = p.out + (long long)blockIdx.y * p.M * p.out_ld;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (rbase + q < p.M) slab[(long long)(rbase + q) * p.out_ld + col] = acc[i][j][4 * g + q];
-                } else if (EPI == EPI_PLAIN) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (rbase + q < p.M) p.out[(long long)(rbase + q) * p.out_ld + col] = v[q];
-                } else if (EPI == EPI_S2D) {
-                    // tf.space_to_depth(2): pixel m>>2, channel (m&3)*N + col
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        p.out[(long long)(rbase >> 2) * p.out_ld + q * p.N + col] = v[q];
-                } else {
-                    const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                    if (EPI == EPI_POOL) {
-                        p.out[(long long)(rbase >> 2) * p.out_ld + col] = mx;
-                    } else {  // EPI_POOL_BOTH: out = unpooled (standard NHWC), out2 = pooled
-                        p.out2[(long long)(rbase >> 2) * p.out2_ld + col] = mx;
-                        int b, h, w;
-                        decode_row<ORD_QUAD>(rbase, p.H, p.W, b, h, w);
-                        float *o = p.out + ((long long)(b * p.H + h) * p.W + w) * p.out_ld + col;
-                        o[0] = v[0];
-                        o[p.out_ld] = v[1];
-                        o[(long long)p.W * p.out_ld] = v[2];
-                        o[(long long)(p.W + 1) * p.out_ld] = v[3];
-                    }
-                }
-            }
-        }
 }
 
-template <int KS, int BM, int BN, int WGM, int WGN, int ORDER, int EPI>
+template <int KS, int BM, int BN, int WGM, int WGN, int ORDER, int EPI, bool PERSIST = false>
 static int launch_one(hipStream_t st, const ConvArgs &a, int ksplit = 1)
 {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     const size_t lds = (size_t)NSTAGE * (BM + BN) * LDK * sizeof(float);
-    auto kern = conv_igemm_f32<KS, BM, BN, WGM, WGN, ORDER, EPI>;
+    auto kern = conv_igemm_f32<KS, BM, BN, WGM, WGN, ORDER, EPI, PERSIST>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -561,18 +682,35 @@ static int launch_one(hipStream_t st, const ConvArgs &a, int ksplit = 1)
             return 1;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ntn), (unsigned)ksplit, (unsigned)(a.zbatch > 1 ? a.zbatch : 1)),
-                       dim3(64 * WGM * WGN), lds, st, a);
+    // one workgroup per tile, or -- with more tiles than resident slots -- a persistent grid of one
+    // workgroup per slot (256 CUs x 2 four-wave workgroups, or x 1 of the 8/16-wave ones) that walks the tiles
+    int grid = ntm * ntn * (a.zbatch > 1 ? a.zbatch : 1);
+#if DT_GLDS && DT_BK == 32
+    static const int persist_env = [] { const char *e = getenv("DT_PERSIST"); return e ? atoi(e) : 1; }();
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n;
+    }();
+    const int slots = ((cus * (WGM * WGN > 4 ? 1 : 2)) / 8) * 8;   // multiple of 8: L % 8 stays the XCD
+    if (PERSIST && persist_env && ksplit == 1 && slots > 0 && grid > slots) grid = slots;
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ksplit), dim3(64 * WGM * WGN), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 template <int KS, int ORDER, int EPI>
 static int launch_cfg(hipStream_t st, const ConvArgs &a, int cfg)
 {
-    if (cfg == CFG_128x64) return launch_one<KS, 128, 64, 4, 1, ORDER, EPI>(st, a);
-    if (cfg == CFG_256x128) return launch_one<KS, 256, 128, 4, 2, ORDER, EPI>(st, a);   // 8 waves, 1 workgroup per CU
-    if (cfg == CFG_256x256) return launch_one<KS, 256, 256, 4, 4, ORDER, EPI>(st, a);   // 16 waves, 1 workgroup per CU
-    return launch_one<KS, 128, 128, 2, 2, ORDER, EPI>(st, a);
+    // The GEMM-shaped launches (1x1 layers and the batched Winograd GEMMs: short K, many tiles) use the
+    // persistent form of the kernel; the 3x3 layers keep one tile per workgroup (long K per tile, and the
+    // extra live state of the tile loop costs them registers).
+    constexpr bool P = (KS == 1 && ORDER == ORD_LINEAR && EPI == EPI_PLAIN) && DT_GLDS && DT_BK == 32;
+    if (cfg == CFG_128x64) return launch_one<KS, 128, 64, 4, 1, ORDER, EPI, P>(st, a);
+    if (cfg == CFG_256x128) return launch_one<KS, 256, 128, 4, 2, ORDER, EPI, P>(st, a);   // 8 waves, 1 workgroup per CU
+    if (cfg == CFG_256x256) return launch_one<KS, 256, 256, 4, 4, ORDER, EPI, P>(st, a);   // 16 waves, 1 workgroup per CU
+    return launch_one<KS, 128, 128, 2, 2, ORDER, EPI, P>(st, a);
 }
 
 int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, int epi, int cfg)
@@ -602,6 +740,7 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
     }
     a.zeros = zeros_dev;
     if (a.Cin % KCH != 0 || a.K != ks * ks * a.Cin) return 2;
+    if (ks == 1 && order == ORD_LINEAR && a.in_bs != (long long)a.H * a.W * a.in_ld) return 2;   // flat row addressing
     if (epi == EPI_GATES) {
         if (order != ORD_LINEAR) return 2;
         if (ks == 3 && cfg == CFG_256x256) return launch_one<3, 256, 256, 8, 2, ORD_LINEAR, EPI_GATES>(st, a);   // 16 waves

@@ -274,7 +274,7 @@ static void prof_direct_form(dt_ctx *ctx, double flops)
 // ---------------------------------------------------------------------------
 // Winograd F(2x2,3x3) path for the wide 3x3 layers (winograd.hip)
 // ---------------------------------------------------------------------------
-// DT_WINO: 1 (default) = wide layers (Cin, Cout >= 256) when a launch has >= 1024 tiles;
+// DT_WINO: 1 (default) = wide layers (Cin >= 128, Cout >= 256) when a launch has >= 1024 tiles;
 //          0 = never (direct MFMA form everywhere); 2 = every 3x3 layer the transforms support,
 //          at any size (parity tests of the path at small shapes).  Read when weights are loaded.
 static int wino_mode()
@@ -287,7 +287,8 @@ static bool wino_wanted(int ks, int cin, int cout)
 {
     const int mode = wino_mode();
     if (ks != 3 || mode == 0 || cin % 32 || cout % 4) return false;
-    return mode == 2 || (cin >= 256 && cout >= 256);
+    static const int minc = [] { const char *e = getenv("DT_WINO_MINC"); return e ? atoi(e) : 128; }();   // A/B runs
+    return mode == 2 || (cin >= minc && cout >= 256);
 }
 
 static bool wino_runs(const float *wino_wt, int B, int H, int W)
@@ -306,19 +307,21 @@ static int upload_wino(dt_ctx *ctx, float **dst, const float *hwio, int cin_src,
     return upload(ctx, dst, u);
 }
 
-// Tile configuration of the 16 batched GEMMs [Mt x Cin] x [Cin x N]
-// Measured (tools/wino_ab.sh): with K = Cin >= 512 a tile lasts >= 16 chunks and the 4-wave 128x128 tile
-// wins (128.6 vs 121.4 TFLOP/s at K=1024) -- two workgroups per CU overlap one's epilogue / next prologue
-// with the other's MFMAs, which the single resident 256x256 workgroup cannot; at K = 256 the 256x256
-// tile's lower staging cost still wins (116.7 vs 112.7).
+// Tile configuration of the 16 batched GEMMs [Mt x Cin] x [Cin x N] (persistent launch, conv_igemm.hip).
+// Measured (tools/wino_ab.sh): a GEMM tile is only Cin/32 = 4..40 chunks long, so what matters is what
+// happens BETWEEN tiles.  One tile per workgroup: 128x128 (two workgroups per CU overlap each other's
+// epilogue/prologue) 128.6 vs 256x256 121.4 TFLOP/s at K=1024.  Persistent with the next tile's first DMA
+// issued inside the last chunk: 256x256 132.4 (K=1024), 128.3 (K=512), 122.3 (K=256) -- ahead of 128x128
+// everywhere, so the wide tile is taken whenever wave quantisation does not eat the gain.
 static int pick_cfg_gemm(int Mt, int N, int K)
 {
-    if (N % 256 == 0 && K < 512) {
+    (void)K;
+    if (N % 256 == 0) {
         const long long t256 = 16ll * ((Mt + 255) / 256) * (N / 256);
         const long long t128 = 16ll * ((Mt + 127) / 128) * (N / 128);
         const double e256 = (double)Mt / (((Mt + 255) / 256) * 256.0) * (double)t256 / (double)(((t256 + 255) / 256) * 256);
         const double e128 = (double)Mt / (((Mt + 127) / 128) * 128.0) * (double)t128 / (double)(((t128 + 511) / 512) * 512);
-        if (e256 * 1.05 > e128) return CFG_256x256;
+        if (e256 * 1.03 > e128) return CFG_256x256;
     }
     return CFG_128x128;
 }
