@@ -73,14 +73,15 @@ void pack_conv_weights(const float *hwio, int ks, int cin_src, int cout_src, con
 // Winograd F(2x2,3x3) transforms around the batched MFMA GEMM (winograd.hip)
 // ---------------------------------------------------------------------------
 struct WinoArgs {
-    // geometry: B images of H x W; th x tw tiles of 2x2 outputs per image; Mt = B*th*tw
-    int B, H, W, th, tw, Mt;
-    // input transform: in (NHWC, pixel stride in_ld, image stride in_bs), C channels -> v [16][Mt][C]
+    // geometry: B images of H x W; th x tw tiles of ts x ts outputs per image (ts = 2 or 4); Mt = B*th*tw;
+    // P = (ts+2)^2 Winograd positions
+    int B, H, W, th, tw, Mt, ts;
+    // input transform: in (NHWC, pixel stride in_ld, image stride in_bs), C channels -> v [P][Mt][C]
     const float *in;
     long long in_bs;
     int in_ld, C;
     float *v;
-    // output transform: m [16][Mt][m_ld], N columns -> out (full resolution, may be null) / out2 (2x2 pooled, may be null)
+    // output transform: m [P][Mt][m_ld], N columns -> out (full resolution, may be null) / out2 (2x2 pooled, may be null)
     const float *m;
     int m_ld, N;
     const float *bias;
@@ -100,7 +101,7 @@ struct WinoArgs {
 };
 int launch_wino_input(hipStream_t st, const WinoArgs &a);
 int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates);
-void wino_pack_weights(const float *hwio, int cin_src, int cout_src, const int *cin_map, int cin_dst, const int *n_map,
+void wino_pack_weights(int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map, int cin_dst, const int *n_map,
                        int npad, const float *scale, float *dst);
 
 // ---------------------------------------------------------------------------
@@ -167,7 +168,8 @@ struct DevBuf {
 struct ConvLayer {
     int idx, ks, cin, cout, npad, pool;  // pool: reference MaxPooling2D after this layer
     float *wt = nullptr;                 // device, packed
-    float *wino = nullptr;               // device, [16][npad][cin] Winograd-domain weights (wide 3x3 layers) or null
+    float *wino = nullptr;               // device, [P][npad][cin] Winograd-domain weights (wide 3x3 layers) or null
+    int wino_ts = 0;                     // their output tile size (2 or 4)
     float *bias = nullptr;               // device, [npad]
 };
 
@@ -188,6 +190,7 @@ struct dt_ctx {
     float *trk_wx = nullptr, *trk_bx = nullptr;   // input conv, N gate-interleaved
     float *trk_wh = nullptr;                      // recurrent conv
     float *trk_wx_wino = nullptr, *trk_wh_wino = nullptr;   // their Winograd-domain forms
+    int trk_wino_ts = 0;
     float *trk_wo = nullptr, *trk_bo = nullptr;   // tconv_2 1x1
     int trk_wo_npad = 0;
     // tiny tracker

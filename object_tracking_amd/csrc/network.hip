@@ -186,7 +186,8 @@ static void oihw_to_hwio(const float *src, int O, int I, int k, std::vector<floa
 }
 
 static bool wino_wanted(int ks, int cin, int cout);
-static int upload_wino(dt_ctx *ctx, float **dst, const float *hwio, int cin_src, int cout_src, const int *cin_map,
+static int wino_tile();
+static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map,
                        int cin_dst, const int *n_map, int npad, const float *scale);
 
 static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, const float *hwio, const float *scale,
@@ -203,7 +204,8 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
     if (rc) return rc;
     if (L.wino) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino); L.wino = nullptr; }
     if (wino_wanted(ks, cin, cout)) {
-        rc = upload_wino(ctx, &L.wino, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale);
+        L.wino_ts = wino_tile();
+        rc = upload_wino(ctx, &L.wino, L.wino_ts, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale);
         if (rc) return rc;
     }
     return upload(ctx, &L.bias, bias);
@@ -291,34 +293,42 @@ static bool wino_wanted(int ks, int cin, int cout)
     return mode == 2 || (cin >= minc && cout >= 256);
 }
 
-static bool wino_runs(const float *wino_wt, int B, int H, int W)
+// DT_WINO_TILE: output tile of the Winograd form, 4 = F(4x4,3x3) (default), 2 = F(2x2,3x3).  Read when
+// weights are loaded.
+static int wino_tile()
 {
-    if (!wino_wt) return false;
-    const long long mt = (long long)B * ((H + 1) / 2) * ((W + 1) / 2);
-    if (mt >= (1ll << 31) / 16) return false;
-    return wino_mode() == 2 || mt >= 1024;
+    const char *e = getenv("DT_WINO_TILE");
+    return (e && atoi(e) == 2) ? 2 : 4;
 }
 
-static int upload_wino(dt_ctx *ctx, float **dst, const float *hwio, int cin_src, int cout_src, const int *cin_map,
+static bool wino_runs(const float *wino_wt, int ts, int B, int H, int W)
+{
+    if (!wino_wt) return false;
+    const long long mt = (long long)B * ((H + ts - 1) / ts) * ((W + ts - 1) / ts);
+    if (mt >= (1ll << 31) / 64) return false;
+    // below this many tiles the batched GEMMs' row tiles are mostly empty and the direct (split-K) form wins
+    return wino_mode() == 2 || mt >= (ts == 2 ? 1024 : 512);
+}
+
+static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map,
                        int cin_dst, const int *n_map, int npad, const float *scale)
 {
-    std::vector<float> u((size_t)16 * npad * cin_dst);
-    wino_pack_weights(hwio, cin_src, cout_src, cin_map, cin_dst, n_map, npad, scale, u.data());
+    std::vector<float> u((size_t)(ts + 2) * (ts + 2) * npad * cin_dst);
+    wino_pack_weights(ts, hwio, cin_src, cout_src, cin_map, cin_dst, n_map, npad, scale, u.data());
     return upload(ctx, dst, u);
 }
 
-// Tile configuration of the 16 batched GEMMs [Mt x Cin] x [Cin x N] (persistent launch, conv_igemm.hip).
+// Tile configuration of the P batched GEMMs [Mt x Cin] x [Cin x N] (persistent launch, conv_igemm.hip).
 // Measured (tools/wino_ab.sh): a GEMM tile is only Cin/32 = 4..40 chunks long, so what matters is what
 // happens BETWEEN tiles.  One tile per workgroup: 128x128 (two workgroups per CU overlap each other's
 // epilogue/prologue) 128.6 vs 256x256 121.4 TFLOP/s at K=1024.  Persistent with the next tile's first DMA
 // issued inside the last chunk: 256x256 132.4 (K=1024), 128.3 (K=512), 122.3 (K=256) -- ahead of 128x128
 // everywhere, so the wide tile is taken whenever wave quantisation does not eat the gain.
-static int pick_cfg_gemm(int Mt, int N, int K)
+static int pick_cfg_gemm(int Mt, int N, int P)
 {
-    (void)K;
     if (N % 256 == 0) {
-        const long long t256 = 16ll * ((Mt + 255) / 256) * (N / 256);
-        const long long t128 = 16ll * ((Mt + 127) / 128) * (N / 128);
+        const long long t256 = (long long)P * ((Mt + 255) / 256) * (N / 256);
+        const long long t128 = (long long)P * ((Mt + 127) / 128) * (N / 128);
         const double e256 = (double)Mt / (((Mt + 255) / 256) * 256.0) * (double)t256 / (double)(((t256 + 255) / 256) * 256);
         const double e128 = (double)Mt / (((Mt + 127) / 128) * 128.0) * (double)t128 / (double)(((t128 + 511) / 512) * 512);
         if (e256 * 1.03 > e128) return CFG_256x256;
@@ -334,15 +344,16 @@ struct WinoIO {
     float *cstate; long long c_bs; int c_ld;
 };
 
-static int run_wino(dt_ctx *ctx, const float *wino_wt, const float *bias, int cin, int N, int npad, int B, int H,
+static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias, int cin, int N, int npad, int B, int H,
                     int W, const WinoIO &io, float slope, const char *tag)
 {
     WinoArgs w;
     memset(&w, 0, sizeof(w));
-    w.B = B; w.H = H; w.W = W; w.th = (H + 1) / 2; w.tw = (W + 1) / 2; w.Mt = B * w.th * w.tw;
+    w.B = B; w.H = H; w.W = W; w.ts = ts; w.th = (H + ts - 1) / ts; w.tw = (W + ts - 1) / ts; w.Mt = B * w.th * w.tw;
+    const int P = (ts + 2) * (ts + 2);
     const size_t mt = (size_t)w.Mt;
-    float *V = ws_get(ctx, "wino_v", 16 * mt * cin * sizeof(float));
-    float *Mp = ws_get(ctx, "wino_m", 16 * mt * N * sizeof(float));
+    float *V = ws_get(ctx, "wino_v", P * mt * cin * sizeof(float));
+    float *Mp = ws_get(ctx, "wino_m", P * mt * N * sizeof(float));
     if (!V || !Mp) return DT_ERR_DEVICE;
     w.in = io.in; w.in_bs = io.in_bs; w.in_ld = io.in_ld; w.C = cin; w.v = V;
     w.m = Mp; w.m_ld = N; w.N = N; w.bias = bias; w.slope = slope;
@@ -350,7 +361,7 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, const float *bias, int ci
     w.xproj = io.xproj; w.xp_bs = io.xp_bs; w.xp_ld = io.xp_ld;
     w.cstate = io.cstate; w.c_bs = io.c_bs; w.c_ld = io.c_ld;
     {
-        ProfScope ps(ctx, "wino_input", 0.0, 4.0 * ((double)B * H * W * cin + 16.0 * mt * cin), tag);
+        ProfScope ps(ctx, "wino_input", 0.0, 4.0 * ((double)B * H * W * cin + (double)P * mt * cin), tag);
         const int rc = launch_wino_input(ctx->stream, w);
         if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: Winograd input transform launch failed", tag);
     }
@@ -362,13 +373,13 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, const float *bias, int ci
         a.out = Mp; a.out_ld = N; a.out_bs = (long long)mt * N;
         a.B = 1; a.H = 1; a.W = w.Mt; a.Cin = cin; a.N = N; a.M = w.Mt; a.K = cin;
         a.npad = npad; a.slope = 1.0f;
-        a.zbatch = 16; a.z_in = (long long)mt * cin; a.z_wt = (long long)npad * cin; a.z_out = (long long)mt * N;
-        // flops = executed MFMA work of the 16 GEMMs (the direct form of the same layer would be 2.25x
-        // that, 1.94x at 13x13); bytes = V + U + M'
-        ProfScope ps(ctx, "conv_igemm", 32.0 * mt * (double)cin * N,
-                     4.0 * 16.0 * ((double)mt * cin + (double)cin * N + (double)mt * N), tag);
+        a.zbatch = P; a.z_in = (long long)mt * cin; a.z_wt = (long long)npad * cin; a.z_out = (long long)mt * N;
+        // flops = executed MFMA work of the P GEMMs (the direct form of the same layer is 9*ts*ts/P times
+        // that on whole tiles: 4x for F(4x4,3x3), 2.25x for F(2x2,3x3)); bytes = V + U + M'
+        ProfScope ps(ctx, "conv_igemm", 2.0 * P * mt * (double)cin * N,
+                     4.0 * P * ((double)mt * cin + (double)cin * N + (double)mt * N), tag);
         prof_direct_form(ctx, 2.0 * B * H * W * 9.0 * cin * N);
-        int cfg = pick_cfg_gemm(w.Mt, N, cin);
+        int cfg = pick_cfg_gemm(w.Mt, N, P);
         if (const char *e = getenv("DT_WINO_CFG")) cfg = atoi(e);     // A/B runs
         if (const char *e = getenv("DT_WINO_GN")) a.tile_gn = -atoi(e) - 1;   // A/B runs: column-group width (see launch_conv_igemm)
         const int rc = launch_conv_igemm(ctx->stream, a, 1, ORD_LINEAR, EPI_PLAIN, cfg);
@@ -377,7 +388,7 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, const float *bias, int ci
     {
         const double outb = (io.out ? (double)B * H * W * N : 0.0) + (io.out2 ? (double)B * H * W * N / 4.0 : 0.0) +
                             (io.cstate ? 3.0 * B * H * W * N / 4.0 + (double)B * H * W * N : 0.0);
-        ProfScope ps(ctx, "wino_output", 0.0, 4.0 * (16.0 * mt * N + outb), tag);
+        ProfScope ps(ctx, "wino_output", 0.0, 4.0 * ((double)P * mt * N + outb), tag);
         const int rc = launch_wino_output(ctx->stream, w, io.cstate != nullptr);
         if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: Winograd output transform launch failed", tag);
     }
@@ -421,13 +432,13 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
                                 (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0));
     char tag[32];
     snprintf(tag, sizeof(tag), L.idx == 102 ? "tconv_2" : "conv_%d", L.idx);
-    if (wino_runs(L.wino, B, H, W) && ((epi == EPI_PLAIN && order == ORD_LINEAR) || epi == EPI_POOL || epi == EPI_POOL_BOTH)) {
+    if (wino_runs(L.wino, L.wino_ts, B, H, W) && ((epi == EPI_PLAIN && order == ORD_LINEAR) || epi == EPI_POOL || epi == EPI_POOL_BOTH)) {
         WinoIO io;
         memset(&io, 0, sizeof(io));
         io.in = in; io.in_ld = in_ld; io.in_bs = a.in_bs;
         if (epi == EPI_POOL) { io.out2 = out; io.out2_ld = out_ld; }
         else { io.out = out; io.out_ld = out_ld; io.out_bs = a.out_bs; io.out2 = out2; io.out2_ld = out2_ld; }
-        return run_wino(ctx, L.wino, L.bias, L.cin, L.cout, L.npad, B, H, W, io, slope, tag);
+        return run_wino(ctx, L.wino, L.wino_ts, L.bias, L.cin, L.cout, L.npad, B, H, W, io, slope, tag);
     }
     // Wave quantisation for small batches (few frames at 13x13 / 26x26): with 512 resident
     // workgroup slots (256 CUs x 2) a layer of a few hundred output tiles leaves the chip
@@ -677,11 +688,14 @@ extern "C" int dt_tracker_load(dt_ctx *ctx, int units, const float *h_kernel, co
     if ((rc = upload(ctx, &ctx->trk_bo, bo))) return rc;
     for (float **w : {&ctx->trk_wx_wino, &ctx->trk_wh_wino})
         if (*w) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(*w); *w = nullptr; }
+    ctx->trk_wino_ts = wino_tile();
     if (wino_wanted(3, Cx, 4 * U) &&
-        (rc = upload_wino(ctx, &ctx->trk_wx_wino, h_kernel, Csrc, 4 * U, cin_map.data(), Cx, n_map.data(), 4 * U, nullptr)))
+        (rc = upload_wino(ctx, &ctx->trk_wx_wino, ctx->trk_wino_ts, h_kernel, Csrc, 4 * U, cin_map.data(), Cx, n_map.data(),
+                          4 * U, nullptr)))
         return rc;
     if (wino_wanted(3, U, 4 * U) &&
-        (rc = upload_wino(ctx, &ctx->trk_wh_wino, h_recurrent, U, 4 * U, nullptr, U, n_map.data(), 4 * U, nullptr)))
+        (rc = upload_wino(ctx, &ctx->trk_wh_wino, ctx->trk_wino_ts, h_recurrent, U, 4 * U, nullptr, U, n_map.data(), 4 * U,
+                          nullptr)))
         return rc;
     ctx->trk_units = U; ctx->trk_cx = Cx; ctx->trk_wo_npad = npad;
     ctx->trk_loaded = true;
@@ -697,12 +711,12 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
     float *xproj = ws_get(ctx, "trk_xproj", (size_t)F * GG * N4 * sizeof(float));
     float *cst = ws_get(ctx, "trk_c", (size_t)n_clips * GG * U * sizeof(float));
     if (!xproj || !cst) return DT_ERR_DEVICE;
-    if (wino_runs(wx_wino, F, gh, gw)) {
+    if (wino_runs(wx_wino, ctx->trk_wino_ts, F, gh, gw)) {
         WinoIO io;
         memset(&io, 0, sizeof(io));
         io.in = z; io.in_ld = Cx; io.in_bs = (long long)GG * Cx;
         io.out = xproj; io.out_ld = N4; io.out_bs = (long long)GG * N4;
-        const int rc = run_wino(ctx, wx_wino, bx, Cx, N4, N4, F, gh, gw, io, 1.0f, "convlstm_xproj");
+        const int rc = run_wino(ctx, wx_wino, ctx->trk_wino_ts, bx, Cx, N4, N4, F, gh, gw, io, 1.0f, "convlstm_xproj");
         if (rc) return rc;
     } else {
         ConvArgs a;
@@ -726,14 +740,14 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM t=0 launch failed");
     }
     for (int t = 1; t < T; ++t) {
-        if (wino_runs(wh_wino, n_clips, gh, gw)) {
+        if (wino_runs(wh_wino, ctx->trk_wino_ts, n_clips, gh, gw)) {
             WinoIO io;
             memset(&io, 0, sizeof(io));
             io.in = hseq + (long long)(t - 1) * GG * U; io.in_ld = U; io.in_bs = h_bs;
             io.out = hseq + (long long)t * GG * U; io.out_ld = U; io.out_bs = h_bs;
             io.xproj = xproj + (long long)t * GG * N4; io.xp_ld = N4; io.xp_bs = xp_bs;
             io.cstate = cst; io.c_ld = U; io.c_bs = c_bs;
-            const int rc = run_wino(ctx, wh_wino, nullptr, U, N4, N4, n_clips, gh, gw, io, 1.0f, "convlstm_step");
+            const int rc = run_wino(ctx, wh_wino, ctx->trk_wino_ts, nullptr, U, N4, N4, n_clips, gh, gw, io, 1.0f, "convlstm_step");
             if (rc) return rc;
             continue;
         }
@@ -1026,21 +1040,22 @@ extern "C" int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int
     if (!xproj) return DT_ERR_DEVICE;
     if (wino_mode() == 2 && wino_wanted(3, Cx, N4) && wino_wanted(3, U, N4)) {   // the same step through the Winograd path
         float *uwx = nullptr, *uwh = nullptr;
-        if ((rc = upload_wino(ctx, &uwx, h_kernel, Cx, N4, nullptr, Cx, n_map.data(), N4, nullptr)) ||
-            (rc = upload_wino(ctx, &uwh, h_recurrent, U, N4, nullptr, U, n_map.data(), N4, nullptr)))
+        const int ts = wino_tile();
+        if ((rc = upload_wino(ctx, &uwx, ts, h_kernel, Cx, N4, nullptr, Cx, n_map.data(), N4, nullptr)) ||
+            (rc = upload_wino(ctx, &uwh, ts, h_recurrent, U, N4, nullptr, U, n_map.data(), N4, nullptr)))
             return rc;
         WinoIO io;
         memset(&io, 0, sizeof(io));
         io.in = d_x; io.in_ld = Cx; io.in_bs = (long long)GG * Cx;
         io.out = xproj; io.out_ld = N4; io.out_bs = (long long)GG * N4;
-        if ((rc = run_wino(ctx, uwx, dbx, Cx, N4, N4, B, H, W, io, 1.0f, "convlstm_xproj"))) return rc;
+        if ((rc = run_wino(ctx, uwx, ts, dbx, Cx, N4, N4, B, H, W, io, 1.0f, "convlstm_xproj"))) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(d_c_out, d_c, (size_t)B * GG * U * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         memset(&io, 0, sizeof(io));
         io.in = d_h; io.in_ld = U; io.in_bs = (long long)GG * U;
         io.out = d_h_out; io.out_ld = U; io.out_bs = (long long)GG * U;
         io.xproj = xproj; io.xp_ld = N4; io.xp_bs = (long long)GG * N4;
         io.cstate = d_c_out; io.c_ld = U; io.c_bs = (long long)GG * U;
-        if ((rc = run_wino(ctx, uwh, nullptr, U, N4, N4, B, H, W, io, 1.0f, "convlstm_step"))) return rc;
+        if ((rc = run_wino(ctx, uwh, ts, nullptr, U, N4, N4, B, H, W, io, 1.0f, "convlstm_step"))) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(dwx); (void)hipFree(dwh); (void)hipFree(dbx); (void)hipFree(uwx); (void)hipFree(uwh);
         return DT_OK;

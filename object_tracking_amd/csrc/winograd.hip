@@ -1,74 +1,148 @@
-// winograd.hip -- Winograd F(2x2, 3x3) form of the reference's 3x3 'same' stride-1 convolutions
+// winograd.hip -- Winograd form of the reference's 3x3 'same' stride-1 convolutions
 // (models_detection/KerasYOLO.py:279-396 conv blocks, models_tracking/MultiObjDetTracker.py:176
 // ConvLSTM2D input and recurrent convolutions) for the wide layers, where it pays:
 //
-//     Y = At [ (G g Gt) .* (Bt d B) ] A          per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//     Y = At [ (G g Gt) .* (Bt d B) ] A      per TSxTS output tile, (TS+2)x(TS+2) input patch d, 3x3 filter g
 //
-// 16 multiplies per 4 outputs instead of 36: the MFMA work of a layer drops 2.25x (1.94x at 13x13,
-// whose 7x7 tiles cover 14x14).  The contraction over input channels becomes 16 independent GEMMs
-//     M'[p][tile][cout] = sum_c V[p][tile][c] * U[p][cout][c],      p = 4*xi + nu
-// which run as ONE launch of the fp32 MFMA kernel of conv_igemm.hip (1x1 path, grid.z = 16), so the
-// matrix-core code is shared with the direct form.  This file holds what is around it:
-//   wino_input_kernel    activation NHWC -> V [16][tiles][Cin]        (Bt d B; HBM-bound, 1 read : 4 writes)
-//   wino_output_kernel   M' [16][tiles][Cout] -> NHWC output           (At m A + bias + LeakyReLU
-//                        [+ MaxPooling2D(2,2): an output tile IS a pooling window]; or the ConvLSTM
-//                        gate update of MultiObjDetTracker.py:176 in registers)
-//   wino_pack_weights    host: U = G g Gt per (cin, cout), packed per position for the MFMA kernel
-// fp32 throughout; the transforms only add/subtract (and halve, in G), so the result differs from
-// the direct form by rounding only (measured: same error against float64 as the direct kernel).
+// F(4x4,3x3) (TS=4, default): 36 multiplies per 16 outputs instead of 144 -- the MFMA work of a layer
+// drops 4x (2.64x at 13x13, whose 4x4 tiles cover 16x16; 3.45x at 26x26).  F(2x2,3x3) (TS=2): 16 per 4
+// outputs, 2.25x (1.94x at 13x13); kept selectable (DT_WINO_TILE=2) -- its fp32 rounding error equals the
+// direct form's, F(4x4,3x3)'s is ~15x that (1.5e-5 absolute at activation scale 4; SURVEY.md's bar is 1e-3).
+// The contraction over input channels becomes P = (TS+2)^2 independent GEMMs
+//     M'[p][tile][cout] = sum_c V[p][tile][c] * U[p][cout][c],      p = (TS+2)*xi + nu
+// which run as ONE persistent launch of the fp32 MFMA kernel of conv_igemm.hip (1x1 path, P problems), so
+// the matrix-core code is shared with the direct form.  This file holds what is around it:
+//   wino_input_kernel    activation NHWC -> V [P][tiles][Cin]          (Bt d B; HBM-bound)
+//   wino_output_kernel   M' [P][tiles][Cout] -> NHWC output             (At m A + bias + LeakyReLU
+//                        [+ MaxPooling2D(2,2): tiles start on even coordinates, so pooling windows never
+//                        straddle tiles])
+//   wino_output_gates_kernel   the same transform followed by the ConvLSTM2D gate update of
+//                        MultiObjDetTracker.py:176 in registers
+//   wino_pack_weights    host: U = G g Gt per (cin, cout), laid out per position for the MFMA kernel
+// fp32 throughout.
+#include <thread>
+
 #include "dt_internal.h"
 
 #define WINO_THREADS 256
 
-__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
-__device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+template <int V> struct VecOf;
+template <> struct VecOf<1> { typedef float T; };
+template <> struct VecOf<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<4> { typedef float T __attribute__((ext_vector_type(4))); };
+
+template <int V> __device__ __forceinline__ typename VecOf<V>::T vload(const float *p)
+{
+    return *reinterpret_cast<const typename VecOf<V>::T *>(p);
+}
+template <int V> __device__ __forceinline__ void vstore(float *p, typename VecOf<V>::T v)
+{
+    *reinterpret_cast<typename VecOf<V>::T *>(p) = v;
+}
+template <int V> __device__ __forceinline__ float lane_of(const typename VecOf<V>::T &v, int e) { return v[e]; }
+template <> __device__ __forceinline__ float lane_of<1>(const float &v, int) { return v; }
+template <int V> __device__ __forceinline__ void set_lane(typename VecOf<V>::T &v, int e, float x) { v[e] = x; }
+template <> __device__ __forceinline__ void set_lane<1>(float &v, int, float x) { v = x; }
+template <int V> __device__ __forceinline__ typename VecOf<V>::T vzero()
+{
+    typename VecOf<V>::T z;
+#pragma unroll
+    for (int e = 0; e < V; ++e) set_lane<V>(z, e, 0.0f);
+    return z;
+}
+
+// 1-D transforms (Lavin & Gray, "Fast Algorithms for Convolutional Neural Networks", the standard
+// interpolation points 0, +-1 for F(2,3) and 0, +-1, +-2 for F(4,3)), applied to rows then columns.
+//   bt: (TS+2) inputs -> (TS+2) outputs in place;  at: (TS+2) inputs -> TS outputs (first TS slots)
+template <int TS, typename T> __device__ __forceinline__ void bt_1d(T *d)
+{
+    if (TS == 2) {
+        const T t0 = d[0] - d[2], t1 = d[1] + d[2], t2 = d[2] - d[1], t3 = d[1] - d[3];
+        d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3;
+    } else {
+        const T t0 = 4.0f * d[0] - 5.0f * d[2] + d[4];
+        const T t1 = -4.0f * (d[1] + d[2]) + d[3] + d[4];
+        const T t2 = 4.0f * (d[1] - d[2]) - d[3] + d[4];
+        const T t3 = 2.0f * (d[3] - d[1]) - d[2] + d[4];
+        const T t4 = 2.0f * (d[1] - d[3]) - d[2] + d[4];
+        const T t5 = 4.0f * d[1] - 5.0f * d[3] + d[5];
+        d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3; d[4] = t4; d[5] = t5;
+    }
+}
+template <int TS, typename T> __device__ __forceinline__ void at_1d(T *m)
+{
+    if (TS == 2) {
+        const T y0 = m[0] + m[1] + m[2], y1 = m[1] - m[2] - m[3];
+        m[0] = y0; m[1] = y1;
+    } else {
+        const T a = m[1] + m[2], b = m[1] - m[2], c = m[3] + m[4], e = m[3] - m[4];
+        const T y0 = m[0] + a + c;
+        const T y1 = b + 2.0f * e;
+        const T y2 = a + 4.0f * c;
+        const T y3 = b + 8.0f * e + m[5];
+        m[0] = y0; m[1] = y1; m[2] = y2; m[3] = y3;
+    }
+}
+
+struct TileId {
+    int b, ty, tx;
+};
+__device__ __forceinline__ TileId tile_id(const WinoArgs &p, int tile)
+{
+    const int tpf = p.th * p.tw;
+    TileId t;
+    t.b = tile / tpf;
+    const int r = tile - t.b * tpf;
+    t.ty = r / p.tw;
+    t.tx = r - t.ty * p.tw;
+    return t;
+}
 
 // ---- input transform ----------------------------------------------------------------------------
-// One work item = (tile, 4 channels).  Tile (b, ty, tx) covers input rows 2ty-1 .. 2ty+2, cols
-// 2tx-1 .. 2tx+2 ('same' padding and the odd last row/column of 13x13 read as zero).
-__global__ __launch_bounds__(WINO_THREADS) void wino_input_kernel(WinoArgs p)
+// One work item = (tile, V channels).  Tile (b, ty, tx) covers input rows TS*ty-1 .. TS*ty+TS, cols
+// TS*tx-1 .. TS*tx+TS ('same' padding and the rows/columns past an image that is not a multiple of TS
+// read as zero).
+template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_input_kernel(WinoArgs p)
 {
-    const int cq_n = p.C >> 2;
+    typedef typename VecOf<V>::T T;
+    constexpr int NI = TS + 2;
+    const int cq_n = p.C / V;
     const long long items = (long long)p.Mt * cq_n;
-    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     const long long plane = (long long)p.Mt * p.C;
     for (long long it = (long long)blockIdx.x * WINO_THREADS + threadIdx.x; it < items;
          it += (long long)gridDim.x * WINO_THREADS) {
         const int tile = (int)(it / cq_n);
-        const int c = (int)(it - (long long)tile * cq_n) * 4;
-        const int tpf = p.th * p.tw;
-        const int b = tile / tpf;
-        const int r = tile - b * tpf;
-        const int ty = r / p.tw, tx = r - ty * p.tw;
-        const float *src = p.in + (long long)b * p.in_bs + c;
-        f32x4 d[4][4];
+        const int c = (int)(it - (long long)tile * cq_n) * V;
+        const TileId t = tile_id(p, tile);
+        const float *src = p.in + (long long)t.b * p.in_bs + c;
+        T d[NI][NI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int h = 2 * ty - 1 + i;
+        for (int i = 0; i < NI; ++i) {
+            const int h = TS * t.ty - 1 + i;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int w = 2 * tx - 1 + j;
+            for (int j = 0; j < NI; ++j) {
+                const int w = TS * t.tx - 1 + j;
                 const bool ok = h >= 0 && h < p.H && w >= 0 && w < p.W;
-                d[i][j] = ok ? ld4(src + (long long)(h * p.W + w) * p.in_ld) : zero;
+                d[i][j] = ok ? vload<V>(src + (long long)(h * p.W + w) * p.in_ld) : vzero<V>();
             }
         }
-        // Bt d : rows
-        f32x4 t[4][4];
+        // Bt d : down the columns
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[0][j] = d[0][j] - d[2][j];
-            t[1][j] = d[1][j] + d[2][j];
-            t[2][j] = d[2][j] - d[1][j];
-            t[3][j] = d[1][j] - d[3][j];
+        for (int j = 0; j < NI; ++j) {
+            T col[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) col[i] = d[i][j];
+            bt_1d<TS>(col);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) d[i][j] = col[i];
         }
+        // (Bt d) B : along the rows, stored plane by plane
         float *dst = p.v + (long long)tile * p.C + c;
-        // (Bt d) B : columns, stored plane by plane
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            st4(dst + (4 * i + 0) * plane, t[i][0] - t[i][2]);
-            st4(dst + (4 * i + 1) * plane, t[i][1] + t[i][2]);
-            st4(dst + (4 * i + 2) * plane, t[i][2] - t[i][1]);
-            st4(dst + (4 * i + 3) * plane, t[i][1] - t[i][3]);
+        for (int i = 0; i < NI; ++i) {
+            bt_1d<TS>(d[i]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) vstore<V>(dst + (long long)(NI * i + j) * plane, d[i][j]);
         }
     }
 }
@@ -80,131 +154,137 @@ __device__ __forceinline__ float wino_hard_sigmoid(float x)
     return fminf(fmaxf(y, 0.0f), 1.0f);
 }
 
-// At m A for four channels: m[16] planes -> y[2][2]
-__device__ __forceinline__ void wino_at_m_a(const f32x4 *m, f32x4 y[2][2])
+// At m A: loads the (TS+2)^2 planes of one (tile, V columns) item and leaves y[TS][TS] in m[i][j], i,j < TS
+template <int TS, int V>
+__device__ __forceinline__ void wino_at_m_a(const float *src, long long plane, typename VecOf<V>::T (*m)[TS + 2])
 {
-    f32x4 s0[4], s1[4];
+    typedef typename VecOf<V>::T T;
+    constexpr int NI = TS + 2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s0[j] = m[0 + j] + m[4 + j] + m[8 + j];
-        s1[j] = m[4 + j] - m[8 + j] - m[12 + j];
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) m[i][j] = vload<V>(src + (long long)(NI * i + j) * plane);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {   // At m : down the columns
+        T col[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) col[i] = m[i][j];
+        at_1d<TS>(col);
+#pragma unroll
+        for (int i = 0; i < TS; ++i) m[i][j] = col[i];
     }
-    y[0][0] = s0[0] + s0[1] + s0[2];
-    y[0][1] = s0[1] - s0[2] - s0[3];
-    y[1][0] = s1[0] + s1[1] + s1[2];
-    y[1][1] = s1[1] - s1[2] - s1[3];
+#pragma unroll
+    for (int i = 0; i < TS; ++i) at_1d<TS>(m[i]);   // (At m) A : along the rows
 }
 
 // ---- output transform, conv block epilogue -------------------------------------------------------
-// One work item = (tile, 4 output channels): bias + LeakyReLU, optional full-resolution output and
-// optional 2x2-pooled output (tiles start on even coordinates, so a tile is one pooling window).
-__global__ __launch_bounds__(WINO_THREADS) void wino_output_kernel(WinoArgs p)
+// One work item = (tile, V output channels): bias + LeakyReLU, optional full-resolution output and
+// optional 2x2-pooled output.
+template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_output_kernel(WinoArgs p)
 {
-    const int nq = (p.N + 3) >> 2;
+    typedef typename VecOf<V>::T T;
+    constexpr int NI = TS + 2;
+    const int nq = p.N / V;
     const long long items = (long long)p.Mt * nq;
     const long long plane = (long long)p.Mt * p.m_ld;
     for (long long it = (long long)blockIdx.x * WINO_THREADS + threadIdx.x; it < items;
          it += (long long)gridDim.x * WINO_THREADS) {
         const int tile = (int)(it / nq);
-        const int c = (int)(it - (long long)tile * nq) * 4;
-        const int tpf = p.th * p.tw;
-        const int b = tile / tpf;
-        const int r = tile - b * tpf;
-        const int ty = r / p.tw, tx = r - ty * p.tw;
-        const float *src = p.m + (long long)tile * p.m_ld + c;
-        f32x4 m[16];
+        const int c = (int)(it - (long long)tile * nq) * V;
+        const TileId t = tile_id(p, tile);
+        T m[NI][NI];
+        wino_at_m_a<TS, V>(p.m + (long long)tile * p.m_ld + c, plane, m);
+        const T bv = p.bias ? vload<V>(p.bias + c) : vzero<V>();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) m[q] = ld4(src + q * plane);
-        f32x4 y[2][2];
-        wino_at_m_a(m, y);
-        const f32x4 bv = p.bias ? ld4(p.bias + c) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        f32x4 mx;
+        for (int i = 0; i < TS; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TS; ++j) {
+                T v = m[i][j] + bv;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f32x4 v = y[i][j] + bv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = wino_leaky(v[e], p.slope);
-                y[i][j] = v;
-                if (i == 0 && j == 0) mx = v;
-                else
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], v[e]);
+                for (int e = 0; e < V; ++e) set_lane<V>(v, e, wino_leaky(lane_of<V>(v, e), p.slope));
+                m[i][j] = v;
             }
-        const int nvalid = min(4, p.N - c);
         if (p.out) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TS; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int h = 2 * ty + i, w = 2 * tx + j;
-                    if (h < p.H && w < p.W) {
-                        float *o = p.out + (long long)b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c;
-                        if (nvalid == 4) st4(o, y[i][j]);
-                        else
-                            for (int e = 0; e < nvalid; ++e) o[e] = y[i][j][e];
-                    }
+                for (int j = 0; j < TS; ++j) {
+                    const int h = TS * t.ty + i, w = TS * t.tx + j;
+                    if (h < p.H && w < p.W)
+                        vstore<V>(p.out + (long long)t.b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c, m[i][j]);
                 }
         }
         if (p.out2) {   // MaxPooling2D(2,2): H and W are even whenever the reference pools
-            float *o = p.out2 + ((long long)(b * (p.H >> 1) + ty) * (p.W >> 1) + tx) * p.out2_ld + c;
-            if (nvalid == 4) st4(o, mx);
-            else
-                for (int e = 0; e < nvalid; ++e) o[e] = mx[e];
+            const int H2 = p.H >> 1, W2 = p.W >> 1;
+#pragma unroll
+            for (int i = 0; i < TS / 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TS / 2; ++j) {
+                    const int h2 = (TS / 2) * t.ty + i, w2 = (TS / 2) * t.tx + j;
+                    if (h2 < H2 && w2 < W2) {
+                        T mx;
+#pragma unroll
+                        for (int e = 0; e < V; ++e)
+                            set_lane<V>(mx, e, fmaxf(fmaxf(lane_of<V>(m[2 * i][2 * j], e), lane_of<V>(m[2 * i][2 * j + 1], e)),
+                                                     fmaxf(lane_of<V>(m[2 * i + 1][2 * j], e), lane_of<V>(m[2 * i + 1][2 * j + 1], e))));
+                        vstore<V>(p.out2 + ((long long)(t.b * H2 + h2) * W2 + w2) * p.out2_ld + c, mx);
+                    }
+                }
         }
     }
 }
 
 // ---- output transform, ConvLSTM2D gate update ------------------------------------------------------
-// N axis packed [j/32][gate][j%32] like EPI_GATES of conv_igemm.hip.  One work item = (tile, 4 hidden
+// N axis packed [j/32][gate][j%32] like EPI_GATES of conv_igemm.hip.  One work item = (tile, V hidden
 // channels): the i,f,c,o pre-activations of the recurrent convolution come out of the transform in
 // registers, the input projection (bias included) is added, c is updated in place and h written.
-__global__ __launch_bounds__(WINO_THREADS) void wino_output_gates_kernel(WinoArgs p)
+template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_output_gates_kernel(WinoArgs p)
 {
+    typedef typename VecOf<V>::T T;
+    constexpr int NI = TS + 2;
     const int U = p.N >> 2;
-    const int uq = U >> 2;
+    const int uq = U / V;
     const long long items = (long long)p.Mt * uq;
     const long long plane = (long long)p.Mt * p.m_ld;
     for (long long it = (long long)blockIdx.x * WINO_THREADS + threadIdx.x; it < items;
          it += (long long)gridDim.x * WINO_THREADS) {
         const int tile = (int)(it / uq);
-        const int jc = (int)(it - (long long)tile * uq) * 4;          // hidden channel
+        const int jc = (int)(it - (long long)tile * uq) * V;          // hidden channel
         const int col = (jc >> 5) * 128 + (jc & 31);                  // column of gate i; f,c,o at +32,+64,+96
-        const int tpf = p.th * p.tw;
-        const int b = tile / tpf;
-        const int r = tile - b * tpf;
-        const int ty = r / p.tw, tx = r - ty * p.tw;
-        const float *src = p.m + (long long)tile * p.m_ld + col;
-        f32x4 y[4][2][2];
+        const TileId t = tile_id(p, tile);
+        T y[4][TS][TS];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 m[16];
+            T m[NI][NI];
+            wino_at_m_a<TS, V>(p.m + (long long)tile * p.m_ld + col + g * 32, plane, m);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) m[q] = ld4(src + q * plane + g * 32);
-            wino_at_m_a(m, y[g]);
+            for (int i = 0; i < TS; ++i)
+#pragma unroll
+                for (int j = 0; j < TS; ++j) y[g][i][j] = m[i][j];
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TS; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int h = 2 * ty + i, w = 2 * tx + j;
+            for (int j = 0; j < TS; ++j) {
+                const int h = TS * t.ty + i, w = TS * t.tx + j;
                 if (h >= p.H || w >= p.W) continue;
                 const long long pix = h * p.W + w;
-                const float *xp = p.xproj + (long long)b * p.xp_bs + pix * p.xp_ld + col;
-                const f32x4 zi = y[0][i][j] + ld4(xp), zf = y[1][i][j] + ld4(xp + 32);
-                const f32x4 zc = y[2][i][j] + ld4(xp + 64), zo = y[3][i][j] + ld4(xp + 96);
-                float *cp = p.cstate + (long long)b * p.c_bs + pix * p.c_ld + jc;
-                const f32x4 cprev = ld4(cp);
-                f32x4 cn, hn;
+                const float *xp = p.xproj + (long long)t.b * p.xp_bs + pix * p.xp_ld + col;
+                const T zi = y[0][i][j] + vload<V>(xp), zf = y[1][i][j] + vload<V>(xp + 32);
+                const T zc = y[2][i][j] + vload<V>(xp + 64), zo = y[3][i][j] + vload<V>(xp + 96);
+                float *cp = p.cstate + (long long)t.b * p.c_bs + pix * p.c_ld + jc;
+                const T cprev = vload<V>(cp);
+                T cn, hn;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float gi = wino_hard_sigmoid(zi[e]), gf = wino_hard_sigmoid(zf[e]), go = wino_hard_sigmoid(zo[e]);
-                    cn[e] = gf * cprev[e] + gi * tanhf(zc[e]);
-                    hn[e] = go * tanhf(cn[e]);
+                for (int e = 0; e < V; ++e) {
+                    const float gi = wino_hard_sigmoid(lane_of<V>(zi, e)), gf = wino_hard_sigmoid(lane_of<V>(zf, e));
+                    const float go = wino_hard_sigmoid(lane_of<V>(zo, e));
+                    const float cv = gf * lane_of<V>(cprev, e) + gi * tanhf(lane_of<V>(zc, e));
+                    set_lane<V>(cn, e, cv);
+                    set_lane<V>(hn, e, go * tanhf(cv));
                 }
-                st4(cp, cn);
-                st4(p.out + (long long)b * p.out_bs + pix * p.out_ld + jc, hn);
+                vstore<V>(cp, cn);
+                vstore<V>(p.out + (long long)t.b * p.out_bs + pix * p.out_ld + jc, hn);
             }
     }
 }
@@ -217,52 +297,79 @@ static unsigned wino_blocks(long long items)
     return (unsigned)(nb < 1 ? 1 : nb);
 }
 
+// vector width per work item: F(2,3) 4 channels, F(4,3) 2 (its 36-value patch would not fit in registers at 4)
 int launch_wino_input(hipStream_t st, const WinoArgs &a)
 {
-    if (a.C % 4 || a.in_ld % 4 || a.Mt <= 0) return 2;
-    hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)a.Mt * (a.C / 4))), dim3(WINO_THREADS), 0, st, a);
+    if (a.C % 4 || a.in_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4)) return 2;
+    if (a.ts == 2)
+        hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.C / 4))), dim3(WINO_THREADS), 0,
+                           st, a);
+    else
+        hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(wino_blocks((long long)a.Mt * (a.C / 2))), dim3(WINO_THREADS), 0,
+                           st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates)
 {
-    if (a.m_ld % 4 || a.Mt <= 0) return 2;
+    if (a.m_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4)) return 2;
     if (gates) {
         if (a.N % 128 || a.out_ld % 4 || a.c_ld % 4 || a.xp_ld % 4) return 2;
-        hipLaunchKernelGGL(wino_output_gates_kernel, dim3(wino_blocks((long long)a.Mt * (a.N / 16))), dim3(WINO_THREADS),
-                           0, st, a);
+        if (a.ts == 2)
+            hipLaunchKernelGGL((wino_output_gates_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.N / 16))),
+                               dim3(WINO_THREADS), 0, st, a);
+        else
+            hipLaunchKernelGGL((wino_output_gates_kernel<4, 1>), dim3(wino_blocks((long long)a.Mt * (a.N / 4))),
+                               dim3(WINO_THREADS), 0, st, a);
     } else {
-        // vector stores need 16-byte aligned rows; ragged N (conv_23-like heads) never takes this path
-        if ((a.out && a.out_ld % 4) || (a.out2 && a.out2_ld % 4)) return 2;
-        hipLaunchKernelGGL(wino_output_kernel, dim3(wino_blocks((long long)a.Mt * ((a.N + 3) / 4))), dim3(WINO_THREADS),
-                           0, st, a);
+        // vector stores need aligned rows; ragged N (conv_23-like heads) never takes this path
+        if (a.N % 4 || (a.out && a.out_ld % 4) || (a.out2 && a.out2_ld % 4)) return 2;
+        if (a.ts == 2)
+            hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.N / 4))), dim3(WINO_THREADS),
+                               0, st, a);
+        else
+            hipLaunchKernelGGL((wino_output_kernel<4, 2>), dim3(wino_blocks((long long)a.Mt * (a.N / 2))), dim3(WINO_THREADS),
+                               0, st, a);
     }
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-// Host: U[p] = (G g Gt)[xi][nu] for every (cin, cout), p = 4*xi + nu, as 16 HWIO-shaped [1,1,Cin,Cout]
-// kernels, each packed like a 1x1 layer of the MFMA kernel: dst [16][npad][cin_dst].
-//   G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
-void wino_pack_weights(const float *hwio, int cin_src, int cout_src, const int *cin_map, int cin_dst, const int *n_map,
-                       int npad, const float *scale, float *dst)
+// Host: U[p] = (G g Gt)[xi][nu] for every (cin, cout), p = (ts+2)*xi + nu, written directly in the MFMA
+// kernel's 1x1 weight layout dst[p][npad][cin_dst] (for a 1x1 kernel the packed K order is the channel order).
+//   cin_map[cin_dst] / n_map[npad]: source channel or -1 (zero), like pack_conv_weights; scale[cout_src]: folded BN
+void wino_pack_weights(int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map, int cin_dst,
+                       const int *n_map, int npad, const float *scale, float *dst)
 {
-    static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
-    const size_t plane = (size_t)cin_src * cout_src;
-    std::vector<float> u(16 * plane);
-    for (int ci = 0; ci < cin_src; ++ci)
-        for (int co = 0; co < cout_src; ++co) {
-            double g[3][3], t[4][3];
-            const double sc = scale ? (double)scale[co] : 1.0;
-            for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = (double)hwio[((size_t)k * cin_src + ci) * cout_src + co] * sc;
-            for (int xi = 0; xi < 4; ++xi)
-                for (int kx = 0; kx < 3; ++kx)
-                    t[xi][kx] = G[xi][0] * g[0][kx] + G[xi][1] * g[1][kx] + G[xi][2] * g[2][kx];
-            for (int xi = 0; xi < 4; ++xi)
-                for (int nu = 0; nu < 4; ++nu)
-                    u[(size_t)(4 * xi + nu) * plane + (size_t)ci * cout_src + co] =
-                        (float)(t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1] + t[xi][2] * G[nu][2]);
+    static const double G2[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+    static const double G4[6][3] = {{1. / 4, 0, 0},          {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
+                                    {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0, 0, 1}};
+    const int ni = ts + 2, P = ni * ni;
+    const double(*G)[3] = ts == 2 ? G2 : G4;
+    const size_t plane = (size_t)npad * cin_dst;
+    auto work = [&](int n_lo, int n_hi) {
+        for (int n = n_lo; n < n_hi; ++n) {
+            const int ns = n_map ? n_map[n] : (n < cout_src ? n : -1);
+            for (int ci = 0; ci < cin_dst; ++ci) {
+                const int cs = cin_map ? cin_map[ci] : (ci < cin_src ? ci : -1);
+                float *o = dst + (size_t)n * cin_dst + ci;
+                if (ns < 0 || cs < 0) {
+                    for (int q = 0; q < P; ++q) o[q * plane] = 0.0f;
+                    continue;
+                }
+                const double sc = scale ? (double)scale[ns] : 1.0;
+                double g[3][3], t[6][3];
+                for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = (double)hwio[((size_t)k * cin_src + cs) * cout_src + ns] * sc;
+                for (int xi = 0; xi < ni; ++xi)
+                    for (int kx = 0; kx < 3; ++kx) t[xi][kx] = G[xi][0] * g[0][kx] + G[xi][1] * g[1][kx] + G[xi][2] * g[2][kx];
+                for (int xi = 0; xi < ni; ++xi)
+                    for (int nu = 0; nu < ni; ++nu)
+                        o[(size_t)(ni * xi + nu) * plane] = (float)(t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1] + t[xi][2] * G[nu][2]);
+            }
         }
-    for (int q = 0; q < 16; ++q)
-        pack_conv_weights(u.data() + q * plane, 1, cin_src, cout_src, cin_map, cin_dst, n_map, npad, nullptr,
-                          dst + (size_t)q * npad * cin_dst);
+    };
+    const int nthreads = npad >= 64 ? 8 : 1;
+    std::vector<std::thread> pool;
+    for (int i = 0; i < nthreads; ++i)
+        pool.emplace_back(work, (int)((long long)npad * i / nthreads), (int)((long long)npad * (i + 1) / nthreads));
+    for (auto &th : pool) th.join();
 }

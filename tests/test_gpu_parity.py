@@ -751,11 +751,14 @@ def test_batch_generators_on_image_files(ctx, tmp_path):
 
 
 # ---- Winograd F(2x2,3x3) form of the wide 3x3 layers (csrc/winograd.hip) ------------------
-@pytest.fixture
-def wino_all(monkeypatch):
+@pytest.fixture(params=[4, 2], ids=["F4x4", "F2x2"])
+def wino_all(monkeypatch, request):
     """DT_WINO=2: every 3x3 layer the transforms support goes through the Winograd path, at any size
-    (the default policy only takes it for Cin, Cout >= 256 and >= 1024 tiles per launch)."""
+    (the default policy only takes it for Cin >= 128, Cout >= 256 and >= 512 tiles per launch), once as
+    F(4x4,3x3) (the default tile) and once as F(2x2,3x3).  Returns the output tile size."""
     monkeypatch.setenv("DT_WINO", "2")
+    monkeypatch.setenv("DT_WINO_TILE", str(request.param))
+    return request.param
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [
@@ -777,7 +780,7 @@ def test_conv2d_winograd_vs_oracle(ctx, wino_all, B, H, W, Cin, Cout, pool):
     got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=pool)
     ctx.profile_enable(False)
     assert ctx.profile_read("wino_input")["launches"] == 1 and ctx.profile_read("wino_output")["launches"] == 1
-    tol = 2e-5
+    tol = 2e-5 if wino_all == 2 else 1e-4    # F(4x4,3x3): ~15x the rounding error of the direct form
     if pool == 0:
         assert relerr(got.cpu().numpy(), ref) < tol
     elif pool == 1:
@@ -796,7 +799,11 @@ def test_conv2d_winograd_detects_transpose(ctx, wino_all):
     for n in range(Cout):
         w[n % 3, (n // 3) % 3, (n * 7) % Cin, n] = 1.0
     got = ctx.conv2d(dev(x, ctx), w, None, leaky_slope=1.0, pool=0).cpu().numpy()
-    assert np.array_equal(got, orc.conv2d(x, w))
+    ref = orc.conv2d(x, w)
+    if wino_all == 2:
+        assert np.array_equal(got, ref)          # halves and small integers only: exact
+    else:
+        assert np.abs(got - ref).max() < 0.05    # values are integers up to 250: any misplaced tap is off by >= 1
 
 
 def test_convlstm_step_winograd_vs_oracle(ctx, wino_all):
@@ -817,10 +824,10 @@ def test_tracker_winograd_boxes_and_ids_vs_oracle(ctx, wino_all):
 
 
 def test_winograd_default_policy_engages_on_wide_layers(ctx):
-    """Default policy: 24 frames of 13x13x512 -> 1176 tiles >= 1024 takes the Winograd path and agrees
-    with the direct MFMA form of the same layer (DT_WINO=0) to rounding."""
+    """Default policy: 40 frames of 13x13x512 -> 640 F(4x4,3x3) tiles >= 512 takes the Winograd path and
+    agrees with the direct MFMA form of the same layer (DT_WINO=0) to rounding."""
     rs = np.random.RandomState(77)
-    x = rs.randn(24, 13, 13, 512).astype(np.float32)
+    x = rs.randn(40, 13, 13, 512).astype(np.float32)
     w = (rs.randn(3, 3, 512, 256) * np.sqrt(2.0 / (9 * 512))).astype(np.float32)
     b = rs.randn(256).astype(np.float32)
     ctx.profile_reset(); ctx.profile_enable(True)
@@ -835,7 +842,7 @@ def test_winograd_default_policy_engages_on_wide_layers(ctx):
         assert ctx.profile_read("wino_input")["launches"] == 0
     finally:
         del os.environ["DT_WINO"]
-    assert relerr(got.cpu().numpy(), direct.cpu().numpy()) < 2e-5
+    assert relerr(got.cpu().numpy(), direct.cpu().numpy()) < 1e-4
     ref = orc.conv2d(x[:2], w, b)
     ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
-    assert relerr(got[:2].cpu().numpy(), ref) < 2e-5
+    assert relerr(got[:2].cpu().numpy(), ref) < 1e-4
