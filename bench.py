@@ -305,10 +305,11 @@ def _run():
                          "achieved_algorithmic_incl_transforms":
                              (direct_form / ((ig["ms"] + wino_ms) * 1e-3) / 1e12) if ig["ms"] > 0 else None,
                          "note": "achieved/frac = MFMA FLOPs the kernel EXECUTES / its HIP-event time (pipe utilisation, "
-                                 "<= 1). The wide 3x3 layers run in Winograd F(2x2,3x3) form (16 batched GEMMs through the "
-                                 "same kernel), which executes 2.25x (1.94x at 13x13) fewer FLOPs than the direct form "
-                                 "SURVEY.md 8d counts; achieved_algorithmic = direct-form FLOPs of the same launches / "
-                                 "the same time, and may exceed the peak."},
+                                 "<= 1). The 3x3 layers from conv_3 up and both ConvLSTM convolutions run in Winograd "
+                                 "F(4x4,3x3) form (36 batched GEMMs through the same kernel), which executes up to 4x fewer "
+                                 "FLOPs than the direct form SURVEY.md 8d counts (2.64x at 13x13, 3.45x at 26x26); "
+                                 "achieved_algorithmic = direct-form FLOPs of the same launches / the same time, and "
+                                 "exceeds the peak; ..._incl_transforms adds the HBM-bound transform kernels to the time."},
             "kernels": kern,
         }
         tr = load_traffic(args.clips, args.T, args.size) if args.workload == "track" else None

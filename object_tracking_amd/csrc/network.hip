@@ -276,7 +276,9 @@ static void prof_direct_form(dt_ctx *ctx, double flops)
 // ---------------------------------------------------------------------------
 // Winograd F(2x2,3x3) path for the wide 3x3 layers (winograd.hip)
 // ---------------------------------------------------------------------------
-// DT_WINO: 1 (default) = wide layers (Cin >= 128, Cout >= 256) when a launch has >= 1024 tiles;
+// DT_WINO: 1 (default) = layers with Cin >= 64 and Cout >= 128 (conv_3 and up: below that the batched
+//          GEMMs have K <= 32 and the transforms' traffic costs more than the MFMA work saved) when a
+//          launch has enough tiles (wino_runs);
 //          0 = never (direct MFMA form everywhere); 2 = every 3x3 layer the transforms support,
 //          at any size (parity tests of the path at small shapes).  Read when weights are loaded.
 static int wino_mode()
@@ -289,8 +291,9 @@ static bool wino_wanted(int ks, int cin, int cout)
 {
     const int mode = wino_mode();
     if (ks != 3 || mode == 0 || cin % 32 || cout % 4) return false;
-    static const int minc = [] { const char *e = getenv("DT_WINO_MINC"); return e ? atoi(e) : 128; }();   // A/B runs
-    return mode == 2 || (cin >= minc && cout >= 256);
+    static const int minc = [] { const char *e = getenv("DT_WINO_MINC"); return e ? atoi(e) : 64; }();   // A/B runs
+    static const int minn = [] { const char *e = getenv("DT_WINO_MINN"); return e ? atoi(e) : 128; }();   // A/B runs
+    return mode == 2 || (cin >= minc && cout >= minn);
 }
 
 // DT_WINO_TILE: output tile of the Winograd form, 4 = F(4x4,3x3) (default), 2 = F(2x2,3x3).  Read when
@@ -307,7 +310,10 @@ static bool wino_runs(const float *wino_wt, int ts, int B, int H, int W)
     const long long mt = (long long)B * ((H + ts - 1) / ts) * ((W + ts - 1) / ts);
     if (mt >= (1ll << 31) / 64) return false;
     // below this many tiles the batched GEMMs' row tiles are mostly empty and the direct (split-K) form wins
-    return wino_mode() == 2 || mt >= (ts == 2 ? 1024 : 512);
+    // (detector-only sweep, batch 1/4/8/16: threshold 512 -> 679/1822/2672/3487 frames/s, 64 -> 695/1960/3341/4402,
+    // 16 -> 556/1947/3337/4427)
+    static const int mint = [] { const char *e = getenv("DT_WINO_MINT"); return e ? atoi(e) : 0; }();   // A/B runs
+    return wino_mode() == 2 || mt >= (mint > 0 ? mint : (ts == 2 ? 256 : 64));
 }
 
 static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map,

@@ -824,8 +824,8 @@ def test_tracker_winograd_boxes_and_ids_vs_oracle(ctx, wino_all):
 
 
 def test_winograd_default_policy_engages_on_wide_layers(ctx):
-    """Default policy: 40 frames of 13x13x512 -> 640 F(4x4,3x3) tiles >= 512 takes the Winograd path and
-    agrees with the direct MFMA form of the same layer (DT_WINO=0) to rounding."""
+    """Default policy: 40 frames of 13x13x512 -> 640 F(4x4,3x3) tiles (>= 64) takes the Winograd path and
+    agrees with the direct MFMA form of the same layer (DT_WINO=0) to rounding; 2 frames stay direct."""
     rs = np.random.RandomState(77)
     x = rs.randn(40, 13, 13, 512).astype(np.float32)
     w = (rs.randn(3, 3, 512, 256) * np.sqrt(2.0 / (9 * 512))).astype(np.float32)
@@ -834,6 +834,10 @@ def test_winograd_default_policy_engages_on_wide_layers(ctx):
     got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=0)
     ctx.profile_enable(False)
     assert ctx.profile_read("wino_input")["launches"] == 1
+    ctx.profile_reset(); ctx.profile_enable(True)
+    small = ctx.conv2d(dev(x[:2], ctx), w, b, leaky_slope=0.1, pool=0)
+    ctx.profile_enable(False)
+    assert ctx.profile_read("wino_input")["launches"] == 0 and relerr(small.cpu().numpy(), got[:2].cpu().numpy()) < 1e-4
     os.environ["DT_WINO"] = "0"
     try:
         ctx.profile_reset(); ctx.profile_enable(True)
