@@ -259,6 +259,18 @@ def _run():
     # wide 3x3 layers run in Winograd form.  Time base: the MFMA kernel alone / with its transform kernels.
     direct_form = ctx.profile_read("conv_direct_form")["flops"]
     wino_ms = ctx.profile_read("wino_input")["ms"] + ctx.profile_read("wino_output")["ms"]
+    # split the family's launches by arithmetic intensity (executed FLOP per algorithmic byte): below the ridge
+    # of the chip (157.3 TFLOP/s over ~6.3 TB/s achievable = 25 FLOP/B; 40 used as the class boundary) a launch is
+    # HBM-bound whatever the kernel does, and is priced against the HBM roof instead
+    regimes = {"mfma": [0.0, 0.0, 0.0, []], "hbm": [0.0, 0.0, 0.0, []]}
+    for name in ctx.profile_names():
+        if not name.startswith("conv_igemm:"):
+            continue
+        p = ctx.profile_read(name)
+        if p["ms"] <= 0 or p["bytes"] <= 0:
+            continue
+        r = regimes["mfma" if p["flops"] / p["bytes"] >= 40.0 else "hbm"]
+        r[0] += p["flops"]; r[1] += p["bytes"]; r[2] += p["ms"]; r[3].append(name.split(":", 1)[1])
     boxes_per_frame = None
     if args.workload == "track" and res is not None and isinstance(res, dict):
         boxes_per_frame = float(res["counts"].float().mean().item())
@@ -304,12 +316,24 @@ def _run():
                          "achieved_algorithmic": (direct_form / (ig["ms"] * 1e-3) / 1e12) if ig["ms"] > 0 else None,
                          "achieved_algorithmic_incl_transforms":
                              (direct_form / ((ig["ms"] + wino_ms) * 1e-3) / 1e12) if ig["ms"] > 0 else None,
+                         "mfma_bound_launches": None if regimes["mfma"][2] <= 0 else {
+                             "layers": sorted(regimes["mfma"][3]), "ms_per_step": regimes["mfma"][2] / args.steps,
+                             "achieved": regimes["mfma"][0] / (regimes["mfma"][2] * 1e-3) / 1e12,
+                             "frac": regimes["mfma"][0] / (regimes["mfma"][2] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                         "hbm_bound_launches": None if regimes["hbm"][2] <= 0 else {
+                             "layers": sorted(regimes["hbm"][3]), "ms_per_step": regimes["hbm"][2] / args.steps,
+                             "achieved_GBps": regimes["hbm"][1] / (regimes["hbm"][2] * 1e-3) / 1e9,
+                             "frac_of_8TBps": regimes["hbm"][1] / (regimes["hbm"][2] * 1e-3) / 8e12,
+                             "executed_tflops": regimes["hbm"][0] / (regimes["hbm"][2] * 1e-3) / 1e12},
                          "note": "achieved/frac = MFMA FLOPs the kernel EXECUTES / its HIP-event time (pipe utilisation, "
                                  "<= 1). The 3x3 layers from conv_3 up and both ConvLSTM convolutions run in Winograd "
                                  "F(4x4,3x3) form (36 batched GEMMs through the same kernel), which executes up to 4x fewer "
                                  "FLOPs than the direct form SURVEY.md 8d counts (2.64x at 13x13, 3.45x at 26x26); "
                                  "achieved_algorithmic = direct-form FLOPs of the same launches / the same time, and "
-                                 "exceeds the peak; ..._incl_transforms adds the HBM-bound transform kernels to the time."},
+                                 "exceeds the peak; ..._incl_transforms adds the HBM-bound transform kernels to the time. "
+                                 "mfma_bound_launches / hbm_bound_launches split the family by arithmetic intensity "
+                                 "(>= / < 40 executed FLOP per algorithmic byte): the short-K launches (K = 64/128 Winograd "
+                                 "GEMMs, early 1x1 layers) sit under the HBM roof, not the MFMA one."},
             "kernels": kern,
         }
         tr = load_traffic(args.clips, args.T, args.size) if args.workload == "track" else None

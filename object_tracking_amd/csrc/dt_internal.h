@@ -76,6 +76,7 @@ struct WinoArgs {
     // geometry: B images of H x W; th x tw tiles of ts x ts outputs per image (ts = 2 or 4); Mt = B*th*tw;
     // P = (ts+2)^2 Winograd positions
     int B, H, W, th, tw, Mt, ts;
+    int g;   // frames per side of the virtual mosaic the tiles live on (1: one frame; winograd.hip:vpixel)
     // input transform: in (NHWC, pixel stride in_ld, image stride in_bs), C channels -> v [P][Mt][C]
     const float *in;
     long long in_bs;

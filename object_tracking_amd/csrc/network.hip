@@ -355,7 +355,24 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
 {
     WinoArgs w;
     memset(&w, 0, sizeof(w));
-    w.B = B; w.H = H; w.W = W; w.ts = ts; w.th = (H + ts - 1) / ts; w.tw = (W + ts - 1) / ts; w.Mt = B * w.th * w.tw;
+    w.B = B; w.H = H; w.W = W; w.ts = ts;
+    // mosaic factor g: g x g frames with zero separators share one virtual image (winograd.hip:vpixel) when
+    // that needs fewer tiles per frame (13x13: 12.25 instead of 16); pooled outputs need frame-aligned tiles
+    w.g = 1;
+    {
+        const char *ge = getenv("DT_WINO_MOSAIC");   // 1: never (tests, A/B), 2 / 4: force; read per call
+        const int g_env = ge ? atoi(ge) : -1;
+        double best = (double)((H + ts - 1) / ts) * ((W + ts - 1) / ts);
+        for (int g = 2; g <= 4 && !io.out2 && g_env != 1; g *= 2) {
+            const double t = (double)((g * (H + 1) + ts - 1) / ts) * ((g * (W + 1) + ts - 1) / ts) / (g * g);
+            if ((t < best * 0.97 && B >= g * g) || g_env == g) { best = t; w.g = g; }
+        }
+    }
+    if (w.g == 1) { w.th = (H + ts - 1) / ts; w.tw = (W + ts - 1) / ts; w.Mt = B * w.th * w.tw; }
+    else {
+        w.th = (w.g * (H + 1) + ts - 1) / ts; w.tw = (w.g * (W + 1) + ts - 1) / ts;
+        w.Mt = ((B + w.g * w.g - 1) / (w.g * w.g)) * w.th * w.tw;
+    }
     const int P = (ts + 2) * (ts + 2);
     const size_t mt = (size_t)w.Mt;
     float *V = ws_get(ctx, "wino_v", P * mt * cin * sizeof(float));

@@ -84,24 +84,41 @@ template <int TS, typename T> __device__ __forceinline__ void at_1d(T *m)
     }
 }
 
+// Tiles live on a VIRTUAL image: one frame (g = 1), or a g x g mosaic of frames laid out with a pitch of
+// H+1 / W+1, i.e. with one row / column of zeros between neighbours.  The zero separator is exactly the
+// 'same' padding both neighbours need, so tiles may straddle frames: a 13x13 grid costs (2*14/4)^2 / 4 =
+// 12.25 F(4x4,3x3) tiles per frame instead of the 16 that cover 16x16 (-23 % GEMM rows and transform traffic).
 struct TileId {
-    int b, ty, tx;
+    int grp, ty, tx;   // frame group (g*g frames), tile row / column on its virtual image
 };
 __device__ __forceinline__ TileId tile_id(const WinoArgs &p, int tile)
 {
     const int tpf = p.th * p.tw;
     TileId t;
-    t.b = tile / tpf;
-    const int r = tile - t.b * tpf;
+    t.grp = tile / tpf;
+    const int r = tile - t.grp * tpf;
     t.ty = r / p.tw;
     t.tx = r - t.ty * p.tw;
     return t;
 }
+// virtual (row, col) of group grp -> frame b and pixel (h, w); false = padding / separator / no such frame
+__device__ __forceinline__ bool vpixel(const WinoArgs &p, int grp, int vh, int vw, int &b, int &h, int &w)
+{
+    if (vh < 0 || vw < 0) return false;
+    if (p.g == 1) {
+        b = grp; h = vh; w = vw;
+        return vh < p.H && vw < p.W;
+    }
+    const int fy = vh / (p.H + 1), fx = vw / (p.W + 1);
+    h = vh - fy * (p.H + 1);
+    w = vw - fx * (p.W + 1);
+    b = (grp * p.g + fy) * p.g + fx;
+    return fy < p.g && fx < p.g && h < p.H && w < p.W && b < p.B;
+}
 
 // ---- input transform ----------------------------------------------------------------------------
-// One work item = (tile, V channels).  Tile (b, ty, tx) covers input rows TS*ty-1 .. TS*ty+TS, cols
-// TS*tx-1 .. TS*tx+TS ('same' padding and the rows/columns past an image that is not a multiple of TS
-// read as zero).
+// One work item = (tile, V channels).  Tile (grp, ty, tx) covers virtual rows TS*ty-1 .. TS*ty+TS, cols
+// TS*tx-1 .. TS*tx+TS ('same' padding, separators and the rows/columns past the image read as zero).
 template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_input_kernel(WinoArgs p)
 {
     typedef typename VecOf<V>::T T;
@@ -114,16 +131,14 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_in
         const int tile = (int)(it / cq_n);
         const int c = (int)(it - (long long)tile * cq_n) * V;
         const TileId t = tile_id(p, tile);
-        const float *src = p.in + (long long)t.b * p.in_bs + c;
         T d[NI][NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int h = TS * t.ty - 1 + i;
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                const int w = TS * t.tx - 1 + j;
-                const bool ok = h >= 0 && h < p.H && w >= 0 && w < p.W;
-                d[i][j] = ok ? vload<V>(src + (long long)(h * p.W + w) * p.in_ld) : vzero<V>();
+                int b, h, w;
+                const bool ok = vpixel(p, t.grp, TS * t.ty - 1 + i, TS * t.tx - 1 + j, b, h, w);
+                d[i][j] = ok ? vload<V>(p.in + (long long)b * p.in_bs + (long long)(h * p.W + w) * p.in_ld + c) : vzero<V>();
             }
         }
         // Bt d : down the columns
@@ -209,12 +224,12 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
             for (int i = 0; i < TS; ++i)
 #pragma unroll
                 for (int j = 0; j < TS; ++j) {
-                    const int h = TS * t.ty + i, w = TS * t.tx + j;
-                    if (h < p.H && w < p.W)
-                        vstore<V>(p.out + (long long)t.b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c, m[i][j]);
+                    int b, h, w;
+                    if (vpixel(p, t.grp, TS * t.ty + i, TS * t.tx + j, b, h, w))
+                        vstore<V>(p.out + (long long)b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c, m[i][j]);
                 }
         }
-        if (p.out2) {   // MaxPooling2D(2,2): H and W are even whenever the reference pools
+        if (p.out2) {   // MaxPooling2D(2,2): H and W are even whenever the reference pools; g == 1 (launcher)
             const int H2 = p.H >> 1, W2 = p.W >> 1;
 #pragma unroll
             for (int i = 0; i < TS / 2; ++i)
@@ -227,7 +242,7 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
                         for (int e = 0; e < V; ++e)
                             set_lane<V>(mx, e, fmaxf(fmaxf(lane_of<V>(m[2 * i][2 * j], e), lane_of<V>(m[2 * i][2 * j + 1], e)),
                                                      fmaxf(lane_of<V>(m[2 * i + 1][2 * j], e), lane_of<V>(m[2 * i + 1][2 * j + 1], e))));
-                        vstore<V>(p.out2 + ((long long)(t.b * H2 + h2) * W2 + w2) * p.out2_ld + c, mx);
+                        vstore<V>(p.out2 + ((long long)(t.grp * H2 + h2) * W2 + w2) * p.out2_ld + c, mx);
                     }
                 }
         }
@@ -266,13 +281,13 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
         for (int i = 0; i < TS; ++i)
 #pragma unroll
             for (int j = 0; j < TS; ++j) {
-                const int h = TS * t.ty + i, w = TS * t.tx + j;
-                if (h >= p.H || w >= p.W) continue;
+                int b, h, w;
+                if (!vpixel(p, t.grp, TS * t.ty + i, TS * t.tx + j, b, h, w)) continue;
                 const long long pix = h * p.W + w;
-                const float *xp = p.xproj + (long long)t.b * p.xp_bs + pix * p.xp_ld + col;
+                const float *xp = p.xproj + (long long)b * p.xp_bs + pix * p.xp_ld + col;
                 const T zi = y[0][i][j] + vload<V>(xp), zf = y[1][i][j] + vload<V>(xp + 32);
                 const T zc = y[2][i][j] + vload<V>(xp + 64), zo = y[3][i][j] + vload<V>(xp + 96);
-                float *cp = p.cstate + (long long)t.b * p.c_bs + pix * p.c_ld + jc;
+                float *cp = p.cstate + (long long)b * p.c_bs + pix * p.c_ld + jc;
                 const T cprev = vload<V>(cp);
                 T cn, hn;
 #pragma unroll
@@ -284,7 +299,7 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
                     set_lane<V>(hn, e, go * tanhf(cv));
                 }
                 vstore<V>(cp, cn);
-                vstore<V>(p.out + (long long)t.b * p.out_bs + pix * p.out_ld + jc, hn);
+                vstore<V>(p.out + (long long)b * p.out_bs + pix * p.out_ld + jc, hn);
             }
     }
 }
@@ -300,7 +315,7 @@ static unsigned wino_blocks(long long items)
 // vector width per work item: F(2,3) 4 channels, F(4,3) 2 (its 36-value patch would not fit in registers at 4)
 int launch_wino_input(hipStream_t st, const WinoArgs &a)
 {
-    if (a.C % 4 || a.in_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4)) return 2;
+    if (a.C % 4 || a.in_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4) || a.g < 1) return 2;
     if (a.ts == 2)
         hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.C / 4))), dim3(WINO_THREADS), 0,
                            st, a);
@@ -312,7 +327,7 @@ int launch_wino_input(hipStream_t st, const WinoArgs &a)
 
 int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates)
 {
-    if (a.m_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4)) return 2;
+    if (a.m_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4) || a.g < 1 || (a.out2 && a.g != 1)) return 2;
     if (gates) {
         if (a.N % 128 || a.out_ld % 4 || a.c_ld % 4 || a.xp_ld % 4) return 2;
         if (a.ts == 2)

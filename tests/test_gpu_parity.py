@@ -235,22 +235,29 @@ def test_detector_full_size_one_frame_vs_oracle(ctx):
         assert box_err(got, rows) < 1e-3
 
 
-def test_detector_batch_invariance_full_size(ctx):
-    """A frame's output must not depend on WHERE it sits in the batch or on its
-    neighbours (bit-exact for a given batch size), and must be reproducible run to
-    run.  Across different batch sizes the split-K factor of the small-M layers
-    changes the fp32 summation order, so only closeness is required there."""
+def test_detector_batch_invariance_full_size(ctx, monkeypatch):
+    """A frame's output must not depend on WHERE it sits in the batch or on its neighbours, and must be
+    reproducible run to run (bit-exact).  Position independence is bit-exact with one frame per Winograd
+    tile grid (DT_WINO_MOSAIC=1); with the default 2x2 frame mosaic of the 13x13 layers a frame's tile
+    offsets depend on its slot in the group of four, so its values move at rounding level (<= 2e-5
+    relative; north_star's bar is 1e-3).  Across different batch sizes the split-K factor / the
+    Winograd-vs-direct choice of the small-M layers changes the fp32 summation order: closeness only."""
     det, _, _ = _detector(ctx, 416, 416, 12)
     frames = np.concatenate([synth.synth_clip(3, 416, 416, 2, seed=s) for s in (1, 2)])
     d = dev(frames, det.model.ctx)
-    full = det.model.ctx.detect_forward(d)
     perm = [4, 0, 5, 2, 1, 3]
+    full = det.model.ctx.detect_forward(d)
     shuffled = det.model.ctx.detect_forward(d[perm].contiguous())
-    assert torch.equal(shuffled, full[perm]), "position / neighbour independence"
+    assert relerr(shuffled.cpu().numpy(), full[perm].cpu().numpy()) < 2e-5, "position / neighbour independence"
     again = det.model.ctx.detect_forward(d)
     assert torch.equal(again, full), "run-to-run determinism"
     single = det.model.ctx.detect_forward(d[4:5].contiguous())
     assert relerr(single[0].cpu().numpy(), full[4].cpu().numpy()) < 1e-4
+    monkeypatch.setenv("DT_WINO_MOSAIC", "1")
+    full1 = det.model.ctx.detect_forward(d)
+    shuffled1 = det.model.ctx.detect_forward(d[perm].contiguous())
+    assert torch.equal(shuffled1, full1[perm]), "position / neighbour independence (bit-exact without the mosaic)"
+    assert relerr(full1.cpu().numpy(), full.cpu().numpy()) < 2e-5
 
 
 @pytest.mark.parametrize("ks,Cin,Cout,M_hw,B", [(3, 512, 1024, 13, 1), (3, 1024, 1024, 13, 2), (1, 1024, 512, 13, 1),
@@ -768,6 +775,9 @@ def wino_all(monkeypatch, request):
     (1, 7, 5, 96, 36, 0),        # ragged everything, N a multiple of 4 only
     (5, 26, 26, 32, 32, 0),      # more tiles than one row tile of the GEMM
     (1, 13, 13, 1280, 256, 0),   # conv_22's Cin, 256-wide column tile
+    (6, 13, 13, 64, 128, 0),     # 2x2 frame mosaic with zero separators (tiles straddle frames), ragged last group
+    (18, 26, 26, 32, 64, 0),     # 4x4 mosaic (F(4x4) only; F(2x2) tiles 26 exactly), ragged last group
+    (9, 5, 7, 32, 64, 0),        # non-square mosaic
 ])
 def test_conv2d_winograd_vs_oracle(ctx, wino_all, B, H, W, Cin, Cout, pool):
     rs = np.random.RandomState(B * 1000 + H + Cin + Cout)
@@ -811,6 +821,17 @@ def test_convlstm_step_winograd_vs_oracle(ctx, wino_all):
     test_convlstm_step_vs_oracle(ctx)
     ctx.profile_enable(False)
     assert ctx.profile_read("wino_output")["launches"] == 2      # input projection + gate step
+    # 13x13 grids of 6 clips: the 2x2 frame mosaic (ragged last group) through the gate-update transform
+    rs = np.random.RandomState(19)
+    B, H, W, Cx, U = 6, 13, 13, 64, 32
+    x = rs.randn(B, H, W, Cx).astype(np.float32)
+    h = (rs.randn(B, H, W, U) * .5).astype(np.float32); c = rs.randn(B, H, W, U).astype(np.float32)
+    Wk = (rs.randn(3, 3, Cx, 4 * U) * .05).astype(np.float32); Uk = (rs.randn(3, 3, U, 4 * U) * .05).astype(np.float32)
+    b = rs.randn(4 * U).astype(np.float32) * .1
+    rh, rc = orc.convlstm_step(x, h, c, Wk, Uk, b)
+    gh, gc = ctx.convlstm_step(dev(x, ctx), dev(h, ctx), dev(c, ctx), Wk, Uk, b)
+    np.testing.assert_allclose(gh.cpu().numpy(), rh, rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(gc.cpu().numpy(), rc, rtol=1e-4, atol=5e-5)
 
 
 def test_detector_winograd_vs_oracle(ctx, wino_all):
