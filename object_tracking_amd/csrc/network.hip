@@ -274,7 +274,7 @@ static void prof_direct_form(dt_ctx *ctx, double flops)
 }
 
 // ---------------------------------------------------------------------------
-// Winograd F(2x2,3x3) path for the wide 3x3 layers (winograd.hip)
+// Winograd path for the 3x3 layers from conv_3 up and the ConvLSTM convolutions (winograd.hip)
 // ---------------------------------------------------------------------------
 // DT_WINO: 1 (default) = layers with Cin >= 64 and Cout >= 128 (conv_3 and up: below that the batched
 //          GEMMs have K <= 32 and the transforms' traffic costs more than the MFMA work saved) when a
@@ -304,11 +304,16 @@ static int wino_tile()
     return (e && atoi(e) == 2) ? 2 : 4;
 }
 
-static bool wino_runs(const float *wino_wt, int ts, int B, int H, int W)
+static bool wino_runs(const float *wino_wt, int ts, int B, int H, int W, int cin, int N)
 {
     if (!wino_wt) return false;
     const long long mt = (long long)B * ((H + ts - 1) / ts) * ((W + ts - 1) / ts);
     if (mt >= (1ll << 31) / 64) return false;
+    // V and M' workspaces are (ts+2)^2 * tiles * (Cin + N) floats (27 GB for conv_3 at 1440 frames); a launch
+    // that would need more than DT_WINO_WS_GB (default 96) takes the direct form instead of failing to allocate
+    const char *cap_env = getenv("DT_WINO_WS_GB");   // read per call
+    const double ws_cap = (cap_env ? atof(cap_env) : 96.0) * 1e9;
+    if (4.0 * (ts + 2) * (ts + 2) * (double)mt * ((double)cin + N) > ws_cap) return false;
     // below this many tiles the batched GEMMs' row tiles are mostly empty and the direct (split-K) form wins
     // (detector-only sweep, batch 1/4/8/16: threshold 512 -> 679/1822/2672/3487 frames/s, 64 -> 695/1960/3341/4402,
     // 16 -> 556/1947/3337/4427)
@@ -455,7 +460,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
                                 (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0));
     char tag[32];
     snprintf(tag, sizeof(tag), L.idx == 102 ? "tconv_2" : "conv_%d", L.idx);
-    if (wino_runs(L.wino, L.wino_ts, B, H, W) && ((epi == EPI_PLAIN && order == ORD_LINEAR) || epi == EPI_POOL || epi == EPI_POOL_BOTH)) {
+    if (wino_runs(L.wino, L.wino_ts, B, H, W, L.cin, L.cout) && ((epi == EPI_PLAIN && order == ORD_LINEAR) || epi == EPI_POOL || epi == EPI_POOL_BOTH)) {
         WinoIO io;
         memset(&io, 0, sizeof(io));
         io.in = in; io.in_ld = in_ld; io.in_bs = a.in_bs;
@@ -734,7 +739,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
     float *xproj = ws_get(ctx, "trk_xproj", (size_t)F * GG * N4 * sizeof(float));
     float *cst = ws_get(ctx, "trk_c", (size_t)n_clips * GG * U * sizeof(float));
     if (!xproj || !cst) return DT_ERR_DEVICE;
-    if (wino_runs(wx_wino, ctx->trk_wino_ts, F, gh, gw)) {
+    if (wino_runs(wx_wino, ctx->trk_wino_ts, F, gh, gw, Cx, N4)) {
         WinoIO io;
         memset(&io, 0, sizeof(io));
         io.in = z; io.in_ld = Cx; io.in_bs = (long long)GG * Cx;
@@ -763,7 +768,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM t=0 launch failed");
     }
     for (int t = 1; t < T; ++t) {
-        if (wino_runs(wh_wino, ctx->trk_wino_ts, n_clips, gh, gw)) {
+        if (wino_runs(wh_wino, ctx->trk_wino_ts, n_clips, gh, gw, U, N4)) {
             WinoIO io;
             memset(&io, 0, sizeof(io));
             io.in = hseq + (long long)(t - 1) * GG * U; io.in_ld = U; io.in_bs = h_bs;

@@ -859,6 +859,14 @@ def test_winograd_default_policy_engages_on_wide_layers(ctx):
     small = ctx.conv2d(dev(x[:2], ctx), w, b, leaky_slope=0.1, pool=0)
     ctx.profile_enable(False)
     assert ctx.profile_read("wino_input")["launches"] == 0 and relerr(small.cpu().numpy(), got[:2].cpu().numpy()) < 1e-4
+    os.environ["DT_WINO_WS_GB"] = "0.01"      # workspace cap below what this launch needs -> direct form, not an error
+    try:
+        ctx.profile_reset(); ctx.profile_enable(True)
+        capped = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=0)
+        ctx.profile_enable(False)
+        assert ctx.profile_read("wino_input")["launches"] == 0 and relerr(capped.cpu().numpy(), got.cpu().numpy()) < 1e-4
+    finally:
+        del os.environ["DT_WINO_WS_GB"]
     os.environ["DT_WINO"] = "0"
     try:
         ctx.profile_reset(); ctx.profile_enable(True)
