@@ -73,6 +73,28 @@
 #ifndef DT_DMA_AUX
 #define DT_DMA_AUX 0   // cache-policy bits of the global_load_lds instructions (0 = default)
 #endif
+#ifdef DT_TILE_TIMING
+// debug build only (tools/tile_timing.py): per-workgroup, per-tile timestamps of the persistent loop
+#define DT_TT_BLOCKS 512
+#define DT_TT_TILES 48
+__device__ unsigned long long g_tile_times[DT_TT_BLOCKS * DT_TT_TILES * 4];
+extern "C" __attribute__((visibility("default"))) int dt_debug_tile_times(unsigned long long *dst, int clear)
+{
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tile_times)) != hipSuccess) return 1;
+        return hipMemset(p, 0, sizeof(unsigned long long) * DT_TT_BLOCKS * DT_TT_TILES * 4) == hipSuccess ? 0 : 1;
+    }
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tile_times), sizeof(unsigned long long) * DT_TT_BLOCKS * DT_TT_TILES * 4) == hipSuccess ? 0 : 1;
+}
+#define TT_STAMP(slot)                                                                                   \
+    do {                                                                                                  \
+        if (tid == 0 && blockIdx.x < DT_TT_BLOCKS && tt_i < DT_TT_TILES)                                  \
+            g_tile_times[((size_t)blockIdx.x * DT_TT_TILES + tt_i) * 4 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define TT_STAMP(slot) do { } while (0)
+#endif
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
@@ -555,7 +577,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
         epilogue(cur_t);
     } else {
         int cur = 0;
+#ifdef DT_TILE_TIMING
+        int tt_i = 0;
+#endif
         for (;;) {
+            TT_STAMP(0);
             for (int kc = 0; kc < nk - 1; ++kc) {
                 mma_part(f0, 0, 1);
                 SB();
@@ -588,6 +614,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
                 mma_part(f1, 1, 4);
                 cur ^= 1;
             }
+            TT_STAMP(1);
             // last chunk of this tile: same body, the DMA belongs to the next tile
             const int Lnext = Lcur + (int)gridDim.x;
             const bool more = Lnext < total;
@@ -627,7 +654,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
                 lfrag(f1, 0, 1);
                 mma(f1);
             }
+            TT_STAMP(2);
             epilogue(cur_t);
+            TT_STAMP(3);
+#ifdef DT_TILE_TIMING
+            ++tt_i;
+#endif
             if (!more) break;
             Lcur = Lnext;
             cur_t = next_t;
