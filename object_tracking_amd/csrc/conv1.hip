@@ -4,13 +4,16 @@
 // (models_detection/KerasYOLO.py:278-282).
 //
 // Cin = 3, K = 27: not a dense contraction worth an MFMA tile, and the frame is
-// read exactly once -- this is a direct convolution.  A workgroup owns an 8x8
-// tile of POOLED output pixels (16x16 conv pixels, 18x18x3 input patch staged in
-// LDS as RGBx float4, uint8 -> float through a 256-entry table so that the result
-// equals the reference's float64 x/255. rounded to float32).  Thread = (pooled
-// pixel, group of 8 output channels): 4 conv positions x 8 channels accumulate
-// in registers, the 2x2 max is taken in registers, and each wavefront store
-// writes 16 pixels x 128 B of contiguous NHWC output.
+// read exactly once -- this is a direct convolution on the packed-FMA VALU path.  A
+// workgroup owns an 8x8 tile of POOLED output pixels (16x16 conv pixels, 18x18x3 input
+// patch staged in LDS as RGBx float4, uint8 -> float through a 256-entry table so that
+// the result equals the reference's float64 x/255. rounded to float32).  Wave = one group
+// of 8 output channels, lane = pooled pixel: the 27 x 8 weights of a wave are wave-uniform,
+// so they arrive through scalar loads and feed v_pk_fma_f32 from SGPRs -- no LDS reads
+// for weights in the inner loop (the first version read them from LDS per thread and
+// spent half its cycles there).  4 conv positions x 8 channels accumulate in registers,
+// the 2x2 max is taken in registers; the four waves of a workgroup complete each pixel's
+// 128-byte NHWC line.
 #include "dt_internal.h"
 
 struct Conv1Args {
@@ -27,16 +30,12 @@ struct Conv1Args {
 __global__ __launch_bounds__(256) void conv1_direct_kernel(Conv1Args p)
 {
     __shared__ __attribute__((aligned(16))) float s_patch[18 * 18 * 4];
-    __shared__ __attribute__((aligned(16))) float s_w[27 * 32];
-    __shared__ float s_b[32];
 
     const int tid = threadIdx.x;
     const int H2 = p.H >> 1, W2 = p.W >> 1;
     const int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z;
     const int cy0 = by * 16 - 1, cx0 = bx * 16 - 1;   // patch origin in input pixels
 
-    for (int i = tid; i < 27 * 32; i += 256) s_w[i] = p.w[i];
-    if (tid < 32) s_b[tid] = p.bias[tid];
     for (int i = tid; i < 18 * 18; i += 256) {
         const int r = i / 18, c = i - r * 18;
         const int y = cy0 + r, x = cx0 + c;
@@ -56,9 +55,10 @@ __global__ __launch_bounds__(256) void conv1_direct_kernel(Conv1Args p)
     }
     __syncthreads();
 
-    const int g = tid & 3;          // channel group (8 channels)
-    const int pp = tid >> 2;        // pooled pixel in tile
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);   // channel group (8 channels): wave-uniform
+    const int pp = tid & 63;                                  // pooled pixel in tile
     const int py = pp >> 3, px = pp & 7;
+    const float *wg = p.w + g * 8;                            // uniform address -> scalar loads
 
     float in[4][4][3];
 #pragma unroll
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void conv1_direct_kernel(Conv1Args p)
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
                 const int t = (ky * 3 + kx) * 3 + ci;
-                const f32x4 w0 = *reinterpret_cast<const f32x4 *>(&s_w[t * 32 + g * 8]);
-                const f32x4 w1 = *reinterpret_cast<const f32x4 *>(&s_w[t * 32 + g * 8 + 4]);
+                const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wg + t * 32);
+                const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wg + t * 32 + 4);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float x = in[(q >> 1) + ky][(q & 1) + kx][ci];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void conv1_direct_kernel(Conv1Args p)
         f32x4 o0, o1;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const float bv = s_b[g * 8 + c];
+            const float bv = p.bias[g * 8 + c];
             float m = -INFINITY;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
