@@ -151,6 +151,7 @@ def _run():
     ap.add_argument("--clips", type=int, default=48, help="clips per GPU per step (track)")
     ap.add_argument("--T", type=int, default=30)
     ap.add_argument("--size", type=int, default=416)
+    ap.add_argument("--graphs", action="store_true", help="dt_graph_enable: hipGraph replay of the detector trunk / recurrences")
     ap.add_argument("--boxes", type=int, default=32, help="boxes/frame the synthetic tracker head is calibrated to (track)")
     ap.add_argument("--batch", type=int, default=8, help="frames per step (detect)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -227,12 +228,16 @@ def _run():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.graphs:
+        ctx.graph_enable(True)        # captured during the warm-up steps (second call per shape), replayed afterwards
     res = None
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 3) if args.graphs else args.warmup):
         res = step()
     sync_all()
     ctx.profile_reset()
-    ctx.profile_enable(True)          # HIP events around every launch, on the launch stream
+    if not args.graphs:
+        ctx.profile_enable(True)      # HIP events around every launch, on the launch stream (graphs mode: none,
+                                      # profiling bypasses the replayed graphs)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):

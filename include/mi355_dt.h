@@ -188,6 +188,14 @@ DT_API int dt_encode_targets(dt_ctx *ctx, const int *d_objs, const int *d_counts
                       int nb_class, int image_h, int image_w, int true_box_buffer,
                       const double *h_anchors, double *d_y, double *d_b);
 
+/* ---- hipGraph replay (low-latency serving; default off) ---------------- *
+ * With graphs on, the launch-bound inner sequences that only touch library-owned buffers -- the detector
+ * trunk conv_2..conv_21 and the ConvLSTM recurrence -- are captured once per shape (on the second call
+ * with that shape) and replayed with hipGraphLaunch on an internal stream that is ordered after and
+ * before the caller's stream with events.  Results are identical.  Graphs are dropped when weights are
+ * reloaded or a workspace grows; profiling (dt_profile_enable) bypasses them. */
+DT_API int dt_graph_enable(dt_ctx *ctx, int on);
+
 /* ---- layer-level entry points (used by the parity tests) --------------- */
 /* Conv2D 'same' stride 1 (+ optional folded bias, LeakyReLU slope, fused 2x2
  * maxpool) through the MFMA implicit-GEMM kernel.  h_kernel is Keras HWIO

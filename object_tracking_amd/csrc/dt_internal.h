@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -202,6 +203,13 @@ struct dt_ctx {
     std::map<std::string, DevBuf> ws;
     int last_batch = 0;
     int ing_key[4] = {0, 0, 0, 0};   // (Hs, Ws, Hd, Wd) of the cached ingest tables
+    // hipGraph replay of the launch-bound inner sequences (dt_graph_enable; network.hip:graphed)
+    bool graph_on = false, capturing = false;
+    hipStream_t gstream = nullptr;
+    hipEvent_t gev_in = nullptr, gev_out = nullptr;
+    std::map<std::string, hipGraphExec_t> graphs;
+    std::map<std::string, int> graph_seen;
+    int64_t graph_replays = 0, graph_captures = 0;
     // profiling
     bool prof = false;
     std::map<std::string, ProfEntry> prof_tab;

@@ -36,10 +36,74 @@ int dt_fail(dt_ctx *ctx, int code, const char *fmt, ...)
     return code;
 }
 
+static void graphs_clear(dt_ctx *ctx)
+{
+    if (ctx->graphs.empty() && ctx->graph_seen.empty()) return;
+    (void)hipStreamSynchronize(ctx->gstream);
+    for (auto &kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
+    ctx->graphs.clear();
+    ctx->graph_seen.clear();
+}
+
+// Runs `body` (a sequence of launches on ctx->stream that touches library-owned buffers only), as a replayed
+// hipGraph when graphs are on: first sighting of `key` runs plainly (allocates workspaces, one-time kernel
+// attribute calls), the second captures on the internal stream and instantiates, later ones replay.
+static int graphed(dt_ctx *ctx, const std::string &key, const std::function<int()> &body)
+{
+    if (!ctx->graph_on || ctx->prof || ctx->capturing) return body();
+    hipStream_t user = ctx->stream;
+    auto it = ctx->graphs.find(key);
+    if (it == ctx->graphs.end()) {
+        int &seen = ctx->graph_seen[key];
+        if (seen < 0 || seen++ == 0) return body();
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(ctx->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) { seen = -1; return body(); }
+        ctx->capturing = true; ctx->stream = ctx->gstream;
+        const int rc = body();
+        ctx->stream = user; ctx->capturing = false;
+        const hipError_t e = hipStreamEndCapture(ctx->gstream, &g);
+        hipGraphExec_t ex = nullptr;
+        if (rc != DT_OK || e != hipSuccess || !g || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            ctx->graph_seen[key] = -1;      // do not try again for this shape
+            return rc != DT_OK ? rc : body();
+        }
+        (void)hipGraphDestroy(g);
+        ++ctx->graph_captures;
+        it = ctx->graphs.emplace(key, ex).first;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->gev_in, user));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->gstream, ctx->gev_in, 0));
+    HIP_TRY(ctx, hipGraphLaunch(it->second, ctx->gstream));
+    ++ctx->graph_replays;
+    HIP_TRY(ctx, hipEventRecord(ctx->gev_out, ctx->gstream));
+    HIP_TRY(ctx, hipStreamWaitEvent(user, ctx->gev_out, 0));
+    return DT_OK;
+}
+
+extern "C" int dt_graph_enable(dt_ctx *ctx, int on)
+{
+    if (!ctx) return DT_ERR_ARG;
+    if (on && !ctx->gstream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->gev_in, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->gev_out, hipEventDisableTiming));
+    }
+    if (!on) graphs_clear(ctx);
+    ctx->graph_on = on != 0;
+    return DT_OK;
+}
+
 float *ws_get(dt_ctx *ctx, const char *name, size_t bytes, bool zero_on_grow)
 {
     DevBuf &b = ctx->ws[name];
     if (b.bytes < bytes) {
+        if (ctx->capturing) {   // cannot allocate inside a stream capture (graphed() runs every shape once uncaptured first)
+            dt_fail(ctx, DT_ERR_STATE, "workspace %s would grow during graph capture", name);
+            return nullptr;
+        }
+        graphs_clear(ctx);      // captured kernels hold the old pointer
         if (b.p) {
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipFree(b.p);
@@ -58,7 +122,7 @@ float *ws_get(dt_ctx *ctx, const char *name, size_t bytes, bool zero_on_grow)
 }
 
 ProfScope::ProfScope(dt_ctx *c, const char *name, double flops, double bytes, const char *tag)
-    : ctx(c), on(c->prof)
+    : ctx(c), on(c->prof && !c->capturing)
 {
     if (!on) return;
     ev.name = name;
@@ -141,6 +205,11 @@ extern "C" void dt_destroy(dt_ctx *ctx)
     for (float *p : singles)
         if (p) (void)hipFree(p);
     for (auto &e : ctx->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (ctx->gstream) {
+        graphs_clear(ctx);
+        (void)hipEventDestroy(ctx->gev_in); (void)hipEventDestroy(ctx->gev_out);
+        (void)hipStreamDestroy(ctx->gstream);
+    }
     delete ctx;
 }
 
@@ -261,6 +330,7 @@ extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t 
         if (rc) return rc;
     }
     if (consumed) *consumed = off;
+    graphs_clear(ctx);
     ctx->det_loaded = true;
     return DT_OK;
 }
@@ -538,6 +608,8 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
                                 bufA))
             return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");
     }
+    int h = H / 32, w = W / 32;
+    int rc = graphed(ctx, "trunk:" + std::to_string(B), [&]() -> int {   // conv_2 .. conv_21: library-owned buffers only
     float *cur = bufA, *nxt = bufB;
     int h = H / 2, w = W / 2;
     int rc;
@@ -558,7 +630,8 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
         float *t = cur; cur = nxt; nxt = t;
     }
     // conv_21 on the skip tensor + tf.space_to_depth(2) -> channels [0,256) (KerasYOLO.py:386-391)
-    rc = run_conv(ctx, ctx->layers[21], skip, 512, B, 2 * h, 2 * w, cat, 1280, ORD_QUAD, EPI_S2D, LEAKY);
+    return run_conv(ctx, ctx->layers[21], skip, 512, B, 2 * h, 2 * w, cat, 1280, ORD_QUAD, EPI_S2D, LEAKY);
+    });
     if (rc) return rc;
     // conv_22 -> 'conv_feat'
     rc = run_conv(ctx, ctx->layers[22], cat, 1280, B, h, w, feat.p, feat.ld, ORD_LINEAR, EPI_PLAIN, LEAKY);
@@ -726,6 +799,7 @@ extern "C" int dt_tracker_load(dt_ctx *ctx, int units, const float *h_kernel, co
                           nullptr)))
         return rc;
     ctx->trk_units = U; ctx->trk_cx = Cx; ctx->trk_wo_npad = npad;
+    graphs_clear(ctx);
     ctx->trk_loaded = true;
     return DT_OK;
 }
@@ -739,6 +813,8 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
     float *xproj = ws_get(ctx, "trk_xproj", (size_t)F * GG * N4 * sizeof(float));
     float *cst = ws_get(ctx, "trk_c", (size_t)n_clips * GG * U * sizeof(float));
     if (!xproj || !cst) return DT_ERR_DEVICE;
+    // z, hseq, xproj and the cell state are library-owned: the whole recurrence (3 launches per step) replays as a graph
+    return graphed(ctx, "clstm:" + std::to_string(n_clips) + "x" + std::to_string(T), [&]() -> int {
     if (wino_runs(wx_wino, ctx->trk_wino_ts, F, gh, gw, Cx, N4)) {
         WinoIO io;
         memset(&io, 0, sizeof(io));
@@ -796,6 +872,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM step launch failed");
     }
     return DT_OK;
+    });
 }
 
 extern "C" int dt_track_forward(dt_ctx *ctx, const void *d_frames, int frames_dtype, int n_clips, int T,
@@ -873,6 +950,7 @@ extern "C" int dt_tiny_load(dt_ctx *ctx, int D, int units, int out_dim, const fl
     if ((rc = upload(ctx, &ctx->tiny_wd, wd))) return rc;
     if ((rc = upload(ctx, &ctx->tiny_bd, bd))) return rc;
     ctx->tiny_D = D; ctx->tiny_Dpad = Dp; ctx->tiny_U = U; ctx->tiny_O = O; ctx->tiny_Opad = Opad;
+    graphs_clear(ctx);
     ctx->tiny_loaded = true;
     return DT_OK;
 }
@@ -910,6 +988,8 @@ extern "C" int dt_tiny_sequence(dt_ctx *ctx, const float *d_x, int n_seq, int T,
     if (!x || !xproj || !hseq || !cst) return DT_ERR_DEVICE;
     if (launch_copy_cols(ctx->stream, d_x, D, x, Dp, R, D))   // K padded to a multiple of 32 (pad columns stay 0)
         return dt_fail(ctx, DT_ERR_DEVICE, "x staging launch failed");
+    // staged x, xproj, h and c are library-owned: the projection and the T launch-bound steps replay as a graph
+    int grc = graphed(ctx, "lstm:" + std::to_string(n_seq) + "x" + std::to_string(T), [&]() -> int {
     {   // x.W + b for every (sequence, t) at once on the matrix cores
         ConvArgs a;
         memset(&a, 0, sizeof(a));
@@ -934,6 +1014,9 @@ extern "C" int dt_tiny_sequence(dt_ctx *ctx, const float *d_x, int n_seq, int T,
                                   cst, ctx->tiny_ur, hseq + (long long)t * U, h_bs, n_seq, U);
         if (rc) return dt_fail(ctx, DT_ERR_DEVICE, "LSTM step launch failed");
     }
+    return DT_OK;
+    });
+    if (grc) return grc;
     const int O = ctx->tiny_O;
     if (O <= 8) {
         ProfScope ps(ctx, "misc", 2.0 * R * U * (double)O, 4.0 * R * (U + (double)O));
@@ -1164,6 +1247,8 @@ extern "C" int dt_profile_read(dt_ctx *ctx, const char *name, int64_t *launches,
     auto it = ctx->prof_tab.find(name);
     ProfEntry e;
     if (it != ctx->prof_tab.end()) e = it->second;
+    if (!strcmp(name, "graph_replay")) e.launches = ctx->graph_replays;        // counters of the hipGraph path
+    if (!strcmp(name, "graph_capture")) e.launches = ctx->graph_captures;
     if (launches) *launches = e.launches;
     if (total_ms) *total_ms = e.ms;
     if (flops) *flops = e.flops;

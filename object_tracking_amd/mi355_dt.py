@@ -24,7 +24,7 @@ SYMBOLS = [
     "dt_create", "dt_destroy", "dt_last_error", "dt_set_stream", "dt_abi_version",
     "dt_detector_config", "dt_load_darknet_weights", "dt_detect_forward", "dt_detector_tap", "dt_ingest_resize",
     "dt_decode", "dt_bbox_iou", "dt_tracker_load", "dt_track_forward", "dt_associate",
-    "dt_tiny_load", "dt_tiny_forward", "dt_tiny_features", "dt_tiny_sequence", "dt_top_box", "dt_heatmap_from_boxes", "dt_heatmap_from_xywh64", "dt_rect_from_heatmap", "dt_encode_targets", "dt_conv2d", "dt_convlstm_step",
+    "dt_tiny_load", "dt_tiny_forward", "dt_tiny_features", "dt_tiny_sequence", "dt_top_box", "dt_heatmap_from_boxes", "dt_heatmap_from_xywh64", "dt_rect_from_heatmap", "dt_encode_targets", "dt_graph_enable", "dt_conv2d", "dt_convlstm_step",
     "dt_profile_enable", "dt_profile_reset", "dt_profile_read", "dt_profile_names",
 ]
 
@@ -75,6 +75,7 @@ def load_library():
     L.dt_conv2d.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, vp, cf, ci, vp, vp]
     L.dt_convlstm_step.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]
     L.dt_profile_enable.argtypes = [vp, ci]
+    L.dt_graph_enable.argtypes = [vp, ci]
     L.dt_profile_reset.argtypes = [vp]
     L.dt_profile_names.argtypes = [vp, ctypes.c_char_p, csz]
     L.dt_profile_read.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64),
@@ -404,6 +405,10 @@ class Context(object):
         buf = ctypes.create_string_buffer(1 << 16)
         self._check(self.lib.dt_profile_names(self.h, buf, len(buf)), "dt_profile_names")
         return [n for n in buf.value.decode().split("\n") if n]
+
+    def graph_enable(self, on=True):
+        """hipGraph replay of the detector trunk and the ConvLSTM recurrence (low-latency serving)."""
+        self._check(self.lib.dt_graph_enable(self.h, 1 if on else 0), "dt_graph_enable")
 
     def profile_read(self, name):
         n = ctypes.c_int64(0)

@@ -14,6 +14,7 @@ import torch
 
 from oracle import oracle as orc
 from utility import synth
+import mi355_dt
 
 pytestmark = pytest.mark.gpu
 
@@ -879,3 +880,51 @@ def test_winograd_default_policy_engages_on_wide_layers(ctx):
     ref = orc.conv2d(x[:2], w, b)
     ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
     assert relerr(got[:2].cpu().numpy(), ref) < 1e-4
+
+
+# ---- hipGraph replay of the launch-bound inner sequences (dt_graph_enable) ------------------
+def test_graph_replay_is_bit_identical(ctx):
+    """Detector trunk, ConvLSTM recurrence and LSTM sequence captured on the second call with a shape and
+    replayed afterwards: same bits as the plain launches, across weight reloads and shape changes."""
+    H, W, T, n_clips, C = 64, 96, 4, 3, 12
+    trk, blob, tw = _tracker(H, W, T, C)
+    c = trk.model.ctx
+    frames = np.stack([synth.synth_clip(T, H, W, 2, seed=60 + i) for i in range(n_clips)])
+    d = dev(frames, c)
+    plain_trk, plain_det = c.track_forward(d)
+    plain_net = c.detect_forward(d[0].contiguous())
+    plain2, _ = c.track_forward(d[:2].contiguous())      # another batch size rounds differently: its own reference
+    c.graph_enable(True)
+    try:
+        for it in range(4):
+            g_trk, g_det = c.track_forward(d)
+            assert torch.equal(g_trk, plain_trk) and torch.equal(g_det, plain_det), "iteration %d" % it
+            assert torch.equal(c.detect_forward(d[0].contiguous()), plain_net)
+        assert c.profile_read("graph_capture")["launches"] >= 3      # trunk x 2 batch sizes + recurrence
+        assert c.profile_read("graph_replay")["launches"] >= 6
+        # another shape -> its own graphs; the first stays valid
+        g2, _ = c.track_forward(d[:2].contiguous())
+        assert torch.equal(g2, plain2)
+        assert torch.equal(c.track_forward(d)[0], plain_trk)
+        # reloading weights drops the graphs (they hold the old weight pointers)
+        tw2 = dict(tw); tw2["out_bias"] = tw["out_bias"] + 0.5
+        trk.model.set_weights(tw2)
+        changed, _ = c.track_forward(d)
+        c.graph_enable(False)
+        ref_changed, _ = c.track_forward(d)
+        assert torch.equal(changed, ref_changed) and not torch.equal(changed, plain_trk)
+    finally:
+        c.graph_enable(False)
+
+
+def test_graph_replay_lstm_sequence(ctx):
+    tw = synth.synth_tiny_weights(512)
+    c = mi355_dt.Context()
+    c.tiny_load(516, 512, tw["kernel"], tw["recurrent"], tw["bias"], tw["dense_kernel"], tw["dense_bias"])
+    x = torch.randn(7, 9, 516, device=c.device)
+    plain = c.tiny_sequence(x)
+    c.graph_enable(True)
+    for _ in range(3):
+        assert torch.equal(c.tiny_sequence(x), plain)
+    assert c.profile_read("graph_replay")["launches"] >= 1
+    c.close()
