@@ -236,6 +236,21 @@ def test_detector_full_size_one_frame_vs_oracle(ctx):
         assert box_err(got, rows) < 1e-3
 
 
+def test_detector_full_size_default_policy_vs_oracle(ctx):
+    """Four 416x416 frames with the DEFAULT policy: conv_3..8 in Winograd form, the 13x13 layers in Winograd form
+    on a 2x2 frame mosaic (64 tiles) writing into the strided concat / feature buffers -- against the oracle."""
+    det, layers, _ = _detector(ctx, 416, 416, 12)
+    frames = np.concatenate([synth.synth_clip(2, 416, 416, 3, seed=s) for s in (11, 12)])
+    ref_net, ref_feat, _ = orc.yolov2_forward(orc.normalize_u8(frames), layers)
+    c = det.model.ctx
+    c.profile_reset(); c.profile_enable(True)
+    net, feat = c.detect_forward(dev(frames, c), want_feat=True)
+    c.profile_enable(False)
+    assert c.profile_read("wino_input")["launches"] >= 12       # conv_3,5,6,8,9,11,13,14,16,18,19,20,22
+    assert relerr(net.cpu().numpy(), ref_net) < 1e-3
+    assert relerr(feat.cpu().numpy(), ref_feat) < 1e-3
+
+
 def test_detector_batch_invariance_full_size(ctx, monkeypatch):
     """A frame's output must not depend on WHERE it sits in the batch or on its neighbours, and must be
     reproducible run to run (bit-exact).  Position independence is bit-exact with one frame per Winograd
