@@ -366,12 +366,13 @@ static bool wino_wanted(int ks, int cin, int cout)
     return mode == 2 || (cin >= minc && cout >= minn);
 }
 
-// DT_WINO_TILE: output tile of the Winograd form, 4 = F(4x4,3x3) (default), 2 = F(2x2,3x3).  Read when
-// weights are loaded.
+// DT_WINO_TILE: output tile of the Winograd form, 6 = F(6x6,3x3) (default), 4 = F(4x4,3x3), 2 = F(2x2,3x3).
+// Read when weights are loaded.
 static int wino_tile()
 {
     const char *e = getenv("DT_WINO_TILE");
-    return (e && atoi(e) == 2) ? 2 : 4;
+    const int t = e ? atoi(e) : 6;
+    return (t == 2 || t == 4) ? t : 6;
 }
 
 static bool wino_runs(const float *wino_wt, int ts, int B, int H, int W, int cin, int N)
@@ -388,7 +389,7 @@ static bool wino_runs(const float *wino_wt, int ts, int B, int H, int W, int cin
     // (detector-only sweep, batch 1/4/8/16: threshold 512 -> 679/1822/2672/3487 frames/s, 64 -> 695/1960/3341/4402,
     // 16 -> 556/1947/3337/4427)
     static const int mint = [] { const char *e = getenv("DT_WINO_MINT"); return e ? atoi(e) : 0; }();   // A/B runs
-    return wino_mode() == 2 || mt >= (mint > 0 ? mint : (ts == 2 ? 256 : 64));
+    return wino_mode() == 2 || mt >= (mint > 0 ? mint : (ts == 2 ? 256 : (ts == 4 ? 64 : 32)));
 }
 
 static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map,
@@ -438,7 +439,7 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
         const char *ge = getenv("DT_WINO_MOSAIC");   // 1: never (tests, A/B), 2 / 4: force; read per call
         const int g_env = ge ? atoi(ge) : -1;
         double best = (double)((H + ts - 1) / ts) * ((W + ts - 1) / ts);
-        for (int g = 2; g <= 4 && !io.out2 && g_env != 1; g *= 2) {
+        for (int g = 2; g <= 4 && !io.out2 && g_env != 1; ++g) {
             const double t = (double)((g * (H + 1) + ts - 1) / ts) * ((g * (W + 1) + ts - 1) / ts) / (g * g);
             if ((t < best * 0.97 && B >= g * g) || g_env == g) { best = t; w.g = g; }
         }

@@ -4,7 +4,8 @@
 //
 //     Y = At [ (G g Gt) .* (Bt d B) ] A      per TSxTS output tile, (TS+2)x(TS+2) input patch d, 3x3 filter g
 //
-// F(4x4,3x3) (TS=4, default): 36 multiplies per 16 outputs instead of 144 -- the MFMA work of a layer
+// F(6x6,3x3) (TS=6): 64 multiplies per 36 outputs instead of 324 (5.06x on whole tiles).
+// F(4x4,3x3) (TS=4): 36 multiplies per 16 outputs instead of 144 -- the MFMA work of a layer
 // drops 4x (2.64x at 13x13, whose 4x4 tiles cover 16x16; 3.45x at 26x26).  F(2x2,3x3) (TS=2): 16 per 4
 // outputs, 2.25x (1.94x at 13x13); kept selectable (DT_WINO_TILE=2) -- its fp32 rounding error equals the
 // direct form's, F(4x4,3x3)'s is ~15x that (1.5e-5 absolute at activation scale 4; SURVEY.md's bar is 1e-3).
@@ -52,13 +53,22 @@ template <int V> __device__ __forceinline__ typename VecOf<V>::T vzero()
 }
 
 // 1-D transforms (Lavin & Gray, "Fast Algorithms for Convolutional Neural Networks", the standard
-// interpolation points 0, +-1 for F(2,3) and 0, +-1, +-2 for F(4,3)), applied to rows then columns.
+// interpolation points 0, +-1 for F(2,3), 0, +-1, +-2 for F(4,3) and 0, +-1, +-2, +-1/2 for F(6,3)), applied to
+// rows then columns.
 //   bt: (TS+2) inputs -> (TS+2) outputs in place;  at: (TS+2) inputs -> TS outputs (first TS slots)
 template <int TS, typename T> __device__ __forceinline__ void bt_1d(T *d)
 {
     if (TS == 2) {
         const T t0 = d[0] - d[2], t1 = d[1] + d[2], t2 = d[2] - d[1], t3 = d[1] - d[3];
         d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3;
+    } else if (TS == 6) {
+        // F(6,3), points 0, +-1, +-2, +-1/2:  rows of Bt paired as (even part) +- (odd part)
+        const T t0 = d[0] - d[6] + 5.25f * (d[4] - d[2]);
+        const T t7 = d[7] - d[1] + 5.25f * (d[3] - d[5]);
+        const T a = d[2] - 4.25f * d[4] + d[6], b = d[1] - 4.25f * d[3] + d[5];
+        const T c = 0.25f * d[2] - 1.25f * d[4] + d[6], e = 0.5f * d[1] - 2.5f * d[3] + 2.0f * d[5];
+        const T f = 4.0f * d[2] - 5.0f * d[4] + d[6], g = 2.0f * d[1] - 2.5f * d[3] + 0.5f * d[5];
+        d[0] = t0; d[1] = a + b; d[2] = a - b; d[3] = c + e; d[4] = c - e; d[5] = f + g; d[6] = f - g; d[7] = t7;
     } else {
         const T t0 = 4.0f * d[0] - 5.0f * d[2] + d[4];
         const T t1 = -4.0f * (d[1] + d[2]) + d[3] + d[4];
@@ -74,6 +84,15 @@ template <int TS, typename T> __device__ __forceinline__ void at_1d(T *m)
     if (TS == 2) {
         const T y0 = m[0] + m[1] + m[2], y1 = m[1] - m[2] - m[3];
         m[0] = y0; m[1] = y1;
+    } else if (TS == 6) {
+        const T p1 = m[1] + m[2], q1 = m[1] - m[2], p2 = m[3] + m[4], q2 = m[3] - m[4], p3 = m[5] + m[6], q3 = m[5] - m[6];
+        const T y0 = m[0] + p1 + p2 + p3;
+        const T y1 = q1 + 2.0f * q2 + 0.5f * q3;
+        const T y2 = p1 + 4.0f * p2 + 0.25f * p3;
+        const T y3 = q1 + 8.0f * q2 + 0.125f * q3;
+        const T y4 = p1 + 16.0f * p2 + 0.0625f * p3;
+        const T y5 = q1 + 32.0f * q2 + 0.03125f * q3 + m[7];
+        m[0] = y0; m[1] = y1; m[2] = y2; m[3] = y3; m[4] = y4; m[5] = y5;
     } else {
         const T a = m[1] + m[2], b = m[1] - m[2], c = m[3] + m[4], e = m[3] - m[4];
         const T y0 = m[0] + a + c;
@@ -316,8 +335,11 @@ static unsigned wino_blocks(long long items)
 // output transforms (register budget of the 36-plane patch)
 int launch_wino_input(hipStream_t st, const WinoArgs &a)
 {
-    if (a.C % 4 || a.in_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4) || a.g < 1) return 2;
-    if (a.ts == 2)
+    if (a.C % 4 || a.in_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4 && a.ts != 6) || a.g < 1) return 2;
+    if (a.ts == 6)
+        hipLaunchKernelGGL((wino_input_kernel<6, 2>), dim3(wino_blocks((long long)a.Mt * (a.C / 2))), dim3(WINO_THREADS), 0,
+                           st, a);
+    else if (a.ts == 2)
         hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.C / 4))), dim3(WINO_THREADS), 0,
                            st, a);
     else   // 188 VGPRs, two waves per SIMD: still 7 % faster than <4,2> (1 KiB per wave per plane store)
@@ -328,10 +350,13 @@ int launch_wino_input(hipStream_t st, const WinoArgs &a)
 
 int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates)
 {
-    if (a.m_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4) || a.g < 1 || (a.out2 && a.g != 1)) return 2;
+    if (a.m_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4 && a.ts != 6) || a.g < 1 || (a.out2 && a.g != 1)) return 2;
     if (gates) {
         if (a.N % 128 || a.out_ld % 4 || a.c_ld % 4 || a.xp_ld % 4) return 2;
-        if (a.ts == 2)
+        if (a.ts == 6)
+            hipLaunchKernelGGL((wino_output_gates_kernel<6, 1>), dim3(wino_blocks((long long)a.Mt * (a.N / 4))),
+                               dim3(WINO_THREADS), 0, st, a);
+        else if (a.ts == 2)
             hipLaunchKernelGGL((wino_output_gates_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.N / 16))),
                                dim3(WINO_THREADS), 0, st, a);
         else
@@ -340,7 +365,10 @@ int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates)
     } else {
         // vector stores need aligned rows; ragged N (conv_23-like heads) never takes this path
         if (a.N % 4 || (a.out && a.out_ld % 4) || (a.out2 && a.out2_ld % 4)) return 2;
-        if (a.ts == 2)
+        if (a.ts == 6)
+            hipLaunchKernelGGL((wino_output_kernel<6, 2>), dim3(wino_blocks((long long)a.Mt * (a.N / 2))), dim3(WINO_THREADS),
+                               0, st, a);
+        else if (a.ts == 2)
             hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.N / 4))), dim3(WINO_THREADS),
                                0, st, a);
         else   // <4,4> measured equal
@@ -359,8 +387,13 @@ void wino_pack_weights(int ts, const float *hwio, int cin_src, int cout_src, con
     static const double G2[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
     static const double G4[6][3] = {{1. / 4, 0, 0},          {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
                                     {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0, 0, 1}};
+    static const double G6[8][3] = {{1, 0, 0},
+                                    {-2. / 9, -2. / 9, -2. / 9},   {-2. / 9, 2. / 9, -2. / 9},
+                                    {1. / 90, 1. / 45, 2. / 45},   {1. / 90, -1. / 45, 2. / 45},
+                                    {32. / 45, 16. / 45, 8. / 45}, {32. / 45, -16. / 45, 8. / 45},
+                                    {0, 0, 1}};
     const int ni = ts + 2, P = ni * ni;
-    const double(*G)[3] = ts == 2 ? G2 : G4;
+    const double(*G)[3] = ts == 2 ? G2 : (ts == 4 ? G4 : G6);
     const size_t plane = (size_t)npad * cin_dst;
     auto work = [&](int n_lo, int n_hi) {
         for (int n = n_lo; n < n_hi; ++n) {
@@ -373,7 +406,7 @@ void wino_pack_weights(int ts, const float *hwio, int cin_src, int cout_src, con
                     continue;
                 }
                 const double sc = scale ? (double)scale[ns] : 1.0;
-                double g[3][3], t[6][3];
+                double g[3][3], t[8][3];
                 for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = (double)hwio[((size_t)k * cin_src + cs) * cout_src + ns] * sc;
                 for (int xi = 0; xi < ni; ++xi)
                     for (int kx = 0; kx < 3; ++kx) t[xi][kx] = G[xi][0] * g[0][kx] + G[xi][1] * g[1][kx] + G[xi][2] * g[2][kx];

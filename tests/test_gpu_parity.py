@@ -292,7 +292,7 @@ def test_conv2d_split_k_path(ctx, ks, Cin, Cout, M_hw, B):
 
 
 # ------------------------------------------------------------------ ConvLSTM / tracker
-def test_convlstm_step_vs_oracle(ctx):
+def test_convlstm_step_vs_oracle(ctx, atol=2e-5):
     rs = np.random.RandomState(9)
     B, H, W, Cx, U = 3, 5, 7, 96, 64
     x = rs.randn(B, H, W, Cx).astype(np.float32)
@@ -301,8 +301,8 @@ def test_convlstm_step_vs_oracle(ctx):
     b = rs.randn(4 * U).astype(np.float32) * .1
     rh, rc = orc.convlstm_step(x, h, c, Wk, Uk, b)
     gh, gc = ctx.convlstm_step(dev(x, ctx), dev(h, ctx), dev(c, ctx), Wk, Uk, b)
-    np.testing.assert_allclose(gh.cpu().numpy(), rh, rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(gc.cpu().numpy(), rc, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(gh.cpu().numpy(), rh, rtol=1e-4, atol=atol)
+    np.testing.assert_allclose(gc.cpu().numpy(), rc, rtol=1e-4, atol=atol)
 
 
 def _tracker(H, W, T, C=12, seed=1235):
@@ -469,7 +469,10 @@ a, b = shard_range(N, rank, world)
 out = gather_detections(trk.track_clips(frames[a:b]))
 full = gather_detections.__globals__["global_track_ids"]
 ref = trk.track_clips(frames)
-ok = (torch.equal(out["boxes"], ref["boxes"]) and torch.equal(out["counts"], ref["counts"])
+# a rank runs its shard at another batch size than the single-process reference, so layers may take another
+# form (direct / Winograd, split-K factor): box values agree to rounding, everything discrete is exact
+ok = (torch.allclose(out["boxes"], ref["boxes"], rtol=1e-4, atol=1e-5) and torch.equal(out["boxes"][..., 5], ref["boxes"][..., 5])
+      and torch.equal(out["boxes"][..., 7], ref["boxes"][..., 7]) and torch.equal(out["counts"], ref["counts"])
       and torch.equal(out["ids"], ref["ids"]) and torch.equal(out["gids"], full(ref["ids"], ref["nids"]))
       and int(ref["counts"].sum()) > 0)
 print("RANK", rank, "OK" if ok else "MISMATCH", int(ref["counts"].sum()), flush=True)
@@ -774,11 +777,11 @@ def test_batch_generators_on_image_files(ctx, tmp_path):
 
 
 # ---- Winograd F(2x2,3x3) form of the wide 3x3 layers (csrc/winograd.hip) ------------------
-@pytest.fixture(params=[4, 2], ids=["F4x4", "F2x2"])
+@pytest.fixture(params=[6, 4, 2], ids=["F6x6", "F4x4", "F2x2"])
 def wino_all(monkeypatch, request):
     """DT_WINO=2: every 3x3 layer the transforms support goes through the Winograd path, at any size
     (the default policy only takes it for Cin >= 128, Cout >= 256 and >= 512 tiles per launch), once as
-    F(4x4,3x3) (the default tile) and once as F(2x2,3x3).  Returns the output tile size."""
+    F(6x6,3x3) (the default tile), F(4x4,3x3) and F(2x2,3x3).  Returns the output tile size."""
     monkeypatch.setenv("DT_WINO", "2")
     monkeypatch.setenv("DT_WINO_TILE", str(request.param))
     return request.param
@@ -792,7 +795,8 @@ def wino_all(monkeypatch, request):
     (5, 26, 26, 32, 32, 0),      # more tiles than one row tile of the GEMM
     (1, 13, 13, 1280, 256, 0),   # conv_22's Cin, 256-wide column tile
     (6, 13, 13, 64, 128, 0),     # 2x2 frame mosaic with zero separators (tiles straddle frames), ragged last group
-    (18, 26, 26, 32, 64, 0),     # 4x4 mosaic (F(4x4) only; F(2x2) tiles 26 exactly), ragged last group
+    (18, 26, 26, 32, 64, 0),     # 4x4 mosaic for F(4x4), 2x2 for F(6x6) (F(2x2) tiles 26 exactly), ragged last group
+    (11, 13, 13, 32, 64, 0),     # 3x3 mosaic for F(6x6): 3*14 = 7 tiles of 6, ragged last group
     (9, 5, 7, 32, 64, 0),        # non-square mosaic
 ])
 def test_conv2d_winograd_vs_oracle(ctx, wino_all, B, H, W, Cin, Cout, pool):
@@ -806,7 +810,7 @@ def test_conv2d_winograd_vs_oracle(ctx, wino_all, B, H, W, Cin, Cout, pool):
     got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=pool)
     ctx.profile_enable(False)
     assert ctx.profile_read("wino_input")["launches"] == 1 and ctx.profile_read("wino_output")["launches"] == 1
-    tol = 2e-5 if wino_all == 2 else 1e-4    # F(4x4,3x3): ~15x the rounding error of the direct form
+    tol = {2: 2e-5, 4: 1e-4, 6: 2e-4}[wino_all]    # F(4x4) / F(6x6): ~15x / ~20x the rounding error of the direct form
     if pool == 0:
         assert relerr(got.cpu().numpy(), ref) < tol
     elif pool == 1:
@@ -833,8 +837,9 @@ def test_conv2d_winograd_detects_transpose(ctx, wino_all):
 
 
 def test_convlstm_step_winograd_vs_oracle(ctx, wino_all):
+    atol = {2: 2e-5, 4: 5e-5, 6: 1e-4}[wino_all]      # state values are O(1): F(4x4) / F(6x6) round ~15x / ~20x coarser
     ctx.profile_reset(); ctx.profile_enable(True)
-    test_convlstm_step_vs_oracle(ctx)
+    test_convlstm_step_vs_oracle(ctx, atol=atol)
     ctx.profile_enable(False)
     assert ctx.profile_read("wino_output")["launches"] == 2      # input projection + gate step
     # 13x13 grids of 6 clips: the 2x2 frame mosaic (ragged last group) through the gate-update transform
@@ -846,8 +851,8 @@ def test_convlstm_step_winograd_vs_oracle(ctx, wino_all):
     b = rs.randn(4 * U).astype(np.float32) * .1
     rh, rc = orc.convlstm_step(x, h, c, Wk, Uk, b)
     gh, gc = ctx.convlstm_step(dev(x, ctx), dev(h, ctx), dev(c, ctx), Wk, Uk, b)
-    np.testing.assert_allclose(gh.cpu().numpy(), rh, rtol=1e-4, atol=5e-5)
-    np.testing.assert_allclose(gc.cpu().numpy(), rc, rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(gh.cpu().numpy(), rh, rtol=1e-4, atol=max(atol, 5e-5))
+    np.testing.assert_allclose(gc.cpu().numpy(), rc, rtol=1e-4, atol=max(atol, 5e-5))
 
 
 def test_detector_winograd_vs_oracle(ctx, wino_all):
