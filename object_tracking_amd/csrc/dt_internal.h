@@ -192,7 +192,7 @@ struct dt_ctx {
     float *trk_wx = nullptr, *trk_bx = nullptr;   // input conv, N gate-interleaved
     float *trk_wh = nullptr;                      // recurrent conv
     float *trk_wx_wino = nullptr, *trk_wh_wino = nullptr;   // their Winograd-domain forms
-    int trk_wino_ts = 0;
+    int trk_wino_ts = 0, trk_wh_ts = 0;   // tile of the input / recurrent convolution's Winograd weights
     float *trk_wo = nullptr, *trk_bo = nullptr;   // tconv_2 1x1
     int trk_wo_npad = 0;
     // tiny tracker

@@ -255,7 +255,7 @@ static void oihw_to_hwio(const float *src, int O, int I, int k, std::vector<floa
 }
 
 static bool wino_wanted(int ks, int cin, int cout);
-static int wino_tile();
+static int wino_tile(bool recurrent);
 static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map,
                        int cin_dst, const int *n_map, int npad, const float *scale);
 
@@ -273,7 +273,7 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
     if (rc) return rc;
     if (L.wino) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino); L.wino = nullptr; }
     if (wino_wanted(ks, cin, cout)) {
-        L.wino_ts = wino_tile();
+        L.wino_ts = wino_tile(false);
         rc = upload_wino(ctx, &L.wino, L.wino_ts, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale);
         if (rc) return rc;
     }
@@ -368,10 +368,12 @@ static bool wino_wanted(int ks, int cin, int cout)
 
 // DT_WINO_TILE: output tile of the Winograd form, 6 = F(6x6,3x3) (default), 4 = F(4x4,3x3), 2 = F(2x2,3x3).
 // Read when weights are loaded.
-static int wino_tile()
+static int wino_tile(bool recurrent = false)
 {
+    // The ConvLSTM recurrent convolution keeps F(4x4): its per-step GEMM has only clips/4 * 49 rows, which F(6x6)
+    // (clips/9 * 49) fills no better, and the F(6x6) gate-update transform needs all 256 VGPRs (2.0 vs 5.3 TB/s).
     const char *e = getenv("DT_WINO_TILE");
-    const int t = e ? atoi(e) : 6;
+    const int t = e ? atoi(e) : (recurrent ? 4 : 6);
     return (t == 2 || t == 4) ? t : 6;
 }
 
@@ -790,13 +792,14 @@ extern "C" int dt_tracker_load(dt_ctx *ctx, int units, const float *h_kernel, co
     if ((rc = upload(ctx, &ctx->trk_bo, bo))) return rc;
     for (float **w : {&ctx->trk_wx_wino, &ctx->trk_wh_wino})
         if (*w) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(*w); *w = nullptr; }
-    ctx->trk_wino_ts = wino_tile();
+    ctx->trk_wino_ts = wino_tile(false);
+    ctx->trk_wh_ts = wino_tile(true);
     if (wino_wanted(3, Cx, 4 * U) &&
         (rc = upload_wino(ctx, &ctx->trk_wx_wino, ctx->trk_wino_ts, h_kernel, Csrc, 4 * U, cin_map.data(), Cx, n_map.data(),
                           4 * U, nullptr)))
         return rc;
     if (wino_wanted(3, U, 4 * U) &&
-        (rc = upload_wino(ctx, &ctx->trk_wh_wino, ctx->trk_wino_ts, h_recurrent, U, 4 * U, nullptr, U, n_map.data(), 4 * U,
+        (rc = upload_wino(ctx, &ctx->trk_wh_wino, ctx->trk_wh_ts, h_recurrent, U, 4 * U, nullptr, U, n_map.data(), 4 * U,
                           nullptr)))
         return rc;
     ctx->trk_units = U; ctx->trk_cx = Cx; ctx->trk_wo_npad = npad;
@@ -845,14 +848,14 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM t=0 launch failed");
     }
     for (int t = 1; t < T; ++t) {
-        if (wino_runs(wh_wino, ctx->trk_wino_ts, n_clips, gh, gw, U, N4)) {
+        if (wino_runs(wh_wino, ctx->trk_wh_ts, n_clips, gh, gw, U, N4)) {
             WinoIO io;
             memset(&io, 0, sizeof(io));
             io.in = hseq + (long long)(t - 1) * GG * U; io.in_ld = U; io.in_bs = h_bs;
             io.out = hseq + (long long)t * GG * U; io.out_ld = U; io.out_bs = h_bs;
             io.xproj = xproj + (long long)t * GG * N4; io.xp_ld = N4; io.xp_bs = xp_bs;
             io.cstate = cst; io.c_ld = U; io.c_bs = c_bs;
-            const int rc = run_wino(ctx, wh_wino, ctx->trk_wino_ts, nullptr, U, N4, N4, n_clips, gh, gw, io, 1.0f, "convlstm_step");
+            const int rc = run_wino(ctx, wh_wino, ctx->trk_wh_ts, nullptr, U, N4, N4, n_clips, gh, gw, io, 1.0f, "convlstm_step");
             if (rc) return rc;
             continue;
         }
@@ -1152,7 +1155,7 @@ extern "C" int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int
     if (!xproj) return DT_ERR_DEVICE;
     if (wino_mode() == 2 && wino_wanted(3, Cx, N4) && wino_wanted(3, U, N4)) {   // the same step through the Winograd path
         float *uwx = nullptr, *uwh = nullptr;
-        const int ts = wino_tile();
+        const int ts = wino_tile(false);
         if ((rc = upload_wino(ctx, &uwx, ts, h_kernel, Cx, N4, nullptr, Cx, n_map.data(), N4, nullptr)) ||
             (rc = upload_wino(ctx, &uwh, ts, h_recurrent, U, N4, nullptr, U, n_map.data(), N4, nullptr)))
             return rc;
