@@ -332,8 +332,8 @@ def _run():
                              "executed_tflops": regimes["hbm"][0] / (regimes["hbm"][2] * 1e-3) / 1e12},
                          "note": "achieved/frac = MFMA FLOPs the kernel EXECUTES / its HIP-event time (pipe utilisation, "
                                  "<= 1). The 3x3 layers from conv_3 up and both ConvLSTM convolutions run in Winograd "
-                                 "F(4x4,3x3) form (36 batched GEMMs through the same kernel), which executes up to 4x fewer "
-                                 "FLOPs than the direct form SURVEY.md 8d counts (2.64x at 13x13, 3.45x at 26x26); "
+                                 "form (F(6x6,3x3): 64 batched GEMMs through the same kernel; F(4x4,3x3) for the recurrent "
+                                 "step), which executes up to 5x fewer FLOPs than the direct form SURVEY.md 8d counts; "
                                  "achieved_algorithmic = direct-form FLOPs of the same launches / the same time, and "
                                  "exceeds the peak; ..._incl_transforms adds the HBM-bound transform kernels to the time. "
                                  "mfma_bound_launches / hbm_bound_launches split the family by arithmetic intensity "
