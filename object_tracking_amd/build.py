@@ -20,6 +20,7 @@ SOURCES = {
     "conv_igemm.hip": [],
     "conv1.hip": [],
     "winograd.hip": [],
+    "wino_fused.hip": [],
     "ingest.hip": [],
     "decode.hip": ["-ffp-contract=off"],
     "targets.hip": ["-ffp-contract=off"],

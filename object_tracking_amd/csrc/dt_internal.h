@@ -101,6 +101,17 @@ struct WinoArgs {
     long long c_bs;
     int c_ld;
 };
+// fused Winograd F(2x2,3x3) + LeakyReLU + MaxPooling2D(2,2) for conv_2 (32 -> 64 channels), wino_fused.hip
+struct WinoFusedArgs {
+    const float *in;     // [B][H][W][32]
+    int B, H, W;
+    const float *u;      // [16][2][32][2][16]  (wino2_fused_pack)
+    const float *bias;   // [64]
+    float slope;
+    float *out;          // [B][H/2][W/2][64]
+};
+int launch_wino2_fused_pool(hipStream_t st, const WinoFusedArgs &a);
+void wino2_fused_pack(const float *hwio, const float *scale, float *dst);
 int launch_wino_input(hipStream_t st, const WinoArgs &a);
 int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates);
 void wino_pack_weights(int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map, int cin_dst, const int *n_map,
@@ -171,7 +182,8 @@ struct ConvLayer {
     int idx, ks, cin, cout, npad, pool;  // pool: reference MaxPooling2D after this layer
     float *wt = nullptr;                 // device, packed
     float *wino = nullptr;               // device, [P][npad][cin] Winograd-domain weights (wide 3x3 layers) or null
-    int wino_ts = 0;                     // their output tile size (2 or 4)
+    int wino_ts = 0;                     // their output tile size (2, 4 or 6)
+    float *fused = nullptr;              // device, fused-Winograd weights (32 -> 64 pooled layer: conv_2) or null
     float *bias = nullptr;               // device, [npad]
 };
 

@@ -198,6 +198,7 @@ extern "C" void dt_destroy(dt_ctx *ctx)
         if (ctx->layers[i].wt) (void)hipFree(ctx->layers[i].wt);
         if (ctx->layers[i].bias) (void)hipFree(ctx->layers[i].bias);
         if (ctx->layers[i].wino) (void)hipFree(ctx->layers[i].wino);
+        if (ctx->layers[i].fused) (void)hipFree(ctx->layers[i].fused);
     }
     float *singles[] = {ctx->conv1_w, ctx->conv1_b, ctx->lut255, ctx->anchors_dev, ctx->trk_wx, ctx->trk_bx,
                         ctx->trk_wh,  ctx->trk_wo,  ctx->trk_bo, ctx->trk_wx_wino, ctx->trk_wh_wino, ctx->tiny_wx,     ctx->tiny_bx, ctx->tiny_ur,
@@ -255,6 +256,7 @@ static void oihw_to_hwio(const float *src, int O, int I, int k, std::vector<floa
 }
 
 static bool wino_wanted(int ks, int cin, int cout);
+static int wino_mode();
 static int wino_tile(bool recurrent);
 static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map,
                        int cin_dst, const int *n_map, int npad, const float *scale);
@@ -272,6 +274,13 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
     int rc = upload(ctx, &L.wt, packed);
     if (rc) return rc;
     if (L.wino) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino); L.wino = nullptr; }
+    if (L.fused) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused); L.fused = nullptr; }
+    if (ks == 3 && cin == 32 && cout == 64 && wino_mode() != 0) {   // conv_2's shape: fused F(2x2,3x3) + pool kernel
+        std::vector<float> uf((size_t)16 * 2 * 32 * 2 * 16);
+        wino2_fused_pack(hwio, scale, uf.data());
+        rc = upload(ctx, &L.fused, uf);
+        if (rc) return rc;
+    }
     if (wino_wanted(ks, cin, cout)) {
         L.wino_ts = wino_tile(false);
         rc = upload_wino(ctx, &L.wino, L.wino_ts, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale);
@@ -533,6 +542,23 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
                                 (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0));
     char tag[32];
     snprintf(tag, sizeof(tag), L.idx == 102 ? "tconv_2" : "conv_%d", L.idx);
+    // conv_2's shape with its pooling epilogue: the fused Winograd kernel (wino_fused.hip) once there are enough
+    // workgroups to fill the chip (one per 8x8 pooled pixels); DT_WINO_FUSED=0 keeps the direct form
+    if (L.fused && epi == EPI_POOL && in_ld == 32 && out_ld == 64 && !((H | W) & 1)) {
+        const char *fe = getenv("DT_WINO_FUSED");      // 0: never, 2: at any size (parity tests); read per call
+        const int fmode = fe ? atoi(fe) : 1;
+        if (fmode == 2 || (fmode == 1 && (long long)B * ((H / 2 + 7) / 8) * ((W / 2 + 7) / 8) >= 512)) {
+            WinoFusedArgs f;
+            f.in = in; f.B = B; f.H = H; f.W = W; f.u = L.fused; f.bias = L.bias; f.slope = slope; f.out = out;
+            // executed MFMA FLOPs: 16 positions x (tiles x 32 x 64) x 2; bytes: input once (+halo) and the pooled output
+            ProfScope ps(ctx, "conv_fused", 2.0 * 16.0 * B * (H / 2.0) * (W / 2.0) * 32.0 * 64.0,
+                         4.0 * ((double)B * H * W * 32.0 * 1.27 + (double)B * (H / 2) * (W / 2) * 64.0), tag);
+            prof_direct_form(ctx, flops);
+            const int rc = launch_wino2_fused_pool(ctx->stream, f);
+            if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused Winograd launch failed", tag);
+            return DT_OK;
+        }
+    }
     if (wino_runs(L.wino, L.wino_ts, B, H, W, L.cin, L.cout) && ((epi == EPI_PLAIN && order == ORD_LINEAR) || epi == EPI_POOL || epi == EPI_POOL_BOTH)) {
         WinoIO io;
         memset(&io, 0, sizeof(io));

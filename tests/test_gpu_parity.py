@@ -948,3 +948,37 @@ def test_graph_replay_lstm_sequence(ctx):
         assert torch.equal(c.tiny_sequence(x), plain)
     assert c.profile_read("graph_replay")["launches"] >= 1
     c.close()
+
+
+# ---- conv_2 as one fused Winograd F(2x2,3x3) + LeakyReLU + max-pool kernel (csrc/wino_fused.hip) -----------
+@pytest.mark.parametrize("B,H,W", [(2, 16, 16), (3, 32, 48), (1, 18, 34), (2, 2, 2), (5, 104, 104)])
+def test_conv2_fused_winograd_vs_oracle(ctx, monkeypatch, B, H, W):
+    """32 -> 64 channels with the 2x2 pooling epilogue through the fused kernel (forced at any size): whole and
+    partial 8x8-tile workgroups, image borders, several frames; F(2x2,3x3) rounds like the direct form."""
+    monkeypatch.setenv("DT_WINO_FUSED", "2")
+    rs = np.random.RandomState(B * 100 + H + W)
+    x = rs.randn(B, H, W, 32).astype(np.float32)
+    w = (rs.randn(3, 3, 32, 64) * np.sqrt(2.0 / (9 * 32))).astype(np.float32)
+    b = rs.randn(64).astype(np.float32)
+    ref = orc.conv2d(x, w, b)
+    ref = orc.maxpool2(np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32))
+    ctx.profile_reset(); ctx.profile_enable(True)
+    got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=1)
+    ctx.profile_enable(False)
+    assert ctx.profile_read("conv_fused")["launches"] == 1
+    assert relerr(got.cpu().numpy(), ref) < 2e-5
+    monkeypatch.setenv("DT_WINO_FUSED", "0")
+    direct = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=1)
+    assert relerr(got.cpu().numpy(), direct.cpu().numpy()) < 2e-5
+
+
+def test_conv2_fused_winograd_one_hot(ctx, monkeypatch):
+    """one-hot taps on integer data: exact, and any misplaced tile / channel / position is off by >= 1"""
+    monkeypatch.setenv("DT_WINO_FUSED", "2")
+    B, H, W = 2, 20, 12
+    x = (np.arange(B * H * W * 32, dtype=np.float32).reshape(B, H, W, 32) % 251)
+    w = np.zeros((3, 3, 32, 64), dtype=np.float32)
+    for n in range(64):
+        w[n % 3, (n // 3) % 3, (n * 7) % 32, n] = 1.0
+    got = ctx.conv2d(dev(x, ctx), w, None, leaky_slope=1.0, pool=1).cpu().numpy()
+    assert np.array_equal(got, orc.maxpool2(orc.conv2d(x, w)))

@@ -8,6 +8,6 @@ D=object_tracking_amd/ablate; mkdir -p $D
 C=object_tracking_amd/csrc
 for m in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DDT_ABLATE=$m -c $C/conv_igemm.hip -o $D/conv_igemm_$m.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libmi355_dt_abl$m.so $D/conv_igemm_$m.o $C/conv1.o $C/winograd.o $C/ingest.o $C/decode.o $C/targets.o $C/recurrent.o $C/network.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libmi355_dt_abl$m.so $D/conv_igemm_$m.o $C/conv1.o $C/winograd.o $C/wino_fused.o $C/ingest.o $C/decode.o $C/targets.o $C/recurrent.o $C/network.o
   echo built $D/libmi355_dt_abl$m.so
 done

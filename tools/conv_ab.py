@@ -22,6 +22,9 @@ for _ in range(5):
     ctx.conv2d(x, w, b, leaky_slope=0.1, pool=pool)
 ctx.profile_enable(False)
 p = ctx.profile_read("conv_igemm")
+pf = ctx.profile_read("conv_fused")
+if pf["launches"]:
+    p = pf
 fl = 2.0 * B * H * W * k * k * Cin * Cout
 ms = p["ms"] / 5
 extra = ctx.profile_read("wino_input")["ms"] / 5 + ctx.profile_read("wino_output")["ms"] / 5
