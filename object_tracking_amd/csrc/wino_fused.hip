@@ -64,40 +64,46 @@ __global__ __launch_bounds__(256, 2) void wino2_fused_pool_kernel(WinoFusedArgs 
 #pragma unroll
             for (int e = 0; e < 16; ++e) Y[a][c][e] = 0.0f;
 
-    f32x4 bq[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bq[q] = wf_ld4(ub + q * 4);
-
-#pragma unroll
-    for (int pos = 0; pos < 16; ++pos) {
+    // V_p for this lane's tile and 16 channels, straight from the patch
+    auto form_v = [&](int pos, f32x4 *v) {
         const int xi = pos >> 2, nu = pos & 3;
         // Bt rows: 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3  ->  (first, second, sign of second)
         const int i1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), i2 = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
         const int j1 = nu == 0 ? 0 : (nu == 2 ? 2 : 1), j2 = nu == 0 ? 2 : (nu == 1 ? 2 : (nu == 2 ? 1 : 3));
         const bool si_plus = xi == 1, sj_plus = nu == 1;
-        f32x4 v[4];
-        {
-            const int sw1 = (tx + (j1 >> 1)) & 7, sw2 = (tx + (j2 >> 1)) & 7;   // ((2tx + j) >> 1) & 7
-            const float *p11 = pbase + (i1 * WF_P + j1) * WF_C, *p12 = pbase + (i1 * WF_P + j2) * WF_C;
-            const float *p21 = pbase + (i2 * WF_P + j1) * WF_C, *p22 = pbase + (i2 * WF_P + j2) * WF_C;
+        const int sw1 = (tx + (j1 >> 1)) & 7, sw2 = (tx + (j2 >> 1)) & 7;   // ((2tx + j) >> 1) & 7
+        const float *p11 = pbase + (i1 * WF_P + j1) * WF_C, *p12 = pbase + (i1 * WF_P + j2) * WF_C;
+        const float *p21 = pbase + (i2 * WF_P + j1) * WF_C, *p22 = pbase + (i2 * WF_P + j2) * WF_C;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int s1 = ((hi * 4 + q) ^ sw1) << 2, s2 = ((hi * 4 + q) ^ sw2) << 2;
-                const f32x4 a = wf_ld4(p11 + s1), bb = wf_ld4(p12 + s2), c = wf_ld4(p21 + s1), d = wf_ld4(p22 + s2);
-                const f32x4 top = sj_plus ? a + bb : a - bb, bot = sj_plus ? c + d : c - d;
-                v[q] = si_plus ? top + bot : top - bot;
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int s1 = ((hi * 4 + q) ^ sw1) << 2, s2 = ((hi * 4 + q) ^ sw2) << 2;
+            const f32x4 a = wf_ld4(p11 + s1), bb = wf_ld4(p12 + s2), c = wf_ld4(p21 + s1), d = wf_ld4(p22 + s2);
+            const f32x4 top = sj_plus ? a + bb : a - bb, bot = sj_plus ? c + d : c - d;
+            v[q] = si_plus ? top + bot : top - bot;
         }
-        f32x4 bn[4];
-        if (pos < 15) {
+    };
+
+    // Software pipeline over the 16 positions: while the 16 dependent MFMAs of position p run, the lane forms
+    // V_{p+1} (LDS reads + adds) and fetches U_{p+1}; the +-1 output transform of M'_p follows.
+    f32x4 bq[4], vq[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bn[q] = wf_ld4(ub + (pos + 1) * ustride + q * 4);
-        }
+    for (int q = 0; q < 4; ++q) bq[q] = wf_ld4(ub + q * 4);
+    form_v(0, vq);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) {
+        const int xi = pos >> 2, nu = pos & 3;
         f32x16 m;
 #pragma unroll
         for (int e = 0; e < 16; ++e) m[e] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) m = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s >> 2][s & 3], bq[s >> 2][s & 3], m, 0, 0, 0);
+        for (int s = 0; s < 16; ++s) m = __builtin_amdgcn_mfma_f32_32x32x2f32(vq[s >> 2][s & 3], bq[s >> 2][s & 3], m, 0, 0, 0);
+        f32x4 bn[4], vn[4];
+        if (pos < 15) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bn[q] = wf_ld4(ub + (pos + 1) * ustride + q * 4);
+            form_v(pos + 1, vn);
+        }
         // At = [[1,1,1,0],[0,1,-1,-1]]: Y[a][c] += At[a][xi] * At[c][nu] * M'
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -110,9 +116,9 @@ __global__ __launch_bounds__(256, 2) void wino2_fused_pool_kernel(WinoFusedArgs 
             }
         if (pos < 15) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bq[q] = bn[q];
+            for (int q = 0; q < 4; ++q) { bq[q] = bn[q]; vq[q] = vn[q]; }
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the positions apart: hoisting the next positions' loads costs registers
+        __builtin_amdgcn_sched_barrier(0);   // keep the positions apart: hoisting further ahead costs registers
     }
 
     // ---- bias + LeakyReLU + 2x2 max; C/D layout: col = lane & 31 (output channel), row = tile ----
