@@ -251,7 +251,7 @@ def _run():
         elapsed = float(tmax.item())
 
     kern = {}
-    for name in ("conv_igemm", "wino_input", "wino_output", "conv1_direct", "convlstm_gates", "decode_nms", "associate", "splitk_reduce", "pool",
+    for name in ("conv_igemm", "conv_fused", "wino_input", "wino_output", "conv1_direct", "convlstm_gates", "decode_nms", "associate", "splitk_reduce", "pool",
                  "lstm_step", "misc"):
         p = ctx.profile_read(name)
         if p["launches"]:
