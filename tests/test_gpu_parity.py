@@ -982,3 +982,20 @@ def test_conv2_fused_winograd_one_hot(ctx, monkeypatch):
         w[n % 3, (n // 3) % 3, (n * 7) % 32, n] = 1.0
     got = ctx.conv2d(dev(x, ctx), w, None, leaky_slope=1.0, pool=1).cpu().numpy()
     assert np.array_equal(got, orc.maxpool2(orc.conv2d(x, w)))
+
+
+@pytest.mark.parametrize("mode", ["default", "all_winograd"])
+def test_detector_non_square_odd_grid_vs_oracle(ctx, monkeypatch, mode):
+    """352x288 frames (grid 11x9: odd, non-square, not a multiple of any Winograd tile), 5 frames (ragged mosaic
+    groups, partial 8x8 workgroups of the fused conv_2 kernel at 88x72 pooled pixels): whole detector vs oracle."""
+    if mode == "all_winograd":
+        monkeypatch.setenv("DT_WINO", "2")
+        monkeypatch.setenv("DT_WINO_FUSED", "2")
+    det, layers, _ = _detector(ctx, 352, 288, 12)
+    frames = synth.synth_clip(5, 352, 288, 3, seed=21)
+    ref_net, ref_feat, _ = orc.yolov2_forward(orc.normalize_u8(frames), layers)
+    c = det.model.ctx
+    net, feat = c.detect_forward(dev(frames, c), want_feat=True)
+    assert net.shape == (5, 11, 9, 5, 17)
+    assert relerr(net.cpu().numpy(), ref_net) < 1e-3
+    assert relerr(feat.cpu().numpy(), ref_feat) < 1e-3
