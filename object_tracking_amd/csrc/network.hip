@@ -157,7 +157,7 @@ static int upload(dt_ctx *ctx, float **dst, const std::vector<float> &h)
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int dt_abi_version(void) { return 100; }
+extern "C" int dt_abi_version(void) { return 102; }   // 1.02: + dt_encode_targets, dt_graph_enable
 
 extern "C" int dt_create(dt_ctx **out)
 {
