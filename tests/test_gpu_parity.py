@@ -999,3 +999,37 @@ def test_detector_non_square_odd_grid_vs_oracle(ctx, monkeypatch, mode):
     assert net.shape == (5, 11, 9, 5, 17)
     assert relerr(net.cpu().numpy(), ref_net) < 1e-3
     assert relerr(feat.cpu().numpy(), ref_feat) < 1e-3
+
+
+def test_winograd_randomized_shapes_vs_oracle(ctx, monkeypatch):
+    """40 seeded random layers through the Winograd path (every tile size, forced and automatic mosaics, pooled /
+    both / plain epilogues, ragged groups, grids smaller than a tile) against the oracle.  tools/wino_fuzz.py runs
+    the same loop for any seed / count."""
+    monkeypatch.setenv("DT_WINO", "2")
+    rs = np.random.RandomState(1)
+    for it in range(40):
+        ts = int(rs.choice([2, 4, 6]))
+        monkeypatch.setenv("DT_WINO_TILE", str(ts))
+        B = int(rs.randint(1, 21))
+        H = int(rs.randint(1, 21)) * (2 if rs.rand() < 0.5 else 1)
+        W = int(rs.randint(1, 21)) * (2 if rs.rand() < 0.5 else 1)
+        Cin = int(rs.choice([32, 64, 96])); Cout = int(rs.randint(1, 41)) * 4
+        pool = int(rs.choice([0, 1, 2])) if (H % 2 == 0 and W % 2 == 0) else 0
+        mos = rs.choice(["", "1", "2", "3", "4"])
+        if mos:
+            monkeypatch.setenv("DT_WINO_MOSAIC", mos)
+        else:
+            monkeypatch.delenv("DT_WINO_MOSAIC", raising=False)
+        x = rs.randn(B, H, W, Cin).astype(np.float32)
+        w = (rs.randn(3, 3, Cin, Cout) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+        b = rs.randn(Cout).astype(np.float32)
+        ref = orc.conv2d(x, w, b)
+        ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
+        got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=pool)
+        if pool == 0:
+            e = relerr(got.cpu().numpy(), ref)
+        elif pool == 1:
+            e = relerr(got.cpu().numpy(), orc.maxpool2(ref))
+        else:
+            e = max(relerr(got[0].cpu().numpy(), ref), relerr(got[1].cpu().numpy(), orc.maxpool2(ref)))
+        assert e < {2: 2e-5, 4: 1e-4, 6: 3e-4}[ts], (it, ts, B, H, W, Cin, Cout, pool, mos, e)
