@@ -413,6 +413,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
                 }
             return;
         }
+        // Raw GEMM output (the batched Winograd GEMMs: no bias, linear): the epilogue of a 256x256 tile is VALU-issue
+        // bound (tools/tile_timing.py: 6 us), so skip the activation arithmetic and walk the rows with one pointer
+        if (EPI == EPI_PLAIN && PERSIST && p.bias == nullptr && p.slope == 1.0f && p.act == 0) {
+    #pragma unroll
+            for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * WTN + j * 32 + fr;
+                    if (col >= p.N) continue;
+                    const int r0 = m0 + wm * WTM + i * 32 + 4 * hi;
+                    float *o = outz + (long long)r0 * p.out_ld + col;
+    #pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (r0 + 8 * g + q < p.M) o[(long long)(8 * g + q) * p.out_ld] = acc[i][j][4 * g + q];
+                    }
+                }
+            return;
+        }
     #pragma unroll
         for (int i = 0; i < TM; ++i)
     #pragma unroll
