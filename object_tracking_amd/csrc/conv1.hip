@@ -30,12 +30,15 @@ struct Conv1Args {
 __global__ __launch_bounds__(256) void conv1_direct_kernel(Conv1Args p)
 {
     __shared__ __attribute__((aligned(16))) float s_patch[18 * 18 * 4];
+    __shared__ float s_lut[256];
 
     const int tid = threadIdx.x;
     const int H2 = p.H >> 1, W2 = p.W >> 1;
     const int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z;
     const int cy0 = by * 16 - 1, cx0 = bx * 16 - 1;   // patch origin in input pixels
 
+    s_lut[tid] = p.lut[tid];          // 256 threads, 256 entries: the x/255 table moves to LDS once per workgroup
+    __syncthreads();
     for (int i = tid; i < 18 * 18; i += 256) {
         const int r = i / 18, c = i - r * 18;
         const int y = cy0 + r, x = cx0 + c;
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256) void conv1_direct_kernel(Conv1Args p)
             const long long off = (((long long)b * p.H + y) * p.W + x) * 3;
             if (p.dtype == DT_FRAMES_U8) {
                 const unsigned char *s = reinterpret_cast<const unsigned char *>(p.frames) + off;
-                v0 = p.lut[s[0]]; v1 = p.lut[s[1]]; v2 = p.lut[s[2]];
+                v0 = s_lut[s[0]]; v1 = s_lut[s[1]]; v2 = s_lut[s[2]];
             } else {
                 const float *s = reinterpret_cast<const float *>(p.frames) + off;
                 v0 = s[0]; v1 = s[1]; v2 = s[2];
