@@ -39,37 +39,75 @@ ORC_API void orc_normalize_u8(const uint8_t *img, int64_t n, float *out)
 /* Conv2D(strides=(1,1), padding='same'), kernel HWIO, optional bias.
  * KerasYOLO.py:279 (and every conv_N ctor down to :399);
  * MultiObjDetTracker.py:182 (tconv_2). */
+/* One (row, x-block, cout-block) tile: XB pixels x CB output channels held in
+ * accumulators while (ky, kx, ci) run in the reference order -- every output
+ * element is the same fmaf chain as the naive loop nest (out-of-image taps
+ * contribute fmaf(0, w, acc) = acc), the weights are just reused XB times. */
+#define ORC_XB 3
+#define ORC_CB 32
+static void conv_tile(const float *in, int H, int W, int Cin, const float *w, int KS, int Cout,
+                      const float *bias, float *out, int b, int h, int x0, int co0, int xb, int cb, const float *zrow)
+{
+    const int pad = KS / 2;
+    float acc[ORC_XB][ORC_CB];
+    for (int x = 0; x < ORC_XB; ++x)
+        for (int c = 0; c < ORC_CB; ++c) acc[x][c] = (bias && c < cb) ? bias[co0 + c] : 0.0f;
+    for (int ky = 0; ky < KS; ++ky) {
+        const int ih = h + ky - pad;
+        if (ih < 0 || ih >= H) continue;
+        for (int kx = 0; kx < KS; ++kx) {
+            const float *ip[ORC_XB];
+            int any = 0;
+            for (int x = 0; x < ORC_XB; ++x) {
+                const int iw = x0 + x + kx - pad;
+                const int ok = x < xb && iw >= 0 && iw < W;
+                ip[x] = ok ? in + (((size_t)b * H + ih) * W + iw) * Cin : zrow;
+                any |= ok;
+            }
+            if (!any) continue;
+            const float *wp = w + ((size_t)(ky * KS + kx) * Cin) * Cout + co0;
+            if (cb == ORC_CB) {
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const float *wr = wp + (size_t)ci * Cout;
+                    for (int x = 0; x < ORC_XB; ++x) {
+                        const float v = ip[x][ci];
+                        for (int c = 0; c < ORC_CB; ++c) acc[x][c] = fmaf(v, wr[c], acc[x][c]);
+                    }
+                }
+            } else {
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const float *wr = wp + (size_t)ci * Cout;
+                    for (int x = 0; x < ORC_XB; ++x) {
+                        const float v = ip[x][ci];
+                        for (int c = 0; c < cb; ++c) acc[x][c] = fmaf(v, wr[c], acc[x][c]);
+                    }
+                }
+            }
+        }
+    }
+    for (int x = 0; x < xb; ++x)
+        memcpy(out + (((size_t)b * H + h) * W + x0 + x) * Cout + co0, acc[x], sizeof(float) * (size_t)cb);
+}
+
 ORC_API void orc_conv2d(const float *in, int B, int H, int W, int Cin,
                         const float *w, int KS, int Cout, const float *bias,
                         float *out)
 {
-    const int pad = KS / 2;
-#pragma omp parallel for collapse(2) schedule(static)
-    for (int b = 0; b < B; ++b)
-        for (int h = 0; h < H; ++h) {
-            float *acc = (float *)malloc(sizeof(float) * (size_t)Cout);
-            for (int x = 0; x < W; ++x) {
-                for (int co = 0; co < Cout; ++co) acc[co] = bias ? bias[co] : 0.0f;
-                for (int ky = 0; ky < KS; ++ky) {
-                    const int ih = h + ky - pad;
-                    if (ih < 0 || ih >= H) continue;
-                    for (int kx = 0; kx < KS; ++kx) {
-                        const int iw = x + kx - pad;
-                        if (iw < 0 || iw >= W) continue;
-                        const float *ip = in + (((size_t)b * H + ih) * W + iw) * Cin;
-                        const float *wp = w + ((size_t)(ky * KS + kx) * Cin) * Cout;
-                        for (int ci = 0; ci < Cin; ++ci) {
-                            const float v = ip[ci];
-                            const float *wr = wp + (size_t)ci * Cout;
-                            for (int co = 0; co < Cout; ++co) acc[co] = fmaf(v, wr[co], acc[co]);
-                        }
-                    }
-                }
-                memcpy(out + (((size_t)b * H + h) * W + x) * Cout, acc,
-                       sizeof(float) * (size_t)Cout);
-            }
-            free(acc);
-        }
+    const int nxb = (W + ORC_XB - 1) / ORC_XB, ncb = (Cout + ORC_CB - 1) / ORC_CB;
+    const long long ntile = (long long)B * H * nxb * ncb;
+    float *zrow = (float *)calloc((size_t)Cin, sizeof(float));   /* source of out-of-image taps */
+#pragma omp parallel for schedule(dynamic, 8)
+    for (long long t = 0; t < ntile; ++t) {
+        const int cbi = (int)(t % ncb);
+        long long r = t / ncb;
+        const int xbi = (int)(r % nxb); r /= nxb;
+        const int h = (int)(r % H);
+        const int b = (int)(r / H);
+        const int x0 = xbi * ORC_XB, co0 = cbi * ORC_CB;
+        conv_tile(in, H, W, Cin, w, KS, Cout, bias, out, b, h, x0, co0,
+                  W - x0 < ORC_XB ? W - x0 : ORC_XB, Cout - co0 < ORC_CB ? Cout - co0 : ORC_CB, zrow);
+    }
+    free(zrow);
 }
 
 /* BatchNormalization() in inference mode (moving statistics, Keras default
