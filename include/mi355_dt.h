@@ -48,7 +48,7 @@ DT_API int dt_create(dt_ctx **out);
 DT_API void dt_destroy(dt_ctx *ctx);
 DT_API const char *dt_last_error(dt_ctx *ctx);
 DT_API int dt_set_stream(dt_ctx *ctx, void *hip_stream);
-/* ABI version of this header: major*100+minor (1.02: 1.00 + dt_encode_targets, dt_graph_enable) */
+/* ABI version of this header: major*100+minor (1.03: 1.02 + dt_policy_reload, dt_detector_extract) */
 DT_API int dt_abi_version(void);
 
 /* ---- detector: KerasYOLO ---------------------------------------------- */
@@ -80,6 +80,18 @@ DT_API int dt_detect_forward(dt_ctx *ctx, const void *d_frames, int frames_dtype
  * dt_detect_forward of the same batch; copies into d_out. */
 DT_API int dt_detector_tap(dt_ctx *ctx, const char *name, int batch, float *d_out);
 
+/* Replaces KerasYOLO.extract's intermediate_layer_model for ANY layer of the detector graph
+ * (KerasYOLO.py:509-520: Model(inputs, self.model.get_layer(layer).output).predict(...)).  Layer names as the
+ * reference / Keras give them: conv_1..conv_23 (Conv2D output; conv_23 incl. its bias), norm_1..norm_22
+ * (BatchNormalization output), leaky_re_lu_1..21 (alias act_N) and conv_feat (after LeakyReLU),
+ * max_pooling2d_1..5, lambda_1 (space_to_depth), concatenate_1, reshape_1 / lambda_2 (= conv_23 values).
+ * The fused production path never materialises most of these: the call re-runs the graph up to the layer and
+ * executes that layer un-fused (a one-image debugging call, not a hot path).
+ *   shape4 [4] receives (batch, h, w, channels) of the layer (may be NULL); with d_out == NULL only the shape
+ *   is returned; d_out holds out_floats floats and receives the dense NHWC tensor. */
+DT_API int dt_detector_extract(dt_ctx *ctx, const void *d_frames, int frames_dtype, int batch,
+                               const char *layer, float *d_out, size_t out_floats, int *shape4);
+
 /* ---- frame ingest ----------------------------------------------------- */
 /* Replaces cv2.resize(image, (IMAGE_H, IMAGE_W)) on decoded uint8 frames
  * (KerasYOLO.py:526, MultiObjDetTracker.py:302); the /255. of normalize() is fused into
@@ -99,6 +111,13 @@ DT_API int dt_decode(dt_ctx *ctx, const float *d_netout, int batch, int GH, int 
               int NB, int NC, float obj_threshold, float nms_threshold,
               const float *h_anchors, int cap, float *d_boxes, int *d_counts,
               float *d_classes, float *d_post);
+
+/* The same with one (obj_threshold, nms_threshold) pair PER FRAME -- d_thresholds [batch, 2] float32 on the
+ * device: streams of a batch may run different operating points (addition; the reference decodes one frame per
+ * call with one pair, utils.py:208). */
+DT_API int dt_decode_per_frame(dt_ctx *ctx, const float *d_netout, int batch, int GH, int GW,
+                        int NB, int NC, const float *d_thresholds, const float *h_anchors, int cap,
+                        float *d_boxes, int *d_counts, float *d_classes, float *d_post);
 
 /* bbox_iou (utility/utils.py:155-173) on n pairs: d_pairs [n,8] -> d_iou [n] */
 DT_API int dt_bbox_iou(dt_ctx *ctx, const float *d_pairs, int n, float *d_iou);
@@ -211,6 +230,11 @@ DT_API int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int W, 
                      const float *d_h, const float *d_c, int U,
                      const float *h_kernel, const float *h_recurrent,
                      const float *h_bias, float *d_h_out, float *d_c_out);
+
+/* ---- tuning / test knobs ------------------------------------------------- *
+ * The DT_* environment variables of DESIGN.md's appendix are read ONCE, in dt_create (no launch path calls
+ * getenv); this re-reads them into a live context.  dt_conv2d / dt_convlstm_step do the same on entry. */
+DT_API int dt_policy_reload(dt_ctx *ctx);
 
 /* ---- profiling --------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on the ctx

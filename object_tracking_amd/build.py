@@ -22,6 +22,7 @@ SOURCES = {
     "winograd.hip": [],
     "wino_fused.hip": [],
     "ingest.hip": [],
+    "extract.hip": [],
     "decode.hip": ["-ffp-contract=off"],
     "targets.hip": ["-ffp-contract=off"],
     "recurrent.hip": [],

@@ -775,12 +775,9 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
     static const int gn_env = [] { const char *e = getenv("DT_TILE_GN"); return e ? atoi(e) : -1; }();
     if (a_in.tile_gn < 0) a.tile_gn = -a_in.tile_gn - 1;   // caller-chosen width, encoded as -(gn+1)
     else a.tile_gn = gn_env >= 0 ? gn_env : ((ks == 3 && epi != EPI_GATES) ? 1 : 2);
-    // DT_CONV_CFG forces a tile configuration for the 128-wide-or-wider layers (A/B runs and the
-    // tests that exercise every configuration at small shapes); read per call on purpose
-    if (const char *e = getenv("DT_CONV_CFG")) {
-        const int forced = atoi(e);
-        if (forced >= 0 && cfg != CFG_128x64 && epi != EPI_PARTIAL) cfg = forced;
-    }
+    // a caller-forced tile configuration (Policy::conv_cfg: A/B runs and the tests that exercise every
+    // configuration at small shapes) applies to the 128-wide-or-wider layers
+    if (a.force_cfg > 0 && cfg != CFG_128x64 && epi != EPI_PARTIAL) cfg = a.force_cfg - 1;
     if (cfg == CFG_256x256) {   // the column tile may only read weight rows that exist
         const int have = a.npad ? a.npad : (a.N + 127) / 128 * 128;
         if (have < (a.N + 255) / 256 * 256) cfg = CFG_256x128;

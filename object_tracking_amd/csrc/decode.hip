@@ -89,6 +89,7 @@ struct DecodeArgs {
     long long frame_stride;
     int GH, GW, NB, NC;
     float obj_thr, nms_thr;
+    const float *frame_thr;   // optional [batch][2] (obj, nms) per frame: one threshold pair per camera / stream
     const float *anchors;
     int cap;
     float *boxes;
@@ -107,6 +108,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
     const int ncell = p.GH * p.GW * p.NB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frame = blockIdx.x;
+    const float obj_thr = p.frame_thr ? p.frame_thr[2 * frame] : p.obj_thr;
+    const float nms_thr = p.frame_thr ? p.frame_thr[2 * frame + 1] : p.nms_thr;
     const float *net = p.netout + (long long)frame * p.frame_stride;
     float *post = p.post + (long long)frame * ncell * S;
 
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
                 }
                 for (int c = 0; c < p.NC; ++c) {
                     const float pr = conf * (r[5 + c] / sum);   // :215
-                    const float keep = pr > p.obj_thr ? pr : 0.0f;   // :216
+                    const float keep = pr > obj_thr ? pr : 0.0f;   // :216
                     r[5 + c] = keep;
                     if (keep != 0.0f) { any = true; atomicAdd(&s_ccnt[c], 1); }
                 }
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
                     const int kj = l_id[j];
                     const float iou = bbox_iou_ref(ax, ay, aw, ah, s_bx[kj], s_bx[MC + kj],
                                                    s_bx[2 * MC + kj], s_bx[3 * MC + kj]);
-                    if (iou >= p.nms_thr) {
+                    if (iou >= nms_thr) {
                         l_sc[j] = 0.0f;
                         post[(long long)s_cell[kj] * S + 5 + c] = 0.0f;   // :252
                     }
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
                 const float v = r[5 + c];
                 if (v > best) { best = v; lab = c; }   // np.argmax: first maximum
             }
-            keep = best > p.obj_thr;
+            keep = best > obj_thr;
         }
         int tot;
         const int slot = nout + block_flag_scan(keep, s_tot, tot);
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
 
 int launch_decode(hipStream_t st, const float *netout, long long frame_stride, int batch, int GH, int GW, int NB,
                   int NC, float obj_thr, float nms_thr, const float *anchors_dev, int cap, float *boxes,
-                  int *counts, float *classes, float *post, float * /*unused*/)
+                  int *counts, float *classes, float *post, const float *frame_thr)
 {
     const int S = 5 + NC;
     const int ncell = GH * GW * NB;
@@ -328,7 +331,7 @@ int launch_decode(hipStream_t st, const float *netout, long long frame_stride, i
     DecodeArgs a;
     a.netout = netout; a.frame_stride = frame_stride;
     a.GH = GH; a.GW = GW; a.NB = NB; a.NC = NC;
-    a.obj_thr = obj_thr; a.nms_thr = nms_thr; a.anchors = anchors_dev; a.cap = cap;
+    a.obj_thr = obj_thr; a.nms_thr = nms_thr; a.frame_thr = frame_thr; a.anchors = anchors_dev; a.cap = cap;
     a.boxes = boxes; a.counts = counts; a.classes = classes; a.post = post; a.chunk_cells = chunk;
     const int mc = ((ncell + 63) / 64) * 64;
     a.mc = mc;

@@ -54,6 +54,7 @@ struct ConvArgs {
     // batched GEMMs (Winograd positions): grid.z problems, blockIdx.z advances in / wt / out by these (floats)
     int zbatch;
     long long z_in, z_wt, z_out;
+    int force_cfg; // > 0: tile configuration + 1 forced by the caller's policy (Policy::conv_cfg); 0: none
 };
 
 // Tile configurations of the MFMA kernel
@@ -126,7 +127,7 @@ int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, in
 
 int launch_decode(hipStream_t st, const float *netout, long long frame_stride, int batch, int GH, int GW, int NB,
                   int NC, float obj_thr, float nms_thr, const float *anchors_dev, int cap, float *boxes,
-                  int *counts, float *classes, float *post, float *scratch /*[batch][ncell*(5+NC)] or null*/);
+                  int *counts, float *classes, float *post, const float *frame_thr /*[batch][2] (obj, nms) or null*/);
 
 int launch_bbox_iou(hipStream_t st, const float *pairs, int n, float *iou);
 
@@ -147,6 +148,9 @@ int launch_top_box(hipStream_t st, const float *boxes, const int *counts, int n_
 int launch_convlstm_gates_only(hipStream_t st, const float *xproj, long long xp_bs, int xp_ld, float *cstate,
                                long long c_bs, int c_ld, float *hout, long long h_bs, int h_ld, int B, int HW,
                                int U);
+
+int launch_expand_rgb32(hipStream_t st, const void *frames, int dtype, long long n_pix, const float *lut, float *out);
+int launch_unfold_bn(hipStream_t st, float *x, long long rows, int C, const float *scale, const float *shift);
 
 int launch_global_maxpool(hipStream_t st, const float *in, int n, int HW, int C, float *out, int out_ld);
 int launch_maxpool4_flatten(hipStream_t st, const float *in, int n, int H, int W, int C, float *out, int out_ld);
@@ -185,19 +189,41 @@ struct ConvLayer {
     int wino_ts = 0;                     // their output tile size (2, 4 or 6)
     float *fused = nullptr;              // device, fused-Winograd weights (32 -> 64 pooled layer: conv_2) or null
     float *bias = nullptr;               // device, [npad]
+    float *scale = nullptr;              // device, [cout]: folded BatchNorm scale (dt_detector_extract un-folds with it) or null
+    bool scale_has_zero = false;
 };
+
+// Tuning / test knobs.  Read from the environment ONCE, in dt_create; the two layer-level
+// test entry points (dt_conv2d, dt_convlstm_step) re-read it so that the parity tests can force a policy on a
+// live context.  No launch path calls getenv.
+struct Policy {
+    int wino = 1;            // DT_WINO: 0 never / 1 default policy / 2 everywhere the transforms are defined
+    int wino_tile = 0;       // DT_WINO_TILE: 2/4/6 for every layer; 0 = default (6, recurrent convolution 4)
+    int wino_minc = 64, wino_minn = 128, wino_mint = 0;   // DT_WINO_MINC / MINN / MINT (A/B runs)
+    double wino_ws_gb = 96.0;   // DT_WINO_WS_GB: V + M' workspace above this -> direct form
+    int mosaic = -1;         // DT_WINO_MOSAIC: 1 never, 2/3/4 force, -1 = fewest tiles
+    int fused = 1;           // DT_WINO_FUSED: 0 never / 1 from 512 workgroups / 2 always
+    int wino_cfg = -1, wino_gn = -1;   // DT_WINO_CFG / DT_WINO_GN (A/B runs)
+    int ksplit = 0;          // DT_KSPLIT
+    int conv_cfg = -1;       // DT_CONV_CFG
+};
+void policy_from_env(Policy &p);
 
 struct dt_ctx {
     std::string err;
+    Policy pol;
     hipStream_t stream = nullptr;
     int device_ok = 0;
     // detector
     int image_h = 0, image_w = 0, nb_box = 0, nb_class = 0, cb = 0;
     float anchors[64];
     float *anchors_dev = nullptr;
+    float dec_anchors_host[64];   // last anchors handed to dt_decode (persistent staging of the caller's host array)
+    int dec_anchors_n = 0;
     bool det_loaded = false;
     ConvLayer layers[24];   // 1..23
     float *conv1_w = nullptr, *conv1_b = nullptr, *lut255 = nullptr;
+    std::vector<float> conv1_hwio32, conv1_scale, conv1_shift;   // host copy of conv_1 as a Cin = 32 layer (dt_detector_extract)
     // tracker head
     bool trk_loaded = false;
     int trk_units = 0, trk_cx = 0 /*padded z channels*/;
@@ -214,6 +240,7 @@ struct dt_ctx {
     // workspaces (grown on demand)
     std::map<std::string, DevBuf> ws;
     int last_batch = 0;
+    bool tap_feat = false, tap_netout = false;   // last forward wrote the library-owned 'feat' / 'netout' workspaces
     int ing_key[4] = {0, 0, 0, 0};   // (Hs, Ws, Hd, Wd) of the cached ingest tables
     // hipGraph replay of the launch-bound inner sequences (dt_graph_enable; network.hip:graphed)
     bool graph_on = false, capturing = false;

@@ -157,7 +157,7 @@ static int upload(dt_ctx *ctx, float **dst, const std::vector<float> &h)
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int dt_abi_version(void) { return 102; }   // 1.02: + dt_encode_targets, dt_graph_enable
+extern "C" int dt_abi_version(void) { return 103; }   // 1.03: + dt_policy_reload, dt_detector_extract
 
 extern "C" int dt_create(dt_ctx **out)
 {
@@ -177,6 +177,7 @@ extern "C" int dt_create(dt_ctx **out)
                        prop.gcnArchName);
     dt_ctx *c = new dt_ctx();
     c->device_ok = 1;
+    policy_from_env(c->pol);
     std::vector<float> lut(256);
     for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);   // utils.py:150-153
     if (upload(c, &c->lut255, lut) != DT_OK) {
@@ -199,6 +200,7 @@ extern "C" void dt_destroy(dt_ctx *ctx)
         if (ctx->layers[i].bias) (void)hipFree(ctx->layers[i].bias);
         if (ctx->layers[i].wino) (void)hipFree(ctx->layers[i].wino);
         if (ctx->layers[i].fused) (void)hipFree(ctx->layers[i].fused);
+        if (ctx->layers[i].scale) (void)hipFree(ctx->layers[i].scale);
     }
     float *singles[] = {ctx->conv1_w, ctx->conv1_b, ctx->lut255, ctx->anchors_dev, ctx->trk_wx, ctx->trk_bx,
                         ctx->trk_wh,  ctx->trk_wo,  ctx->trk_bo, ctx->trk_wx_wino, ctx->trk_wh_wino, ctx->tiny_wx,     ctx->tiny_bx, ctx->tiny_ur,
@@ -255,9 +257,8 @@ static void oihw_to_hwio(const float *src, int O, int I, int k, std::vector<floa
                     dst[(((size_t)y * k + x) * I + i) * O + o] = src[(((size_t)o * I + i) * k + y) * k + x];
 }
 
-static bool wino_wanted(int ks, int cin, int cout);
-static int wino_mode();
-static int wino_tile(bool recurrent);
+static bool wino_wanted(const dt_ctx *ctx, int ks, int cin, int cout);
+static int wino_tile(const dt_ctx *ctx, bool recurrent);
 static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map,
                        int cin_dst, const int *n_map, int npad, const float *scale);
 
@@ -273,16 +274,23 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
     for (int c = 0; c < cout; ++c) bias[c] = bias_src[c];
     int rc = upload(ctx, &L.wt, packed);
     if (rc) return rc;
+    if (L.scale) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.scale); L.scale = nullptr; }
+    L.scale_has_zero = false;
+    if (scale) {
+        std::vector<float> sc(scale, scale + cout);
+        for (float v : sc) L.scale_has_zero |= (v == 0.0f);
+        if ((rc = upload(ctx, &L.scale, sc))) return rc;
+    }
     if (L.wino) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino); L.wino = nullptr; }
     if (L.fused) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused); L.fused = nullptr; }
-    if (ks == 3 && cin == 32 && cout == 64 && wino_mode() != 0) {   // conv_2's shape: fused F(2x2,3x3) + pool kernel
+    if (ks == 3 && cin == 32 && cout == 64 && ctx->pol.wino != 0) {   // conv_2's shape: fused F(2x2,3x3) + pool kernel
         std::vector<float> uf((size_t)16 * 2 * 32 * 2 * 16);
         wino2_fused_pack(hwio, scale, uf.data());
         rc = upload(ctx, &L.fused, uf);
         if (rc) return rc;
     }
-    if (wino_wanted(ks, cin, cout)) {
-        L.wino_ts = wino_tile(false);
+    if (wino_wanted(ctx, ks, cin, cout)) {
+        L.wino_ts = wino_tile(ctx, false);
         rc = upload_wino(ctx, &L.wino, L.wino_ts, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale);
         if (rc) return rc;
     }
@@ -324,6 +332,12 @@ extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t 
             if (rc) return rc;
             rc = upload(ctx, &ctx->conv1_b, shift);
             if (rc) return rc;
+            ctx->conv1_hwio32.assign((size_t)9 * 32 * 32, 0.0f);   // [3][3][32 (3 used)][32]
+            for (int t = 0; t < 9; ++t)
+                for (int ci = 0; ci < 3; ++ci)
+                    for (int c = 0; c < 32; ++c)
+                        ctx->conv1_hwio32[((size_t)t * 32 + ci) * 32 + c] = hwio[((size_t)t * 3 + ci) * 32 + c];
+            ctx->conv1_scale = scale; ctx->conv1_shift = shift;
         } else {
             int rc = load_conv_layer(ctx, s.idx, s.k, s.cin, s.cout, hwio.data(), scale.data(), shift.data());
             if (rc) return rc;
@@ -355,52 +369,59 @@ static void prof_direct_form(dt_ctx *ctx, double flops)
 // ---------------------------------------------------------------------------
 // Winograd path for the 3x3 layers from conv_3 up and the ConvLSTM convolutions (winograd.hip)
 // ---------------------------------------------------------------------------
-// DT_WINO: 1 (default) = layers with Cin >= 64 and Cout >= 128 (conv_3 and up: below that the batched
+// Policy::wino: 1 (default) = layers with Cin >= 64 and Cout >= 128 (conv_3 and up: below that the batched
 //          GEMMs have K <= 32 and the transforms' traffic costs more than the MFMA work saved) when a
 //          launch has enough tiles (wino_runs);
 //          0 = never (direct MFMA form everywhere); 2 = every 3x3 layer the transforms support,
-//          at any size (parity tests of the path at small shapes).  Read when weights are loaded.
-static int wino_mode()
+//          at any size (parity tests of the path at small shapes).  Applied when weights are loaded.
+void policy_from_env(Policy &p)
 {
-    const char *e = getenv("DT_WINO");
-    return e ? atoi(e) : 1;
+    auto geti = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    Policy d;
+    p.wino = geti("DT_WINO", d.wino);
+    p.wino_tile = geti("DT_WINO_TILE", d.wino_tile);
+    p.wino_minc = geti("DT_WINO_MINC", d.wino_minc);
+    p.wino_minn = geti("DT_WINO_MINN", d.wino_minn);
+    p.wino_mint = geti("DT_WINO_MINT", d.wino_mint);
+    { const char *e = getenv("DT_WINO_WS_GB"); p.wino_ws_gb = e ? atof(e) : d.wino_ws_gb; }
+    p.mosaic = geti("DT_WINO_MOSAIC", d.mosaic);
+    p.fused = geti("DT_WINO_FUSED", d.fused);
+    p.wino_cfg = geti("DT_WINO_CFG", d.wino_cfg);
+    p.wino_gn = geti("DT_WINO_GN", d.wino_gn);
+    p.ksplit = geti("DT_KSPLIT", d.ksplit);
+    p.conv_cfg = geti("DT_CONV_CFG", d.conv_cfg);
 }
 
-static bool wino_wanted(int ks, int cin, int cout)
+static bool wino_wanted(const dt_ctx *ctx, int ks, int cin, int cout)
 {
-    const int mode = wino_mode();
-    if (ks != 3 || mode == 0 || cin % 32 || cout % 4) return false;
-    static const int minc = [] { const char *e = getenv("DT_WINO_MINC"); return e ? atoi(e) : 64; }();   // A/B runs
-    static const int minn = [] { const char *e = getenv("DT_WINO_MINN"); return e ? atoi(e) : 128; }();   // A/B runs
-    return mode == 2 || (cin >= minc && cout >= minn);
+    const Policy &p = ctx->pol;
+    if (ks != 3 || p.wino == 0 || cin % 32 || cout % 4) return false;
+    return p.wino == 2 || (cin >= p.wino_minc && cout >= p.wino_minn);
 }
 
-// DT_WINO_TILE: output tile of the Winograd form, 6 = F(6x6,3x3) (default), 4 = F(4x4,3x3), 2 = F(2x2,3x3).
-// Read when weights are loaded.
-static int wino_tile(bool recurrent = false)
+// Output tile of the Winograd form: 6 = F(6x6,3x3) (default), 4 = F(4x4,3x3), 2 = F(2x2,3x3); Policy::wino_tile
+// forces one size for every layer.  Applied when weights are loaded.
+static int wino_tile(const dt_ctx *ctx, bool recurrent)
 {
     // The ConvLSTM recurrent convolution keeps F(4x4): its per-step GEMM has only clips/4 * 49 rows, which F(6x6)
     // (clips/9 * 49) fills no better, and the F(6x6) gate-update transform needs all 256 VGPRs (2.0 vs 5.3 TB/s).
-    const char *e = getenv("DT_WINO_TILE");
-    const int t = e ? atoi(e) : (recurrent ? 4 : 6);
+    const int t = ctx->pol.wino_tile ? ctx->pol.wino_tile : (recurrent ? 4 : 6);
     return (t == 2 || t == 4) ? t : 6;
 }
 
-static bool wino_runs(const float *wino_wt, int ts, int B, int H, int W, int cin, int N)
+static bool wino_runs(const dt_ctx *ctx, const float *wino_wt, int ts, int B, int H, int W, int cin, int N)
 {
     if (!wino_wt) return false;
     const long long mt = (long long)B * ((H + ts - 1) / ts) * ((W + ts - 1) / ts);
     if (mt >= (1ll << 31) / 64) return false;
     // V and M' workspaces are (ts+2)^2 * tiles * (Cin + N) floats (27 GB for conv_3 at 1440 frames); a launch
-    // that would need more than DT_WINO_WS_GB (default 96) takes the direct form instead of failing to allocate
-    const char *cap_env = getenv("DT_WINO_WS_GB");   // read per call
-    const double ws_cap = (cap_env ? atof(cap_env) : 96.0) * 1e9;
-    if (4.0 * (ts + 2) * (ts + 2) * (double)mt * ((double)cin + N) > ws_cap) return false;
+    // that would need more than Policy::wino_ws_gb (default 96) takes the direct form instead of failing to allocate
+    if (4.0 * (ts + 2) * (ts + 2) * (double)mt * ((double)cin + N) > ctx->pol.wino_ws_gb * 1e9) return false;
     // below this many tiles the batched GEMMs' row tiles are mostly empty and the direct (split-K) form wins
     // (detector-only sweep, batch 1/4/8/16: threshold 512 -> 679/1822/2672/3487 frames/s, 64 -> 695/1960/3341/4402,
     // 16 -> 556/1947/3337/4427)
-    static const int mint = [] { const char *e = getenv("DT_WINO_MINT"); return e ? atoi(e) : 0; }();   // A/B runs
-    return wino_mode() == 2 || mt >= (mint > 0 ? mint : (ts == 2 ? 256 : (ts == 4 ? 64 : 32)));
+    const int mint = ctx->pol.wino_mint;
+    return ctx->pol.wino == 2 || mt >= (mint > 0 ? mint : (ts == 2 ? 256 : (ts == 4 ? 64 : 32)));
 }
 
 static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map,
@@ -429,6 +450,13 @@ static int pick_cfg_gemm(int Mt, int N, int P)
     return CFG_128x128;
 }
 
+// every MFMA-kernel launch of this file goes through here: the context's forced tile configuration (tests, A/B) rides along
+static int launch_igemm(dt_ctx *ctx, ConvArgs &a, int ks, int order, int epi, int cfg)
+{
+    a.force_cfg = ctx->pol.conv_cfg >= 0 ? ctx->pol.conv_cfg + 1 : 0;
+    return launch_conv_igemm(ctx->stream, a, ks, order, epi, cfg);
+}
+
 struct WinoIO {
     const float *in; long long in_bs; int in_ld;      // NHWC input
     float *out; long long out_bs; int out_ld;         // full-resolution output (null: pooled only)
@@ -447,8 +475,7 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
     // that needs fewer tiles per frame (13x13: 12.25 instead of 16); pooled outputs need frame-aligned tiles
     w.g = 1;
     {
-        const char *ge = getenv("DT_WINO_MOSAIC");   // 1: never (tests, A/B), 2 / 4: force; read per call
-        const int g_env = ge ? atoi(ge) : -1;
+        const int g_env = ctx->pol.mosaic;   // 1: never (tests, A/B), 2 / 3 / 4: force
         double best = (double)((H + ts - 1) / ts) * ((W + ts - 1) / ts);
         for (int g = 2; g <= 4 && !io.out2 && g_env != 1; ++g) {
             const double t = (double)((g * (H + 1) + ts - 1) / ts) * ((g * (W + 1) + ts - 1) / ts) / (g * g);
@@ -459,6 +486,11 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
     else {
         w.th = (w.g * (H + 1) + ts - 1) / ts; w.tw = (w.g * (W + 1) + ts - 1) / ts;
         w.Mt = ((B + w.g * w.g - 1) / (w.g * w.g)) * w.th * w.tw;
+    }
+    if (ctx->prof && !ctx->capturing) {   // which mosaic / tile size a launch took (asserted by the configuration parity tests)
+        char mtag[40];
+        snprintf(mtag, sizeof(mtag), "wino_mosaic:g%d_ts%d", w.g, ts);
+        ctx->prof_tab[mtag].launches += 1;
     }
     const int P = (ts + 2) * (ts + 2);
     const size_t mt = (size_t)w.Mt;
@@ -490,9 +522,9 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
                      4.0 * P * ((double)mt * cin + (double)cin * N + (double)mt * N), tag);
         prof_direct_form(ctx, 2.0 * B * H * W * 9.0 * cin * N);
         int cfg = pick_cfg_gemm(w.Mt, N, P);
-        if (const char *e = getenv("DT_WINO_CFG")) cfg = atoi(e);     // A/B runs
-        if (const char *e = getenv("DT_WINO_GN")) a.tile_gn = -atoi(e) - 1;   // A/B runs: column-group width (see launch_conv_igemm)
-        const int rc = launch_conv_igemm(ctx->stream, a, 1, ORD_LINEAR, EPI_PLAIN, cfg);
+        if (ctx->pol.wino_cfg >= 0) cfg = ctx->pol.wino_cfg;               // A/B runs
+        if (ctx->pol.wino_gn >= 0) a.tile_gn = -ctx->pol.wino_gn - 1;      // A/B runs: column-group width (see launch_conv_igemm)
+        const int rc = launch_igemm(ctx, a, 1, ORD_LINEAR, EPI_PLAIN, cfg);
         if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: Winograd GEMM launch failed (rc=%d)", tag, rc);
     }
     {
@@ -545,8 +577,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
     // conv_2's shape with its pooling epilogue: the fused Winograd kernel (wino_fused.hip) once there are enough
     // workgroups to fill the chip (one per 8x8 pooled pixels); DT_WINO_FUSED=0 keeps the direct form
     if (L.fused && epi == EPI_POOL && in_ld == 32 && out_ld == 64 && !((H | W) & 1)) {
-        const char *fe = getenv("DT_WINO_FUSED");      // 0: never, 2: at any size (parity tests); read per call
-        const int fmode = fe ? atoi(fe) : 1;
+        const int fmode = ctx->pol.fused;      // 0: never, 2: at any size (parity tests)
         if (fmode == 2 || (fmode == 1 && (long long)B * ((H / 2 + 7) / 8) * ((W / 2 + 7) / 8) >= 512)) {
             WinoFusedArgs f;
             f.in = in; f.B = B; f.H = H; f.W = W; f.u = L.fused; f.bias = L.bias; f.slope = slope; f.out = out;
@@ -559,7 +590,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
             return DT_OK;
         }
     }
-    if (wino_runs(L.wino, L.wino_ts, B, H, W, L.cin, L.cout) && ((epi == EPI_PLAIN && order == ORD_LINEAR) || epi == EPI_POOL || epi == EPI_POOL_BOTH)) {
+    if (wino_runs(ctx, L.wino, L.wino_ts, B, H, W, L.cin, L.cout) && ((epi == EPI_PLAIN && order == ORD_LINEAR) || epi == EPI_POOL || epi == EPI_POOL_BOTH)) {
         WinoIO io;
         memset(&io, 0, sizeof(io));
         io.in = in; io.in_ld = in_ld; io.in_bs = a.in_bs;
@@ -589,8 +620,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
                 if (t < best - 1e-9) { best = t; ksplit = sp; }
             }
         }
-        static const int ks_env = [] { const char *e = getenv("DT_KSPLIT"); return e ? atoi(e) : 0; }();
-        if (ks_env > 0) ksplit = ks_env < nk ? ks_env : nk;
+        if (ctx->pol.ksplit > 0) ksplit = ctx->pol.ksplit < nk ? ctx->pol.ksplit : nk;
         if (ksplit > 1) cfg = CFG_128x128;   // the split-K path is built for the 128x128 tile
     }
     if (ksplit > 1) {
@@ -600,7 +630,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
         b.out = slab; b.out_ld = L.cout; b.ksplit = ksplit; b.bias = nullptr;
         {
             ProfScope ps(ctx, "conv_igemm", flops, bytes + 4.0 * ksplit * a.M * (double)L.cout, tag);
-            const int rc = launch_conv_igemm(ctx->stream, b, L.ks, ORD_LINEAR, EPI_PARTIAL, CFG_128x128);
+            const int rc = launch_igemm(ctx, b, L.ks, ORD_LINEAR, EPI_PARTIAL, CFG_128x128);
             if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "conv_%d split-K launch failed (rc=%d)", L.idx, rc);
         }
         ProfScope ps2(ctx, "splitk_reduce", 0.0, 4.0 * (ksplit + 1.0) * a.M * (double)L.cout, tag);
@@ -609,8 +639,80 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
         return DT_OK;
     }
     ProfScope ps(ctx, "conv_igemm", flops, bytes, tag);
-    const int rc = launch_conv_igemm(ctx->stream, a, L.ks, order, epi, cfg);
+    const int rc = launch_igemm(ctx, a, L.ks, order, epi, cfg);
     if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "conv_%d launch failed (rc=%d)", L.idx, rc);
+    return DT_OK;
+}
+
+// What dt_detector_extract wants out of the graph: the output of layer `idx` in one of the forms the reference's
+// layer names denote (KerasYOLO.py:279-400): conv_N = the Conv2D output, norm_N = BatchNormalization output,
+// leaky_re_lu_N / conv_feat = after LeakyReLU, max_pooling2d_k = after the pool; lambda_1 = space_to_depth(conv_21
+// block), concatenate_1 = [skip, main].
+enum { EX_CONV = 0, EX_NORM = 1, EX_ACT = 2, EX_POOL = 3, EX_S2D = 4, EX_CAT = 5 };
+struct Extract {
+    int idx, kind;
+    float *out;      // dense [B][h][w][C]
+    bool done = false;
+};
+
+// layer `L` on its own, un-fused, into ex.out: pre-activation (slope 1) for conv_N / norm_N, then the BatchNorm
+// un-folded for conv_N
+static int extract_layer(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld, int B, int h, int w, Extract &ex)
+{
+    if (ex.kind == EX_CONV && L.scale && L.scale_has_zero)
+        return dt_fail(ctx, DT_ERR_ARG, "conv_%d: a BatchNorm gamma of 0 was folded into the kernel; the raw Conv2D output cannot be recovered", L.idx);
+    int rc = run_conv(ctx, L, in, in_ld, B, h, w, ex.out, L.cout, ORD_LINEAR, EPI_PLAIN, ex.kind == EX_ACT ? LEAKY : 1.0f);
+    if (rc) return rc;
+    if (ex.kind == EX_CONV && L.scale && launch_unfold_bn(ctx->stream, ex.out, (long long)B * h * w, L.cout, L.scale, L.bias))
+        return dt_fail(ctx, DT_ERR_DEVICE, "BatchNorm un-fold launch failed");
+    ex.done = true;
+    return DT_OK;
+}
+
+// conv_2 .. conv_21 on the library-owned buffers (bufA holds conv_1's pooled output).  With `ex` the walk stops at
+// the requested layer and writes it to ex->out instead.
+static int run_trunk(dt_ctx *ctx, int B, float *bufA, float *bufB, float *skip, float *cat, Extract *ex)
+{
+    const int H = ctx->image_h, W = ctx->image_w;
+    float *cur = bufA, *nxt = bufB;
+    int h = H / 2, w = W / 2;
+    int rc;
+    for (int li = 1; li < 20; ++li) {   // conv_2 .. conv_20
+        const int idx = TRUNK[li][0], pool = TRUNK[li][4];
+        const ConvLayer &L = ctx->layers[idx];
+        if (ex && ex->idx == idx && ex->kind <= EX_ACT) return extract_layer(ctx, L, cur, L.cin, B, h, w, *ex);
+        if (idx == 13) {   // skip tapped before the pool (KerasYOLO.py:347)
+            rc = run_conv(ctx, L, cur, L.cin, B, h, w, skip, 512, ORD_QUAD, EPI_POOL_BOTH, LEAKY, nxt, 512);
+        } else if (idx == 20) {   // writes channels [256,1280) of the concat buffer (KerasYOLO.py:391)
+            rc = run_conv(ctx, L, cur, L.cin, B, h, w, cat + 256, 1280, ORD_LINEAR, EPI_PLAIN, LEAKY);
+        } else if (pool) {
+            rc = run_conv(ctx, L, cur, L.cin, B, h, w, nxt, L.cout, ORD_QUAD, EPI_POOL, LEAKY);
+        } else {
+            rc = run_conv(ctx, L, cur, L.cin, B, h, w, nxt, L.cout, ORD_LINEAR, EPI_PLAIN, LEAKY);
+        }
+        if (rc) return rc;
+        if (pool) { h /= 2; w /= 2; }
+        if (ex && ex->idx == idx && ex->kind == EX_POOL) {
+            HIP_TRY(ctx, hipMemcpyAsync(ex->out, nxt, (size_t)B * h * w * L.cout * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+            ex->done = true;
+            return DT_OK;
+        }
+        if (ex && ex->idx == 21 && idx == 13 && ex->kind != EX_CAT) break;   // conv_21's block only needs the skip tensor
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    if (ex && ex->idx == 21 && ex->kind <= EX_ACT)
+        return extract_layer(ctx, ctx->layers[21], skip, 512, B, H / 16, W / 16, *ex);
+    if (ex && ex->idx == 21 && ex->kind == EX_S2D) {
+        ex->done = true;
+        return run_conv(ctx, ctx->layers[21], skip, 512, B, H / 16, W / 16, ex->out, 256, ORD_QUAD, EPI_S2D, LEAKY);
+    }
+    // conv_21 on the skip tensor + tf.space_to_depth(2) -> channels [0,256) (KerasYOLO.py:386-391)
+    rc = run_conv(ctx, ctx->layers[21], skip, 512, B, H / 16, W / 16, cat, 1280, ORD_QUAD, EPI_S2D, LEAKY);
+    if (rc) return rc;
+    if (ex && ex->kind == EX_CAT) {
+        HIP_TRY(ctx, hipMemcpyAsync(ex->out, cat, (size_t)B * (H / 32) * (W / 32) * 1280 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        ex->done = true;
+    }
     return DT_OK;
 }
 
@@ -629,6 +731,14 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
     float *cat = ws_get(ctx, "cat", (size_t)B * (H / 32) * (W / 32) * 1280 * sizeof(float));
     if (!bufA || !bufB || !skip || !cat) return DT_ERR_DEVICE;
     ctx->last_batch = B;
+    {   // dt_detector_tap may only hand out 'feat' / 'netout' if THIS forward wrote the library-owned workspaces
+        auto owned = [&](const char *name, const float *p) {
+            auto it = ctx->ws.find(name);
+            return it != ctx->ws.end() && it->second.p == static_cast<const void *>(p);
+        };
+        ctx->tap_feat = owned("feat", feat.p) && feat.ld == 1024;
+        ctx->tap_netout = owned("netout", netout.p) && netout.ld == ctx->cb;
+    }
 
     {   // conv_1 + norm_1 + leaky + pool, with x/255 fused
         ProfScope ps(ctx, "conv1_direct", 2.0 * B * H * W * 27.0 * 32.0,
@@ -637,29 +747,9 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
                                 bufA))
             return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");
     }
-    int h = H / 32, w = W / 32;
+    const int h = H / 32, w = W / 32;
     int rc = graphed(ctx, "trunk:" + std::to_string(B), [&]() -> int {   // conv_2 .. conv_21: library-owned buffers only
-    float *cur = bufA, *nxt = bufB;
-    int h = H / 2, w = W / 2;
-    int rc;
-    for (int li = 1; li < 20; ++li) {   // conv_2 .. conv_20
-        const int idx = TRUNK[li][0], pool = TRUNK[li][4];
-        const ConvLayer &L = ctx->layers[idx];
-        if (idx == 13) {   // skip tapped before the pool (KerasYOLO.py:347)
-            rc = run_conv(ctx, L, cur, L.cin, B, h, w, skip, 512, ORD_QUAD, EPI_POOL_BOTH, LEAKY, nxt, 512);
-        } else if (idx == 20) {   // writes channels [256,1280) of the concat buffer (KerasYOLO.py:391)
-            rc = run_conv(ctx, L, cur, L.cin, B, h, w, cat + 256, 1280, ORD_LINEAR, EPI_PLAIN, LEAKY);
-        } else if (pool) {
-            rc = run_conv(ctx, L, cur, L.cin, B, h, w, nxt, L.cout, ORD_QUAD, EPI_POOL, LEAKY);
-        } else {
-            rc = run_conv(ctx, L, cur, L.cin, B, h, w, nxt, L.cout, ORD_LINEAR, EPI_PLAIN, LEAKY);
-        }
-        if (rc) return rc;
-        if (pool) { h /= 2; w /= 2; }
-        float *t = cur; cur = nxt; nxt = t;
-    }
-    // conv_21 on the skip tensor + tf.space_to_depth(2) -> channels [0,256) (KerasYOLO.py:386-391)
-    return run_conv(ctx, ctx->layers[21], skip, 512, B, 2 * h, 2 * w, cat, 1280, ORD_QUAD, EPI_S2D, LEAKY);
+        return run_trunk(ctx, B, bufA, bufB, skip, cat, nullptr);
     });
     if (rc) return rc;
     // conv_22 -> 'conv_feat'
@@ -699,10 +789,107 @@ extern "C" int dt_detector_tap(dt_ctx *ctx, const char *name, int batch, float *
     else if (!strcmp(name, "conv_23")) { wsname = "netout"; n = (size_t)batch * (H / 32) * (W / 32) * ctx->cb; }
     else return dt_fail(ctx, DT_ERR_ARG, "unknown tap '%s'", name);
     auto it = ctx->ws.find(wsname);
-    if (it == ctx->ws.end() || it->second.bytes < n * sizeof(float))
-        return dt_fail(ctx, DT_ERR_STATE, "tap '%s' not materialised by the last forward (caller-owned output?)", name);
+    const bool stale = (!strcmp(wsname, "feat") && !ctx->tap_feat) || (!strcmp(wsname, "netout") && !ctx->tap_netout);
+    if (it == ctx->ws.end() || it->second.bytes < n * sizeof(float) || stale)
+        return dt_fail(ctx, DT_ERR_STATE, "tap '%s' not materialised by the last forward (it wrote caller-owned outputs; "
+                       "call dt_detect_forward with d_netout = d_feat = NULL first)", name);
     HIP_TRY(ctx, hipMemcpyAsync(d_out, it->second.p, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     return DT_OK;
+}
+
+// layer name -> (layer index, form, output geometry).  Names are the reference's (KerasYOLO.py:279-400) plus the
+// names Keras gives its unnamed layers in a fresh session (leaky_re_lu_N, max_pooling2d_k, lambda_1, concatenate_1).
+static bool parse_layer_name(const dt_ctx *ctx, const char *name, int *idx, int *kind, int *oh, int *ow, int *oc)
+{
+    const int H = ctx->image_h, W = ctx->image_w;
+    int n = 0;
+    char tail = 0;
+    auto geom = [&](int layer, bool pooled) {   // output geometry of conv block `layer` (1..23), before / after its pool
+        int div = 1, c = 0;
+        for (auto &t : TRUNK) {
+            if (t[0] == layer) { c = t[3]; if (pooled) div *= 2; break; }
+            if (t[4]) div *= 2;
+            if (t[0] == 20) break;
+        }
+        if (layer == 21) { div = 16; c = 64; }
+        if (layer == 22) { div = 32; c = 1024; }
+        if (layer == 23) { div = 32; c = ctx->cb; }
+        *oh = H / div; *ow = W / div; *oc = c;
+    };
+    if (sscanf(name, "conv_%d%c", &n, &tail) == 1 && n >= 1 && n <= 23) { *idx = n; *kind = EX_CONV; geom(n, false); return true; }
+    if (sscanf(name, "norm_%d%c", &n, &tail) == 1 && n >= 1 && n <= 22) { *idx = n; *kind = EX_NORM; geom(n, false); return true; }
+    if ((sscanf(name, "leaky_re_lu_%d%c", &n, &tail) == 1 || sscanf(name, "act_%d%c", &n, &tail) == 1) && n >= 1 && n <= 22) {
+        *idx = n; *kind = EX_ACT; geom(n, false); return true;
+    }
+    if (!strcmp(name, "conv_feat")) { *idx = 22; *kind = EX_ACT; geom(22, false); return true; }
+    if (sscanf(name, "max_pooling2d_%d%c", &n, &tail) == 1 && n >= 1 && n <= 5) {
+        static const int pooled_after[5] = {1, 2, 5, 8, 13};
+        *idx = pooled_after[n - 1]; *kind = EX_POOL; geom(*idx, true); return true;
+    }
+    if (!strcmp(name, "lambda_1")) { *idx = 21; *kind = EX_S2D; *oh = H / 32; *ow = W / 32; *oc = 256; return true; }
+    if (!strcmp(name, "concatenate_1")) { *idx = 21; *kind = EX_CAT; *oh = H / 32; *ow = W / 32; *oc = 1280; return true; }
+    if (!strcmp(name, "reshape_1") || !strcmp(name, "lambda_2")) { *idx = 23; *kind = EX_CONV; geom(23, false); return true; }
+    return false;
+}
+
+extern "C" int dt_detector_extract(dt_ctx *ctx, const void *d_frames, int frames_dtype, int batch, const char *layer,
+                                   float *d_out, size_t out_floats, int *shape4)
+{
+    if (!ctx || !layer) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (!ctx->cb) return dt_fail(ctx, DT_ERR_STATE, "dt_detector_config must be called first");
+    int idx = 0, kind = 0, oh = 0, ow = 0, oc = 0;
+    if (!parse_layer_name(ctx, layer, &idx, &kind, &oh, &ow, &oc)) return dt_fail(ctx, DT_ERR_ARG, "No such layer: %s", layer);
+    if (shape4) { shape4[0] = batch; shape4[1] = oh; shape4[2] = ow; shape4[3] = oc; }
+    if (!d_out) return DT_OK;   // shape query
+    if (!d_frames || batch <= 0) return dt_fail(ctx, DT_ERR_ARG, "bad frames / batch");
+    if (!ctx->det_loaded) return dt_fail(ctx, DT_ERR_STATE, "detector weights not loaded");
+    if (frames_dtype != DT_FRAMES_U8 && frames_dtype != DT_FRAMES_F32) return dt_fail(ctx, DT_ERR_ARG, "bad frames dtype");
+    const size_t need = (size_t)batch * oh * ow * oc;
+    if (out_floats < need) return dt_fail(ctx, DT_ERR_ARG, "output buffer holds %zu floats, layer %s needs %zu", out_floats, layer, need);
+    const int B = batch, H = ctx->image_h, W = ctx->image_w;
+    Extract ex{idx, kind, d_out};
+    if (idx == 1 && kind <= EX_ACT) {   // conv_1 un-pooled: as a Cin = 32 layer of the MFMA kernel on zero-padded channels
+        float *x32 = ws_get(ctx, "extract_x32", (size_t)B * H * W * 32 * sizeof(float));
+        if (!x32) return DT_ERR_DEVICE;
+        if (launch_expand_rgb32(ctx->stream, d_frames, frames_dtype, (long long)B * H * W, ctx->lut255, x32))
+            return dt_fail(ctx, DT_ERR_DEVICE, "channel expansion launch failed");
+        int rc = load_conv_layer(ctx, 0, 3, 32, 32, ctx->conv1_hwio32.data(), ctx->conv1_scale.data(), ctx->conv1_shift.data());
+        if (rc) return rc;
+        ctx->layers[0].idx = 1;
+        return extract_layer(ctx, ctx->layers[0], x32, 32, B, H, W, ex);
+    }
+    if (idx <= 21 || kind == EX_CAT) {
+        const size_t per_frame = (size_t)(H / 2) * (W / 2) * 32;
+        float *bufA = ws_get(ctx, "actA", per_frame * B * sizeof(float));
+        float *bufB = ws_get(ctx, "actB", per_frame * B * sizeof(float));
+        float *skip = ws_get(ctx, "skip", (size_t)B * (H / 16) * (W / 16) * 512 * sizeof(float));
+        float *cat = ws_get(ctx, "cat", (size_t)B * (H / 32) * (W / 32) * 1280 * sizeof(float));
+        if (!bufA || !bufB || !skip || !cat) return DT_ERR_DEVICE;
+        ctx->last_batch = 0;            // the tap workspaces no longer hold a complete forward
+        ctx->tap_feat = ctx->tap_netout = false;
+        if (launch_conv1_direct(ctx->stream, d_frames, frames_dtype, B, H, W, ctx->conv1_w, ctx->conv1_b, ctx->lut255, LEAKY, bufA))
+            return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");
+        if (idx == 1) {   // max_pooling2d_1
+            HIP_TRY(ctx, hipMemcpyAsync(d_out, bufA, need * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+            return DT_OK;
+        }
+        int rc = run_trunk(ctx, B, bufA, bufB, skip, cat, &ex);
+        if (rc) return rc;
+        return ex.done ? DT_OK : dt_fail(ctx, DT_ERR_ARG, "layer %s was not reached", layer);
+    }
+    // conv_22 / conv_23 blocks: a whole forward into the library-owned buffers, then the last layer(s) un-fused
+    const int G2 = (H / 32) * (W / 32);
+    float *feat = ws_get(ctx, "feat", (size_t)B * G2 * 1024 * sizeof(float));
+    float *net = ws_get(ctx, "netout", (size_t)B * G2 * ctx->cb * sizeof(float));
+    if (!feat || !net) return DT_ERR_DEVICE;
+    int rc = detect_internal(ctx, d_frames, frames_dtype, B, Dest{feat, 1024}, Dest{net, ctx->cb});
+    if (rc) return rc;
+    if (idx == 23) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_out, net, need * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        return DT_OK;
+    }
+    float *cat = static_cast<float *>(ctx->ws["cat"].p);
+    return extract_layer(ctx, ctx->layers[22], cat, 1280, B, H / 32, W / 32, ex);
 }
 
 // ---------------------------------------------------------------------------
@@ -734,15 +921,20 @@ extern "C" int dt_ingest_resize(dt_ctx *ctx, const uint8_t *d_src, int n, int sr
 // ---------------------------------------------------------------------------
 // decode / iou / associate
 // ---------------------------------------------------------------------------
-extern "C" int dt_decode(dt_ctx *ctx, const float *d_netout, int batch, int GH, int GW, int NB, int NC,
-                         float obj_threshold, float nms_threshold, const float *h_anchors, int cap, float *d_boxes,
-                         int *d_counts, float *d_classes, float *d_post)
+static int decode_common(dt_ctx *ctx, const float *d_netout, int batch, int GH, int GW, int NB, int NC,
+                         float obj_threshold, float nms_threshold, const float *d_frame_thr, const float *h_anchors,
+                         int cap, float *d_boxes, int *d_counts, float *d_classes, float *d_post)
 {
     if (!ctx || !d_netout || !d_boxes || !d_counts || !h_anchors) return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (batch <= 0 || cap <= 0 || NB <= 0 || NB > 32 || NC <= 0) return dt_fail(ctx, DT_ERR_ARG, "bad decode shape");
     float *anch = ws_get(ctx, "dec_anchors", 64 * sizeof(float));
     if (!anch) return DT_ERR_DEVICE;
-    HIP_TRY(ctx, hipMemcpyAsync(anch, h_anchors, sizeof(float) * 2 * NB, hipMemcpyHostToDevice, ctx->stream));
+    // the caller's host buffer may be a temporary: stage it in the context before the (stream-ordered) upload
+    if (memcmp(ctx->dec_anchors_host, h_anchors, sizeof(float) * 2 * NB) != 0 || ctx->dec_anchors_n != 2 * NB) {
+        memcpy(ctx->dec_anchors_host, h_anchors, sizeof(float) * 2 * NB);
+        ctx->dec_anchors_n = 2 * NB;
+        HIP_TRY(ctx, hipMemcpyAsync(anch, ctx->dec_anchors_host, sizeof(float) * 2 * NB, hipMemcpyHostToDevice, ctx->stream));
+    }
     const size_t fsz = (size_t)GH * GW * NB * (5 + NC);
     float *post = d_post;
     if (!post) {
@@ -751,12 +943,29 @@ extern "C" int dt_decode(dt_ctx *ctx, const float *d_netout, int batch, int GH, 
     }
     ProfScope ps(ctx, "decode_nms", 0.0, 4.0 * 3.0 * batch * (double)fsz);
     const int rc = launch_decode(ctx->stream, d_netout, (long long)fsz, batch, GH, GW, NB, NC, obj_threshold,
-                                 nms_threshold, anch, cap, d_boxes, d_counts, d_classes, post, nullptr);
+                                 nms_threshold, anch, cap, d_boxes, d_counts, d_classes, post, d_frame_thr);
     if (rc == 2)
         return dt_fail(ctx, DT_ERR_ARG, "decode: grid %dx%dx%d / %d classes exceeds the LDS-resident limits", GH, GW,
                        NB, NC);
     if (rc) return dt_fail(ctx, DT_ERR_DEVICE, "decode launch failed");
     return DT_OK;
+}
+
+extern "C" int dt_decode(dt_ctx *ctx, const float *d_netout, int batch, int GH, int GW, int NB, int NC,
+                         float obj_threshold, float nms_threshold, const float *h_anchors, int cap, float *d_boxes,
+                         int *d_counts, float *d_classes, float *d_post)
+{
+    return decode_common(ctx, d_netout, batch, GH, GW, NB, NC, obj_threshold, nms_threshold, nullptr, h_anchors, cap,
+                         d_boxes, d_counts, d_classes, d_post);
+}
+
+extern "C" int dt_decode_per_frame(dt_ctx *ctx, const float *d_netout, int batch, int GH, int GW, int NB, int NC,
+                                   const float *d_thresholds, const float *h_anchors, int cap, float *d_boxes,
+                                   int *d_counts, float *d_classes, float *d_post)
+{
+    if (!d_thresholds) return dt_fail(ctx, DT_ERR_ARG, "null thresholds");
+    return decode_common(ctx, d_netout, batch, GH, GW, NB, NC, 0.0f, 0.0f, d_thresholds, h_anchors, cap, d_boxes,
+                         d_counts, d_classes, d_post);
 }
 
 extern "C" int dt_bbox_iou(dt_ctx *ctx, const float *d_pairs, int n, float *d_iou)
@@ -818,13 +1027,13 @@ extern "C" int dt_tracker_load(dt_ctx *ctx, int units, const float *h_kernel, co
     if ((rc = upload(ctx, &ctx->trk_bo, bo))) return rc;
     for (float **w : {&ctx->trk_wx_wino, &ctx->trk_wh_wino})
         if (*w) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(*w); *w = nullptr; }
-    ctx->trk_wino_ts = wino_tile(false);
-    ctx->trk_wh_ts = wino_tile(true);
-    if (wino_wanted(3, Cx, 4 * U) &&
+    ctx->trk_wino_ts = wino_tile(ctx, false);
+    ctx->trk_wh_ts = wino_tile(ctx, true);
+    if (wino_wanted(ctx, 3, Cx, 4 * U) &&
         (rc = upload_wino(ctx, &ctx->trk_wx_wino, ctx->trk_wino_ts, h_kernel, Csrc, 4 * U, cin_map.data(), Cx, n_map.data(),
                           4 * U, nullptr)))
         return rc;
-    if (wino_wanted(3, U, 4 * U) &&
+    if (wino_wanted(ctx, 3, U, 4 * U) &&
         (rc = upload_wino(ctx, &ctx->trk_wh_wino, ctx->trk_wh_ts, h_recurrent, U, 4 * U, nullptr, U, n_map.data(), 4 * U,
                           nullptr)))
         return rc;
@@ -845,7 +1054,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
     if (!xproj || !cst) return DT_ERR_DEVICE;
     // z, hseq, xproj and the cell state are library-owned: the whole recurrence (3 launches per step) replays as a graph
     return graphed(ctx, "clstm:" + std::to_string(n_clips) + "x" + std::to_string(T), [&]() -> int {
-    if (wino_runs(wx_wino, ctx->trk_wino_ts, F, gh, gw, Cx, N4)) {
+    if (wino_runs(ctx, wx_wino, ctx->trk_wino_ts, F, gh, gw, Cx, N4)) {
         WinoIO io;
         memset(&io, 0, sizeof(io));
         io.in = z; io.in_ld = Cx; io.in_bs = (long long)GG * Cx;
@@ -864,7 +1073,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
                      4.0 * ((double)a.M * Cx + (double)a.K * N4 + (double)a.M * N4), "convlstm_xproj");
         a.npad = N4;
         prof_direct_form(ctx, 2.0 * a.M * 9.0 * (ctx->cb + 1024) * N4);
-        if (launch_conv_igemm(ctx->stream, a, 3, ORD_LINEAR, EPI_PLAIN, pick_cfg(a.M, N4, 3)))
+        if (launch_igemm(ctx, a, 3, ORD_LINEAR, EPI_PLAIN, pick_cfg(a.M, N4, 3)))
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM input projection launch failed");
     }
     const long long xp_bs = (long long)T * GG * N4, h_bs = (long long)T * GG * U, c_bs = (long long)GG * U;
@@ -874,7 +1083,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM t=0 launch failed");
     }
     for (int t = 1; t < T; ++t) {
-        if (wino_runs(wh_wino, ctx->trk_wh_ts, n_clips, gh, gw, U, N4)) {
+        if (wino_runs(ctx, wh_wino, ctx->trk_wh_ts, n_clips, gh, gw, U, N4)) {
             WinoIO io;
             memset(&io, 0, sizeof(io));
             io.in = hseq + (long long)(t - 1) * GG * U; io.in_ld = U; io.in_bs = h_bs;
@@ -898,7 +1107,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
                      4.0 * ((double)a.M * U + (double)a.K * N4 + (double)a.M * N4 + 3.0 * a.M * U), "convlstm_step");
         a.npad = N4;
         prof_direct_form(ctx, 2.0 * a.M * (double)a.K * N4);
-        if (launch_conv_igemm(ctx->stream, a, 3, ORD_LINEAR, EPI_GATES, pick_cfg(a.M, N4, 3)))
+        if (launch_igemm(ctx, a, 3, ORD_LINEAR, EPI_GATES, pick_cfg(a.M, N4, 3)))
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM step launch failed");
     }
     return DT_OK;
@@ -1030,7 +1239,7 @@ extern "C" int dt_tiny_sequence(dt_ctx *ctx, const float *d_x, int n_seq, int T,
         a.slope = 1.0f;
         ProfScope ps(ctx, "conv_igemm", 2.0 * R * (double)D * N4, 4.0 * ((double)R * Dp + (double)Dp * N4 + (double)R * N4),
                      "lstm_xproj");
-        if (launch_conv_igemm(ctx->stream, a, 1, ORD_LINEAR, EPI_PLAIN, CFG_128x128))
+        if (launch_igemm(ctx, a, 1, ORD_LINEAR, EPI_PLAIN, CFG_128x128))
             return dt_fail(ctx, DT_ERR_DEVICE, "LSTM input projection launch failed");
     }
     const long long xp_bs = (long long)T * N4, h_bs = (long long)T * U;
@@ -1061,7 +1270,7 @@ extern "C" int dt_tiny_sequence(dt_ctx *ctx, const float *d_x, int n_seq, int T,
         a.B = R; a.H = 1; a.W = 1; a.Cin = U; a.N = O; a.M = R; a.K = U;
         a.slope = 1.0f; a.act = 1;
         ProfScope ps(ctx, "conv_igemm", 2.0 * R * (double)U * O, 4.0 * ((double)R * U + (double)U * O + (double)R * O), "dense_head");
-        if (launch_conv_igemm(ctx->stream, a, 1, ORD_LINEAR, EPI_PLAIN, CFG_128x128))
+        if (launch_igemm(ctx, a, 1, ORD_LINEAR, EPI_PLAIN, CFG_128x128))
             return dt_fail(ctx, DT_ERR_DEVICE, "Dense head launch failed");
     }
     return DT_OK;
@@ -1143,6 +1352,7 @@ extern "C" int dt_conv2d(dt_ctx *ctx, const float *d_in, int B, int H, int W, in
     if (Cin % 32) return dt_fail(ctx, DT_ERR_ARG, "Cin must be a multiple of 32");
     if (k != 1 && k != 3) return dt_fail(ctx, DT_ERR_ARG, "kernel size must be 1 or 3");
     if (pool && ((H | W) & 1)) return dt_fail(ctx, DT_ERR_ARG, "pooling needs even H and W");
+    policy_from_env(ctx->pol);   // test entry point: the parity tests force policies on a live context through the environment
     std::vector<float> zero(Cout, 0.0f);
     int rc = load_conv_layer(ctx, 0, k, Cin, Cout, h_kernel, nullptr, h_bias ? h_bias : zero.data());
     if (rc) return rc;
@@ -1160,6 +1370,21 @@ extern "C" int dt_conv2d(dt_ctx *ctx, const float *d_in, int B, int H, int W, in
     }
 }
 
+namespace {
+struct DevTemps {   // device temporaries of a test entry point: freed on every return path
+    std::vector<float *> p;
+    hipStream_t st;
+    explicit DevTemps(hipStream_t s) : st(s) {}
+    ~DevTemps()
+    {
+        (void)hipStreamSynchronize(st);
+        for (float *q : p)
+            if (q) (void)hipFree(q);
+    }
+    float **add() { p.push_back(nullptr); return &p.back(); }
+};
+}   // namespace
+
 extern "C" int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int W, int Cx, const float *d_h,
                                 const float *d_c, int U, const float *h_kernel, const float *h_recurrent,
                                 const float *h_bias, float *d_h_out, float *d_c_out)
@@ -1167,6 +1392,7 @@ extern "C" int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int
     if (!ctx || !d_x || !d_h || !d_c || !h_kernel || !h_recurrent || !h_bias || !d_h_out || !d_c_out)
         return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (Cx % 32 || U % 32) return dt_fail(ctx, DT_ERR_ARG, "Cx and U must be multiples of 32");
+    policy_from_env(ctx->pol);   // test entry point (see dt_conv2d)
     const int N4 = 4 * U, GG = H * W;
     std::vector<int> n_map;
     gate_interleave_map(U, n_map);
@@ -1174,53 +1400,59 @@ extern "C" int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int
     pack_conv_weights(h_kernel, 3, Cx, N4, nullptr, Cx, n_map.data(), N4, nullptr, wx.data());
     pack_conv_weights(h_recurrent, 3, U, N4, nullptr, U, n_map.data(), N4, nullptr, wh.data());
     for (int np = 0; np < N4; ++np) bx[np] = h_bias[n_map[np]];
-    float *dwx = nullptr, *dwh = nullptr, *dbx = nullptr;
+    DevTemps tmp(ctx->stream);
+    tmp.p.reserve(8);
+    float **dwx = tmp.add(), **dwh = tmp.add(), **dbx = tmp.add();
     int rc;
-    if ((rc = upload(ctx, &dwx, wx)) || (rc = upload(ctx, &dwh, wh)) || (rc = upload(ctx, &dbx, bx))) return rc;
+    if ((rc = upload(ctx, dwx, wx)) || (rc = upload(ctx, dwh, wh)) || (rc = upload(ctx, dbx, bx))) return rc;
     float *xproj = ws_get(ctx, "cl_xproj", (size_t)B * GG * N4 * sizeof(float));
     if (!xproj) return DT_ERR_DEVICE;
-    if (wino_mode() == 2 && wino_wanted(3, Cx, N4) && wino_wanted(3, U, N4)) {   // the same step through the Winograd path
-        float *uwx = nullptr, *uwh = nullptr;
-        const int ts = wino_tile(false);
-        if ((rc = upload_wino(ctx, &uwx, ts, h_kernel, Cx, N4, nullptr, Cx, n_map.data(), N4, nullptr)) ||
-            (rc = upload_wino(ctx, &uwh, ts, h_recurrent, U, N4, nullptr, U, n_map.data(), N4, nullptr)))
+    if (ctx->pol.wino == 2 && wino_wanted(ctx, 3, Cx, N4) && wino_wanted(ctx, 3, U, N4)) {   // the same step through the Winograd path
+        float **uwx = tmp.add(), **uwh = tmp.add();
+        const int ts = wino_tile(ctx, false);
+        if ((rc = upload_wino(ctx, uwx, ts, h_kernel, Cx, N4, nullptr, Cx, n_map.data(), N4, nullptr)) ||
+            (rc = upload_wino(ctx, uwh, ts, h_recurrent, U, N4, nullptr, U, n_map.data(), N4, nullptr)))
             return rc;
         WinoIO io;
         memset(&io, 0, sizeof(io));
         io.in = d_x; io.in_ld = Cx; io.in_bs = (long long)GG * Cx;
         io.out = xproj; io.out_ld = N4; io.out_bs = (long long)GG * N4;
-        if ((rc = run_wino(ctx, uwx, ts, dbx, Cx, N4, N4, B, H, W, io, 1.0f, "convlstm_xproj"))) return rc;
+        if ((rc = run_wino(ctx, *uwx, ts, *dbx, Cx, N4, N4, B, H, W, io, 1.0f, "convlstm_xproj"))) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(d_c_out, d_c, (size_t)B * GG * U * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         memset(&io, 0, sizeof(io));
         io.in = d_h; io.in_ld = U; io.in_bs = (long long)GG * U;
         io.out = d_h_out; io.out_ld = U; io.out_bs = (long long)GG * U;
         io.xproj = xproj; io.xp_ld = N4; io.xp_bs = (long long)GG * N4;
         io.cstate = d_c_out; io.c_ld = U; io.c_bs = (long long)GG * U;
-        if ((rc = run_wino(ctx, uwh, ts, nullptr, U, N4, N4, B, H, W, io, 1.0f, "convlstm_step"))) return rc;
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(dwx); (void)hipFree(dwh); (void)hipFree(dbx); (void)hipFree(uwx); (void)hipFree(uwh);
-        return DT_OK;
+        return run_wino(ctx, *uwh, ts, nullptr, U, N4, N4, B, H, W, io, 1.0f, "convlstm_step");
     }
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.in = d_x; a.in_ld = Cx; a.in_bs = (long long)GG * Cx;
-    a.wt = dwx; a.bias = dbx;
+    a.wt = *dwx; a.bias = *dbx;
     a.out = xproj; a.out_ld = N4; a.out_bs = (long long)GG * N4;
     a.B = B; a.H = H; a.W = W; a.Cin = Cx; a.N = N4; a.M = B * GG; a.K = 9 * Cx; a.slope = 1.0f;
-    if (launch_conv_igemm(ctx->stream, a, 3, ORD_LINEAR, EPI_PLAIN, CFG_128x128))
+    if (launch_igemm(ctx, a, 3, ORD_LINEAR, EPI_PLAIN, CFG_128x128))
         return dt_fail(ctx, DT_ERR_DEVICE, "xproj launch failed");
     HIP_TRY(ctx, hipMemcpyAsync(d_c_out, d_c, (size_t)B * GG * U * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     memset(&a, 0, sizeof(a));
     a.in = d_h; a.in_ld = U; a.in_bs = (long long)GG * U;
-    a.wt = dwh;
+    a.wt = *dwh;
     a.out = d_h_out; a.out_ld = U; a.out_bs = (long long)GG * U;
     a.xproj = xproj; a.xp_ld = N4; a.xp_bs = (long long)GG * N4;
     a.cstate = d_c_out; a.c_ld = U; a.c_bs = (long long)GG * U;
     a.B = B; a.H = H; a.W = W; a.Cin = U; a.N = N4; a.M = B * GG; a.K = 9 * U; a.slope = 1.0f;
-    if (launch_conv_igemm(ctx->stream, a, 3, ORD_LINEAR, EPI_GATES, CFG_128x128))
+    if (launch_igemm(ctx, a, 3, ORD_LINEAR, EPI_GATES, CFG_128x128))
         return dt_fail(ctx, DT_ERR_DEVICE, "gates launch failed");
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(dwx); (void)hipFree(dwh); (void)hipFree(dbx);
+    return DT_OK;
+}
+
+// Re-reads the tuning / test knobs from the environment into the context (they are otherwise read once, in
+// dt_create).  Knobs that shape the uploaded weights (DT_WINO, DT_WINO_TILE) take effect at the next weight load.
+extern "C" int dt_policy_reload(dt_ctx *ctx)
+{
+    if (!ctx) return DT_ERR_ARG;
+    policy_from_env(ctx->pol);
     return DT_OK;
 }
 

@@ -25,7 +25,7 @@ SYMBOLS = [
     "dt_detector_config", "dt_load_darknet_weights", "dt_detect_forward", "dt_detector_tap", "dt_ingest_resize",
     "dt_decode", "dt_bbox_iou", "dt_tracker_load", "dt_track_forward", "dt_associate",
     "dt_tiny_load", "dt_tiny_forward", "dt_tiny_features", "dt_tiny_sequence", "dt_top_box", "dt_heatmap_from_boxes", "dt_heatmap_from_xywh64", "dt_rect_from_heatmap", "dt_encode_targets", "dt_graph_enable", "dt_conv2d", "dt_convlstm_step",
-    "dt_profile_enable", "dt_profile_reset", "dt_profile_read", "dt_profile_names",
+    "dt_profile_enable", "dt_profile_reset", "dt_profile_read", "dt_profile_names", "dt_policy_reload", "dt_detector_extract", "dt_decode_per_frame",
 ]
 
 _lib = None
@@ -57,9 +57,11 @@ def load_library():
     L.dt_load_darknet_weights.argtypes = [vp, vp, csz, ctypes.POINTER(csz)]
     L.dt_detect_forward.argtypes = [vp, vp, ci, ci, vp, vp]
     L.dt_detector_tap.argtypes = [vp, ctypes.c_char_p, ci, vp]
+    L.dt_detector_extract.argtypes = [vp, vp, ci, ci, ctypes.c_char_p, vp, csz, ctypes.POINTER(ci)]
     L.dt_ingest_resize.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci]
     L.dt_decode.argtypes = [vp, vp, ci, ci, ci, ci, ci, cf, cf, vp, ci, vp, vp, vp, vp]
     L.dt_bbox_iou.argtypes = [vp, vp, ci, vp]
+    L.dt_decode_per_frame.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp]
     L.dt_tracker_load.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     L.dt_track_forward.argtypes = [vp, vp, ci, ci, ci, vp, vp]
     L.dt_associate.argtypes = [vp, vp, vp, ci, ci, ci, cf, vp, vp]
@@ -77,6 +79,7 @@ def load_library():
     L.dt_profile_enable.argtypes = [vp, ci]
     L.dt_graph_enable.argtypes = [vp, ci]
     L.dt_profile_reset.argtypes = [vp]
+    L.dt_policy_reload.argtypes = [vp]
     L.dt_profile_names.argtypes = [vp, ctypes.c_char_p, csz]
     L.dt_profile_read.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64),
                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
@@ -193,6 +196,24 @@ class Context(object):
         self._check(self.lib.dt_detector_tap(self.h, name.encode(), batch, _dptr(out)), "dt_detector_tap")
         return out
 
+    def layer_shape(self, layer, batch=1):
+        """(batch, h, w, channels) of a named detector layer; raises NativeError for an unknown name."""
+        shape = (ctypes.c_int * 4)()
+        self._check(self.lib.dt_detector_extract(self.h, None, 0, batch, layer.encode(), None, 0, shape), "dt_detector_extract")
+        return tuple(int(v) for v in shape)
+
+    def detector_extract(self, frames, layer):
+        """frames [B,H,W,3] device tensor -> the named layer's output [B,h,w,C] (KerasYOLO.extract, any layer)."""
+        assert frames.is_cuda and frames.is_contiguous() and frames.dim() == 4
+        B = frames.shape[0]
+        shape = (ctypes.c_int * 4)()
+        self._check(self.lib.dt_detector_extract(self.h, None, 0, B, layer.encode(), None, 0, shape), "dt_detector_extract")
+        out = self._f32(*[int(v) for v in shape])
+        self._sync_stream()
+        self._check(self.lib.dt_detector_extract(self.h, _dptr(frames), self._frames_dtype(frames), B, layer.encode(),
+                                                 _dptr(out), out.numel(), shape), "dt_detector_extract")
+        return out
+
     # ---- frame ingest -------------------------------------------------
     def ingest_resize(self, frames, out_h, out_w):
         """frames uint8 [n,Hs,Ws,3] device tensor -> uint8 [n,out_h,out_w,3] (cv2.resize INTER_LINEAR)."""
@@ -209,7 +230,8 @@ class Context(object):
     def decode(self, netout, obj_threshold, nms_threshold, anchors, nb_class, cap=None,
                want_classes=False, want_post=False):
         """netout [B,GH,GW,NB,5+C] device float32 (not modified).  Returns dict of
-        device tensors: boxes [B,cap,8], counts [B] (+ classes, post)."""
+        device tensors: boxes [B,cap,8], counts [B] (+ classes, post).  obj_threshold / nms_threshold are
+        scalars, or arrays / tensors of one value per frame (dt_decode_per_frame)."""
         t = self.torch
         assert netout.is_cuda and netout.dtype == t.float32 and netout.is_contiguous() and netout.dim() == 5
         B, GH, GW, NB, S = netout.shape
@@ -222,9 +244,18 @@ class Context(object):
         post = t.empty_like(netout) if want_post else None
         keep, ap = _hptr(anchors)
         self._sync_stream()
-        self._check(self.lib.dt_decode(self.h, _dptr(netout), B, GH, GW, NB, nb_class, float(obj_threshold),
-                                       float(nms_threshold), ap, cap, _dptr(boxes), _dptr(counts),
-                                       _dptr(classes), _dptr(post)), "dt_decode")
+        if np.ndim(obj_threshold) or np.ndim(nms_threshold) or t.is_tensor(obj_threshold) or t.is_tensor(nms_threshold):
+            def per_frame(v):
+                v = v.detach().cpu().numpy() if t.is_tensor(v) else np.asarray(v)
+                return np.broadcast_to(v.astype(np.float32).reshape(-1), (B,))
+            thr = t.from_numpy(np.ascontiguousarray(np.stack([per_frame(obj_threshold), per_frame(nms_threshold)], 1))).to(self.device)
+            self._check(self.lib.dt_decode_per_frame(self.h, _dptr(netout), B, GH, GW, NB, nb_class, _dptr(thr), ap, cap,
+                                                     _dptr(boxes), _dptr(counts), _dptr(classes), _dptr(post)),
+                        "dt_decode_per_frame")
+        else:
+            self._check(self.lib.dt_decode(self.h, _dptr(netout), B, GH, GW, NB, nb_class, float(obj_threshold),
+                                           float(nms_threshold), ap, cap, _dptr(boxes), _dptr(counts),
+                                           _dptr(classes), _dptr(post)), "dt_decode")
         return dict(boxes=boxes, counts=counts, classes=classes, post=post)
 
     def bbox_iou(self, pairs):
@@ -405,6 +436,10 @@ class Context(object):
         buf = ctypes.create_string_buffer(1 << 16)
         self._check(self.lib.dt_profile_names(self.h, buf, len(buf)), "dt_profile_names")
         return [n for n in buf.value.decode().split("\n") if n]
+
+    def reload_policy(self):
+        """re-read the DT_* tuning / test knobs from the environment (they are read once, in dt_create)"""
+        self._check(self.lib.dt_policy_reload(self.h), "dt_policy_reload")
 
     def graph_enable(self, on=True):
         """hipGraph replay of the detector trunk and the ConvLSTM recurrence (low-latency serving)."""

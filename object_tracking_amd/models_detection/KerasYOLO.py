@@ -54,17 +54,28 @@ class NativeDetectorModel(object):
         return used
 
     def load_weights(self, weight_path):
-        """Keras `load_weights` analogue for this build's formats: a darknet
-        .weights file or an .npy holding the same float32 stream."""
+        """`model.load_weights(weight_path)` (KerasYOLO.py:409-410) for: a darknet .weights file (what load_model
+        reads, :404), an .npy holding the same float32 stream, or a Keras HDF5 file such as the reference's
+        'weights/WEIGHTS_KerasYOLO.h5' checkpoint (:480-486; layers conv_N / norm_N, read by utility/keras_h5.py)."""
         if weight_path.endswith(".npy"):
             blob = np.load(weight_path)
+        elif weight_path.endswith((".h5", ".hdf5")):
+            from utility import keras_h5
+            blob = keras_h5.darknet_blob_from_keras(keras_h5.read_keras_weights(weight_path))
+            if blob is None:
+                raise IOError("%r holds no detector layers (conv_1 ... conv_23)" % weight_path)
         else:
             blob = WeightReader(weight_path).all_weights
         return self.set_darknet_blob(blob)
 
     def get_layer(self, name):
+        """Any layer name of the reference graph (conv_N, norm_N, leaky_re_lu_N, conv_feat, max_pooling2d_k,
+        lambda_1, concatenate_1, ...): validated by the library (dt_detector_extract shape query)."""
         if name not in self.TAPS:
-            raise ValueError("No such layer: " + name)
+            try:
+                self.ctx.layer_shape(name, 1)
+            except mi355_dt.NativeError:
+                raise ValueError("No such layer: " + name)
         return _Tap(name)
 
     def to_device(self, frames):
@@ -181,13 +192,13 @@ class KerasYOLO(object):
         return image, resized.reshape((1, self.IMAGE_H, self.IMAGE_W, 3))
 
     def extract(self, input_path, layer):
-        """Intermediate layer output for one image (KerasYOLO.py:509-520):
-        'conv_23' (raw grid), 'conv_feat' (13x13x1024), 'act_13' (26x26x512)."""
+        """Output of ANY named layer for one image (KerasYOLO.py:509-520): conv_N / norm_N / leaky_re_lu_N
+        (alias act_N) / conv_feat / max_pooling2d_k / lambda_1 / concatenate_1 / reshape_1.  The production
+        path fuses BatchNorm, LeakyReLU and the pools into the convolutions, so the library re-runs the graph up
+        to the layer and executes that one un-fused (dt_detector_extract)."""
         _, frame = self._frame(input_path)
         self.model.get_layer(layer)
-        ctx = self.model.ctx
-        ctx.detect_forward_internal(self.model.to_device(frame))   # fills the context's tap workspaces
-        return self.extract_frames_tap(layer, 1)[0]
+        return self.model.ctx.detector_extract(self.model.to_device(frame), layer)[0].cpu().numpy()
 
     def extract_frames_tap(self, layer, batch):
         ctx = self.model.ctx

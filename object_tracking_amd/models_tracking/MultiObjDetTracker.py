@@ -49,21 +49,24 @@ class NativeTrackerModel(object):
         self.loaded = True
 
     def load_weights(self, path):
-        """.npz with arrays kernel/recurrent/bias/out_kernel/out_bias (+ optional
-        `darknet` float32 stream for the detector), or a Keras .hdf5 checkpoint
-        when h5py is importable (layer names tconv_lstm / timedist_tconv2)."""
+        """Keras-style load_weights (MultiObjDetTracker.py:291-293).  Accepts
+          * a Keras HDF5 checkpoint (.hdf5 / .h5: whole-model file as ModelCheckpoint writes it, :253-259, or a
+            weights-only file): layers 'tconv_lstm' and 'timedist_tconv2' (:176,182); if the file also carries the
+            detector (the TimeDistributed copies 'timedist_bbox'), its conv_N / norm_N weights replace the
+            detector's.  Read with utility/keras_h5.py (pure Python; h5py is used when importable);
+          * an .npz with arrays kernel / recurrent / bias / out_kernel / out_bias (+ optional `darknet` stream)."""
         if path.endswith(".npz"):
             d = np.load(path)
             if "darknet" in d:
                 self.owner.detector.model.set_darknet_blob(d["darknet"])
             self.set_weights({k: d[k] for k in ("kernel", "recurrent", "bias", "out_kernel", "out_bias")})
             return
-        try:
-            import h5py  # noqa: F401
-        except ImportError:
-            raise IOError("reading Keras HDF5 checkpoints needs h5py, which this image lacks; "
-                          "convert %r to .npz (kernel, recurrent, bias, out_kernel, out_bias)" % path)
-        raise IOError("HDF5 import path is not exercised in this image (no h5py, no checkpoint ships)")
+        from utility import keras_h5
+        layers = keras_h5.read_keras_weights(path)
+        blob = keras_h5.darknet_blob_from_keras(layers)
+        if blob is not None:
+            self.owner.detector.model.set_darknet_blob(blob)
+        self.set_weights(keras_h5.tracker_weights_from_keras(layers))
 
     def forward(self, frames, want_det=True):
         return self.ctx.track_forward(self.owner.detector.model.to_device(frames), want_det=want_det)

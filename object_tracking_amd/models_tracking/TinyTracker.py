@@ -91,7 +91,8 @@ class TinyTracker(BaseTracker):
         gh, gw = ctx.grid
         netout = ctx.detector_tap("conv_23", F).reshape(F, gh, gw, ctx.nb_box, 5 + ctx.nb_class)
         r = ctx.decode(netout, detector.OBJ_THRESHOLD, detector.NMS_THRESHOLD, detector.ANCHORS,
-                       len(detector.LABELS), cap=detector.MAX_BOX_PER_IMAGE)
+                       len(detector.LABELS))      # full cap: boxes come in (row, col, anchor) order, the
+        # best-scoring one may sit behind MAX_BOX_PER_IMAGE others
         det4 = ctx.top_box(r["boxes"], r["counts"])
         return ctx.tiny_features(feat, det4, self.feature_width() + self.det_width(), self.pool), det4
 

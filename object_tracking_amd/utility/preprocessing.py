@@ -115,7 +115,8 @@ def pack_objects(instances, labels, cap=None):
         if len(rec["object"]) > cap:
             raise ValueError("record %d has %d objects, cap is %d" % (i, len(rec["object"]), cap))
         counts[i] = len(rec["object"])
-        dims[i] = (rec["width"], rec["height"])
+        dims[i] = (rec.get("width", 0), rec.get("height", 0))     # absent in records without a <size> block: the
+        # generators then pass the decoded image's dims (what the reference always uses, preprocessing.py:144)
         for k, o in enumerate(rec["object"]):
             objs[i, k] = (o["xmin"], o["ymin"], o["xmax"], o["ymax"], index.get(o["name"], -1))
     return objs, counts, dims
@@ -154,7 +155,7 @@ class BatchGenerator(object):
         size = self.config["BATCH_SIZE"]
         hi = min((idx + 1) * size, len(self.images))
         lo = hi - size if (idx + 1) * size > len(self.images) else idx * size
-        return lo, hi
+        return max(lo, 0), hi      # fewer items than one batch: a short batch (the reference leaves the rest zero)
 
     def load_frames(self, instances):
         """cv2.imread -> cv2.resize -> [:,:,::-1] (preprocessing.py:143,168-169): uint8 RGB [n,H,W,3]
@@ -211,7 +212,7 @@ class BatchSequenceGenerator1(BatchGenerator):
         T = self.config["SEQUENCE_LENGTH"]
         flat = [rec for window in self.images[lo:hi] for rec in window]
         x, b, y = self.output_from_instances(flat)
-        n = hi - lo
+        n = len(self.images[lo:hi])
         x = x.reshape((n, T) + x.shape[1:])
         b = b.reshape((n, T) + b.shape[1:])
         y = y.reshape((n, T) + y.shape[1:])

@@ -104,7 +104,7 @@ def decode_netout_batch(netouts, obj_threshold, nms_threshold, anchors, nb_class
     where rows[b] is the raw [n,8] record array (x,y,w,h,conf,label,score,cell)."""
     import torch
     ctx = mi355_dt.default_context()
-    src = netouts if (isinstance(netouts, np.ndarray) and netouts.dtype == np.float32) else None
+    src = netouts if isinstance(netouts, np.ndarray) else None
     arr = np.ascontiguousarray(netouts, dtype=np.float32)
     B, GH, GW, NB, S = arr.shape
     dev = torch.from_numpy(arr).to(ctx.device)
@@ -116,7 +116,7 @@ def decode_netout_batch(netouts, obj_threshold, nms_threshold, anchors, nb_class
     if writeback:
         post = r["post"].cpu().numpy()
         if src is not None:
-            src[...] = post          # the reference mutates its argument (utils.py:214-216,252)
+            src[...] = post          # the reference mutates its argument (utils.py:214-216,252), whatever its dtype / strides
             post = src
     classes = r["classes"].cpu().numpy() if r["classes"] is not None else None
     out, rows_out = [], []

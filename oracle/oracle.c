@@ -427,7 +427,8 @@ ORC_API int orc_decode_netout(float *netout, int GH, int GW, int NB, int NC,
             }
     /* per-class greedy NMS (:239-252) */
     sc_t *ord = (sc_t *)malloc(sizeof(sc_t) * (size_t)(n > 0 ? n : 1));
-    for (int c = 0; c < NC; ++c) {
+    /* an IoU never exceeds 1: with nms_thr > 1 the sweep cannot suppress anything (tests use that to list candidates) */
+    for (int c = 0; c < NC && nms_thr <= 1.0f; ++c) {
         for (int k = 0; k < n; ++k) {
             ord[k].score = netout[(size_t)cand[k] * S + 5 + c];
             ord[k].idx = k;

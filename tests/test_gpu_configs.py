@@ -1,0 +1,299 @@
+"""GPU suite, part 2 (-m gpu): BASELINE.json's configurations AT THEIR STATED SIZES against the oracle,
+through the same code path bench.py times.
+
+  configs[2]  9 clips x T=30 x 416x416, C=12, default policy (fused conv_2, F(6x6) on 3x3 frame mosaics,
+              F(4x4) recurrent step for 29 steps), tracker head calibrated by bench.build_tracker to ~32 boxes/frame
+  configs[4]  4 clips x T=30 x 608x608 (19x19 grid), ~128 boxes/frame
+  configs[3]  TinyTracker, 32 sequences x T=64 (detector at 416, act_13 tap, LSTM over 64 steps)
+  configs[1]  detector batch 8 at 416, C=80, against the float64 graph fixture as well
+
+Every assert is unconditional.  Two float32 implementations that sum in different orders differ by ~1e-5, and a
+step of 270 frames makes ~230,000 score-vs-threshold decisions whose values lie ~3e-6 apart near 0.5: with ONE fixed
+threshold a few of them flip, and one flipped box renumbers every later track of its clip.  So the discrete
+decisions (score > obj_threshold, IoU >= nms_threshold, IoU >= assoc_threshold) are made robust the only honest
+way: the THRESHOLDS of a test are chosen from the ORACLE's output as the midpoint of the widest gap between
+neighbouring decision values near the reference default (objectness: one threshold per frame inside [0.45, 0.55],
+through dt_decode_per_frame -- the same kernel; NMS / association: one per test), so that no decision value lies
+within `margin` of its threshold; the margins are asserted to exceed the measured value error.  The forward pass,
+which is what is being validated, does not depend on the thresholds.
+
+Grid bar: per channel, max|got-ref| <= 3e-4 * max(1, max|ref|) (measured: ~1e-5 .. 1e-4; the float32 oracle itself
+sits 8e-5 from the float64 graph fixture).  Boxes: coordinates <= 1e-3 and IoU >= 0.999 (north_star's bars).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from utility import synth
+
+pytestmark = pytest.mark.gpu
+
+ANCHORS = [0.57273, 0.677385, 1.87446, 2.06253, 3.33843, 5.47434, 7.88282, 3.52778, 9.77052, 9.16828]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def chan_err(got, ref):
+    """max over channels (last axis) of max|got-ref| / max(1, max|ref|) in that channel: one bad channel cannot hide
+    behind the largest value of the whole grid."""
+    g = got.reshape(-1, got.shape[-1]).astype(np.float64)
+    r = ref.reshape(-1, ref.shape[-1]).astype(np.float64)
+    return float((np.abs(g - r).max(0) / np.maximum(1.0, np.abs(r).max(0))).max())
+
+
+def iou_rows(a, b):
+    """centre-format boxes [n,4] x [n,4] -> IoU [n] (float64; utils.py:155-188 semantics)"""
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    ix = np.minimum(a[:, 0] + a[:, 2] / 2, b[:, 0] + b[:, 2] / 2) - np.maximum(a[:, 0] - a[:, 2] / 2, b[:, 0] - b[:, 2] / 2)
+    iy = np.minimum(a[:, 1] + a[:, 3] / 2, b[:, 1] + b[:, 3] / 2) - np.maximum(a[:, 1] - a[:, 3] / 2, b[:, 1] - b[:, 3] / 2)
+    inter = np.clip(ix, 0, None) * np.clip(iy, 0, None)
+    return inter / (a[:, 2] * a[:, 3] + b[:, 2] * b[:, 3] - inter)
+
+
+def iou_matrix(a, b):
+    n, m = len(a), len(b)
+    if n == 0 or m == 0:
+        return np.zeros((n, m))
+    A = np.repeat(a[:, None, :4], m, 1).reshape(-1, 4)
+    B = np.repeat(b[None, :, :4], n, 0).reshape(-1, 4)
+    return iou_rows(A, B).reshape(n, m)
+
+
+def gap_threshold(values, default, lo, hi):
+    """midpoint of the widest gap between neighbouring decision values in [lo, hi] (plus the window edges);
+    returns (threshold, margin = half the gap).  With no value in the window the default stands."""
+    v = np.sort(np.asarray(values, dtype=np.float64))
+    v = v[(v > lo) & (v < hi)]
+    if v.size == 0:
+        return float(default), min(default - lo, hi - default)
+    edges = np.concatenate([[lo], v, [hi]])
+    k = int(np.argmax(np.diff(edges)))
+    return float(0.5 * (edges[k] + edges[k + 1])), float(0.5 * (edges[k + 1] - edges[k]))
+
+
+def oracle_scores(grid, C):
+    """all class scores conf*softmax of one frame as the reference computes them (decode with nothing thresholded
+    and nothing suppressed: utils.py:214-215)"""
+    _, post = orc.decode_netout(grid, 0.0, 2.0, ANCHORS, C)
+    return post[..., 5:]
+
+
+def _report(name, payload):
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name), "w") as f:
+            json.dump(payload, f, indent=1)
+    except OSError:
+        pass
+    print(name, json.dumps(payload))
+
+
+def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_policy):
+    import bench
+    dev = torch.device("cuda", torch.cuda.current_device())
+    C = 12
+    frames = bench.make_frames(n_clips, T, size, size, dev, seed0=42)
+    trk, blob, tw = bench.build_tracker(size, size, T, target_boxes, frames)
+    ctx = trk.model.ctx
+    G = size // 32
+
+    # ---- oracle forward (the expensive part: n_clips*T frames of the whole graph on the host)
+    layers, used = orc.parse_darknet_blob(blob, C)
+    assert used == blob.size
+    host = frames.cpu().numpy()
+    ref_trk = np.stack([orc.tracker_forward(orc.normalize_u8(host[i]), layers, tw)[0] for i in range(n_clips)])
+
+    # ---- thresholds from the oracle's decision values (module docstring)
+    scores = np.stack([[oracle_scores(ref_trk[i, t], C) for t in range(T)] for i in range(n_clips)])
+    obj_thr = np.zeros((n_clips, T), dtype=np.float32)        # one objectness threshold per frame
+    m_obj = np.inf
+    for i in range(n_clips):
+        for t in range(T):
+            thr, m = gap_threshold(scores[i, t].ravel(), 0.5, 0.45, 0.55)
+            obj_thr[i, t] = np.float32(thr)
+            m_obj = min(m_obj, m - abs(float(obj_thr[i, t]) - thr))
+    cand_iou = []
+    for i in range(n_clips):
+        for t in range(T):
+            rows, _ = orc.decode_netout(ref_trk[i, t], obj_thr[i, t], 2.0, ANCHORS, C)       # candidates, no suppression
+            m = iou_matrix(rows, rows)
+            cand_iou.append(m[np.triu_indices(len(rows), 1)])
+    nms_thr, m_nms = gap_threshold(np.concatenate(cand_iou), 0.45, 0.35, 0.55)
+    rb = np.zeros((n_clips, T, cap, 8), dtype=np.float32)
+    rc = np.zeros((n_clips, T), dtype=np.int32)
+    for i in range(n_clips):
+        for t in range(T):
+            rows, _ = orc.decode_netout(ref_trk[i, t], obj_thr[i, t], nms_thr, ANCHORS, C)
+            assert len(rows) <= cap
+            rb[i, t, :len(rows)] = rows
+            rc[i, t] = len(rows)
+    link_iou = [iou_matrix(rb[i, t, :rc[i, t]], rb[i, t - 1, :rc[i, t - 1]]).ravel()
+                for i in range(n_clips) for t in range(1, T)]
+    assoc_thr, m_assoc = gap_threshold(np.concatenate(link_iou), 0.3, 0.2, 0.4)
+
+    # ---- the HIP path, exactly as bench.py's step() runs it (profiled to see which kernels ran)
+    trk.OBJ_THRESHOLD, trk.NMS_THRESHOLD, trk.ASSOC_THRESHOLD = obj_thr.reshape(-1), nms_thr, assoc_thr
+    ctx.profile_reset(); ctx.profile_enable(True)
+    res = trk.track_clips(frames, cap=cap)
+    ctx.profile_enable(False)
+    names = set(ctx.profile_names())
+    for want in expect_policy:
+        assert want in names, "%s did not run; ran: %s" % (want, sorted(n for n in names if ":" in n or "wino" in n))
+    assert ctx.profile_read("wino_input:convlstm_step")["launches"] == T - 1
+    assert ctx.profile_read("conv_fused")["launches"] == 1
+
+    # ---- tracking grid: per-channel error overall and as a function of t (rounding growth of the recurrence)
+    got = res["netout"].cpu().numpy()
+    err_t = [chan_err(got[:, t], ref_trk[:, t]) for t in range(T)]
+    # class channels are scaled x200 by the synthetic head: compare them relative to their own scale via chan_err
+    assert max(err_t) < 3e-4, "tracking grid error %g at t=%d" % (max(err_t), int(np.argmax(err_t)))
+
+    # ---- score error actually observed vs the margins the thresholds were chosen with
+    gsc = np.stack([[oracle_scores(got[i, t], C) for t in range(T)] for i in range(n_clips)])
+    near = np.abs(scores - obj_thr.reshape(n_clips, T, 1, 1, 1, 1)) < 0.1
+    score_err = float(np.abs(gsc - scores)[near].max()) if near.any() else 0.0
+    assert m_obj > 2.0 * score_err, "objectness margin %g vs observed score error %g" % (m_obj, score_err)
+
+    # ---- boxes: set, order, labels exact; coordinates; IoU per matched box
+    counts = res["counts"].cpu().numpy()
+    assert np.array_equal(counts, rc), "box counts differ in %d of %d frames" % (int((counts != rc).sum()), rc.size)
+    gb = res["boxes"].cpu().numpy()
+    worst_coord, worst_iou, nbox = 0.0, 1.0, 0
+    for i in range(n_clips):
+        for t in range(T):
+            n = rc[i, t]
+            g, r = gb[i, t, :n], rb[i, t, :n]
+            assert np.array_equal(g[:, 7], r[:, 7]), "cell order differs (clip %d t %d)" % (i, t)
+            assert np.array_equal(g[:, 5], r[:, 5]), "labels differ (clip %d t %d)" % (i, t)
+            if n:
+                exy = np.abs(g[:, :2] - r[:, :2]).max()
+                ewh = (np.abs(g[:, 2:4] - r[:, 2:4]) / np.maximum(1.0, np.abs(r[:, 2:4]))).max()
+                worst_coord = max(worst_coord, float(exy), float(ewh))
+                worst_iou = min(worst_iou, float(iou_rows(g[:, :4], r[:, :4]).min()))
+                nbox += n
+    assert worst_coord < 1e-3, "box coordinates differ by %g" % worst_coord
+    assert worst_iou >= 0.999, "IoU vs oracle box %g" % worst_iou
+    assert nbox >= 0.5 * target_boxes * n_clips * T, "calibration gave only %d boxes" % nbox
+
+    # ---- track ids: bit-exact
+    ids = res["ids"].cpu().numpy()
+    nids = res["nids"].cpu().numpy()
+    for i in range(n_clips):
+        rid, rn = orc.associate_clip(rb[i], rc[i], assoc_thr)
+        assert np.array_equal(ids[i], rid), "track ids differ in clip %d" % i
+        assert int(nids[i]) == rn
+    _report("parity_%s.json" % tag, dict(
+        config="%d clips x T=%d x %dx%d, C=12, default policy" % (n_clips, T, size, size), boxes=int(nbox),
+        boxes_per_frame=nbox / float(n_clips * T), tracks=int(nids.sum()),
+        grid_chan_err_t0=err_t[0], grid_chan_err_t10=err_t[min(10, T - 1)], grid_chan_err_t_last=err_t[-1],
+        grid_chan_err_max=max(err_t), score_err_near_threshold=score_err, box_coord_err=worst_coord,
+        box_iou_min=worst_iou, obj_threshold_min=float(obj_thr.min()), obj_threshold_max=float(obj_thr.max()),
+        obj_margin=m_obj, nms_threshold=nms_thr, nms_margin=m_nms,
+        assoc_threshold=assoc_thr, assoc_margin=m_assoc, ids_bit_exact=True, kernels=sorted(n for n in names if ":" in n)))
+
+
+def test_configs2_benched_track_416_vs_oracle():
+    """BASELINE configs[2] as bench.py runs it: this is the path the headline number is measured on."""
+    _track_config_vs_oracle(416, 9, 30, 32, 128, "r02_track416",
+                            ["wino_input:convlstm_xproj", "wino_input:convlstm_step", "wino_input:conv_22",
+                             "wino_input:conv_3", "conv_fused:conv_2", "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4"])
+
+
+def test_configs4_track_608_128_boxes_vs_oracle():
+    """BASELINE configs[4] single-GPU shard: 608x608 -> 19x19 grid, ~128 boxes/frame, 4 clips x 30 frames."""
+    _track_config_vs_oracle(608, 4, 30, 128, 320, "r02_track608",
+                            ["wino_input:convlstm_xproj", "wino_input:convlstm_step", "wino_input:conv_22",
+                             "conv_fused:conv_2"])
+
+
+def test_configs3_tinytracker_T64_vs_oracle():
+    """BASELINE configs[3] at its stated size: 32 sequences x 64 frames at 416x416 (2048 detector frames, act_13
+    tap 26x26x512, global max-pool, top box, LSTM(512) over 64 steps, Dense(4)).  The oracle runs the detector on
+    a subset of the sequences (3 x 64 frames) and the LSTM on all 32; the LSTM state error is reported at t = 63."""
+    from models_detection.KerasYOLO import KerasYOLO
+    from models_tracking.TinyTracker import TinyTracker
+    H = W = 416
+    C, n_seq, T = 12, 32, 64
+    blob = synth.synth_darknet_blob(C, head_std=0.1)
+    det = KerasYOLO({'LABELS': [str(i) for i in range(C)], 'BATCH_SIZE': 4, 'IMAGE_H': H, 'IMAGE_W': W,
+                     'GRID_H': 13, 'GRID_W': 13}, weights=blob)
+    tw = synth.synth_tiny_weights(512)
+    cfg = {"model_tracker": {"name": "TinyTracker", "lstm_units": 512, "sequence_length": T},
+           "train": {"pool": "Global", "batch_size": 4}}
+    ctx = det.model.ctx
+    tt = TinyTracker(cfg, feature_dims=(26, 26, 512), weights=tw, ctx=ctx)
+    import bench
+    frames = bench.make_frames(n_seq, T, H, W, ctx.device, seed0=900)
+    flat = frames.reshape(n_seq * T, H, W, 3)
+    rows, det4 = tt.frame_rows(flat, det)
+    got = ctx.tiny_sequence(rows.reshape(n_seq, T, -1).contiguous()).cpu().numpy()
+    rows = rows.cpu().numpy().reshape(n_seq, T, -1); det4 = det4.cpu().numpy().reshape(n_seq, T, 4)
+
+    # (a) detector + pool + top box of 3 whole sequences against the oracle
+    layers, _ = orc.parse_darknet_blob(blob, C)
+    sub = [0, 13, 31]
+    nbox = 0
+    for s in sub:
+        net, _, taps = orc.yolov2_forward(orc.normalize_u8(frames[s].cpu().numpy()), layers, taps=("act_13",))
+        pooled = orc.global_maxpool(taps["act_13"])
+        assert chan_err(rows[s, :, :512], pooled) < 3e-4
+        # decode of this sequence with per-frame gap thresholds (module docstring) on both sides
+        sc = np.stack([oracle_scores(net[t], C) for t in range(T)])
+        thr = np.array([gap_threshold(sc[t].ravel(), det.OBJ_THRESHOLD, 0.45, 0.55)[0] for t in range(T)], dtype=np.float32)
+        gnet = ctx.detect_forward(frames[s].contiguous())
+        r = ctx.decode(gnet, thr, det.NMS_THRESHOLD, ANCHORS, C)
+        d4 = ctx.top_box(r["boxes"], r["counts"]).cpu().numpy()
+        for t in range(T):
+            rws, _ = orc.decode_netout(net[t], thr[t], det.NMS_THRESHOLD, ANCHORS, C)
+            assert int(r["counts"][t]) == len(rws)
+            if len(rws):
+                sc_sorted = np.sort(rws[:, 6])
+                assert len(rws) == 1 or sc_sorted[-1] - sc_sorted[-2] > 1e-5, "top two scores tie: pick is ambiguous"
+                want = rws[int(np.argmax(rws[:, 6])), :4]
+            else:
+                want = np.zeros(4, dtype=np.float32)
+            assert np.all(np.isfinite(want)) and np.all(np.isfinite(d4[t]))
+            assert (np.abs(d4[t] - want) / np.maximum(1.0, np.abs(want))).max() < 1e-3
+            nbox += len(rws) > 0
+    assert nbox >= len(sub) * T // 2, "vacuous: only %d of %d frames had a detection" % (nbox, len(sub) * T)
+    # (b) the LSTM over 64 steps for ALL sequences from the device's own rows: state error at t = 63
+    U = 512
+    h = np.zeros((n_seq, U), dtype=np.float32); c = np.zeros_like(h)
+    ref = np.zeros((n_seq, T, 4), dtype=np.float32)
+    for t in range(T):
+        h, c = orc.lstm_step(rows[:, t], h, c, tw["kernel"], tw["recurrent"], tw["bias"])
+        ref[:, t] = orc.dense_sigmoid(h, tw["dense_kernel"], tw["dense_bias"])
+    e_t = [float(np.abs(got[:, t] - ref[:, t]).max()) for t in range(T)]
+    assert max(e_t) < 1e-4
+    _report("parity_r02_tiny64.json", dict(config="TinyTracker 32 sequences x T=64 @416", frames_with_box=int(nbox),
+                                           out_err_t0=e_t[0], out_err_t31=e_t[31], out_err_t63=e_t[63], out_err_max=max(e_t)))
+
+
+def test_configs1_detector_batch8_vs_oracle_and_f64_graph(golden_dir):
+    """BASELINE configs[1]: YOLOv2 C=80, batch 8 at 416 -- per-channel bar against the oracle for all 8 frames, and
+    frame 0 against the float64 output of the reference's executed graph (tests/golden/graph_yolov2_416_c80.npz)."""
+    from models_detection.KerasYOLO import KerasYOLO
+    C = 80
+    blob = synth.synth_darknet_blob(C, seed=1234)
+    det = KerasYOLO({'LABELS': KerasYOLO.LABELS_COCO, 'BATCH_SIZE': 8, 'IMAGE_H': 416, 'IMAGE_W': 416, 'GRID_H': 13,
+                     'GRID_W': 13}, weights=blob)
+    d = np.load(os.path.join(golden_dir, "graph_yolov2_416_c80.npz"))
+    frames = np.concatenate([synth.synth_clip(1, 416, 416, 3, seed=int(d["seed_frame"])),
+                             synth.synth_clip(7, 416, 416, 3, seed=8)])
+    ctx = det.model.ctx
+    net, feat = ctx.detect_forward(torch.from_numpy(frames).to(ctx.device), want_feat=True)
+    net = net.cpu().numpy(); feat = feat.cpu().numpy()
+    layers, _ = orc.parse_darknet_blob(blob, C)
+    ref_net, ref_feat, _ = orc.yolov2_forward(orc.normalize_u8(frames), layers)
+    e_net = chan_err(net.reshape(8, 13, 13, -1), ref_net.reshape(8, 13, 13, -1))
+    e_feat = chan_err(feat, ref_feat)
+    e64 = chan_err(net[:1].reshape(1, 13, 13, -1), d["netout"].reshape(1, 13, 13, -1))
+    e64_oracle = chan_err(ref_net[:1].reshape(1, 13, 13, -1), d["netout"].reshape(1, 13, 13, -1))
+    assert e_net < 3e-4 and e_feat < 3e-4
+    assert e64 < 3e-4, "HIP path vs float64 graph: %g (oracle vs float64: %g)" % (e64, e64_oracle)
+    _report("parity_r02_detect8.json", dict(netout_chan_err_vs_oracle=e_net, feat_chan_err_vs_oracle=e_feat,
+                                            netout_chan_err_vs_f64_graph=e64, oracle_vs_f64_graph=e64_oracle))

@@ -29,6 +29,47 @@ def relerr(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
+def chan_err(got, ref):
+    """whole-network bar: per channel (last axis), max|got-ref| / max(1, max|ref| of that channel) -- one bad channel
+    cannot hide behind the largest value of the grid.  Bar 3e-4 (measured 1e-5..1e-4 through 23 float32 layers)."""
+    g = got.reshape(-1, got.shape[-1]).astype(np.float64)
+    r = ref.reshape(-1, ref.shape[-1]).astype(np.float64)
+    return float((np.abs(g - r).max(0) / np.maximum(1.0, np.abs(r).max(0))).max())
+
+
+NET_TOL = 3e-4
+
+
+def flat_c(a):
+    """[..., NB, 5+C] grids -> [..., NB*(5+C)] so that every (anchor, field) pair is its own channel"""
+    return a.reshape(a.shape[:-2] + (-1,))
+
+
+def gap_threshold(values, default, lo, hi):
+    """midpoint of the widest gap between neighbouring decision values inside [lo, hi]: a threshold no value of the
+    oracle's lies close to, so a float32 rounding difference cannot flip a decision (tests/test_gpu_configs.py)"""
+    v = np.sort(np.asarray(values, dtype=np.float64))
+    v = v[(v > lo) & (v < hi)]
+    if v.size == 0:
+        return float(default)
+    edges = np.concatenate([[lo], v, [hi]])
+    k = int(np.argmax(np.diff(edges)))
+    return float(np.float32(0.5 * (edges[k] + edges[k + 1])))
+
+
+def oracle_scores(grid, C, anchors=None):
+    _, post = orc.decode_netout(grid, 0.0, 2.0, anchors if anchors is not None else ANCHORS, C)
+    return post[..., 5:]
+
+
+def iou_rows(a, b):
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    ix = np.minimum(a[:, 0] + a[:, 2] / 2, b[:, 0] + b[:, 2] / 2) - np.maximum(a[:, 0] - a[:, 2] / 2, b[:, 0] - b[:, 2] / 2)
+    iy = np.minimum(a[:, 1] + a[:, 3] / 2, b[:, 1] + b[:, 3] / 2) - np.maximum(a[:, 1] - a[:, 3] / 2, b[:, 1] - b[:, 3] / 2)
+    inter = np.clip(ix, 0, None) * np.clip(iy, 0, None)
+    return inter / (a[:, 2] * a[:, 3] + b[:, 2] * b[:, 3] - inter)
+
+
 def box_err(got, ref):
     """north_star bar: box coords within 1e-3.  x,y live in [0,1] (absolute);
     w,h = anchor*exp(t)/G are unbounded, so they are compared relative to max(1,|ref|)."""
@@ -204,15 +245,15 @@ def test_detector_forward_vs_oracle_small(ctx, H, W, C, B):
     frames = rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
     ref_net, ref_feat, taps = orc.yolov2_forward(orc.normalize_u8(frames), layers, taps=("act_13",))
     net, feat = det.model.ctx.detect_forward(dev(frames, det.model.ctx), want_feat=True)
-    assert relerr(net.cpu().numpy(), ref_net) < 1e-3
-    assert relerr(feat.cpu().numpy(), ref_feat) < 1e-3
+    assert chan_err(flat_c(net.cpu().numpy()), flat_c(ref_net)) < NET_TOL
+    assert chan_err(feat.cpu().numpy(), ref_feat) < NET_TOL
     # float32 frames (already normalised) take the same path
     net32 = det.model.ctx.detect_forward(dev(orc.normalize_u8(frames), det.model.ctx))
     assert torch.equal(net32, net)
     # named taps (KerasYOLO.extract)
     det.model.ctx.detect_forward_internal(dev(frames, det.model.ctx))
     a13 = det.model.ctx.detector_tap("act_13", B).cpu().numpy()
-    assert relerr(a13, taps["act_13"]) < 1e-3
+    assert chan_err(a13, taps["act_13"]) < NET_TOL
     assert torch.equal(det.model.ctx.detector_tap("conv_23", B).reshape(net.shape), net)
 
 
@@ -223,17 +264,20 @@ def test_detector_full_size_one_frame_vs_oracle(ctx):
     ref_net, _, _ = orc.yolov2_forward(orc.normalize_u8(frame), layers)
     net = det.model.ctx.detect_forward(dev(frame, det.model.ctx)).cpu().numpy()
     assert net.shape == (1, 13, 13, 5, 85)
-    assert relerr(net, ref_net) < 1e-3
-    # box parity on the decoded output (boost objectness so boxes exist)
+    assert chan_err(flat_c(net), flat_c(ref_net)) < NET_TOL
+    # box parity on the decoded output (boost objectness so boxes exist); the threshold sits in the widest gap of the
+    # oracle's scores near 0.3, so the comparison is unconditional
     boost = net.copy(); boost[..., 4] += 2.0; boost[..., 5:] *= 4.0
     rboost = ref_net.copy(); rboost[..., 4] += 2.0; rboost[..., 5:] *= 4.0
-    rows, _ = orc.decode_netout(rboost[0], 0.3, 0.45, ANCHORS, 80)
-    r = det.model.ctx.decode(dev(boost, det.model.ctx), 0.3, 0.45, ANCHORS, 80)
+    thr = gap_threshold(oracle_scores(rboost[0], 80).ravel(), 0.3, 0.25, 0.35)
+    rows, _ = orc.decode_netout(rboost[0], thr, 0.45, ANCHORS, 80)
+    r = det.model.ctx.decode(dev(boost, det.model.ctx), thr, 0.45, ANCHORS, 80)
     n = int(r["counts"][0])
     got = r["boxes"][0, :n].cpu().numpy()
-    assert n > 0
-    if len(rows) == n and np.array_equal(got[:, 7], rows[:, 7]):
-        assert box_err(got, rows) < 1e-3
+    assert n > 0 and n == len(rows)
+    assert np.array_equal(got[:, 7], rows[:, 7]) and np.array_equal(got[:, 5], rows[:, 5])
+    assert box_err(got, rows) < 1e-3
+    assert iou_rows(got[:, :4], rows[:, :4]).min() >= 0.999
 
 
 def test_detector_full_size_default_policy_vs_oracle(ctx):
@@ -247,8 +291,8 @@ def test_detector_full_size_default_policy_vs_oracle(ctx):
     net, feat = c.detect_forward(dev(frames, c), want_feat=True)
     c.profile_enable(False)
     assert c.profile_read("wino_input")["launches"] >= 12       # conv_3,5,6,8,9,11,13,14,16,18,19,20,22
-    assert relerr(net.cpu().numpy(), ref_net) < 1e-3
-    assert relerr(feat.cpu().numpy(), ref_feat) < 1e-3
+    assert chan_err(flat_c(net.cpu().numpy()), flat_c(ref_net)) < NET_TOL
+    assert chan_err(feat.cpu().numpy(), ref_feat) < NET_TOL
 
 
 def test_detector_batch_invariance_full_size(ctx, monkeypatch):
@@ -270,6 +314,7 @@ def test_detector_batch_invariance_full_size(ctx, monkeypatch):
     single = det.model.ctx.detect_forward(d[4:5].contiguous())
     assert relerr(single[0].cpu().numpy(), full[4].cpu().numpy()) < 1e-4
     monkeypatch.setenv("DT_WINO_MOSAIC", "1")
+    det.model.ctx.reload_policy()
     full1 = det.model.ctx.detect_forward(d)
     shuffled1 = det.model.ctx.detect_forward(d[perm].contiguous())
     assert torch.equal(shuffled1, full1[perm]), "position / neighbour independence (bit-exact without the mosaic)"
@@ -327,8 +372,8 @@ def test_track_forward_vs_oracle_small(ctx):
     got_trk, got_det = trk.model.predict([frames, None])
     for i in range(n_clips):
         ref_trk, ref_det = orc.tracker_forward(orc.normalize_u8(frames[i]), layers, tw)
-        assert relerr(got_det[i], ref_det) < 1e-3
-        assert relerr(got_trk[i], ref_trk) < 1e-3
+        assert chan_err(flat_c(got_det[i]), flat_c(ref_det)) < NET_TOL
+        assert chan_err(flat_c(got_trk[i]), flat_c(ref_trk)) < NET_TOL
 
 
 def test_track_clips_boxes_and_ids_vs_oracle(ctx):
@@ -576,15 +621,18 @@ def test_track_608_vs_oracle(ctx):
     ref_trk, _ = orc.tracker_forward(orc.normalize_u8(frames[0]), layers, tw)
     got = res["netout"][0].cpu().numpy()
     assert got.shape == (T, 19, 19, 5, 17)
-    assert relerr(got, ref_trk) < 1e-3
-    cnt = res["counts"][0].cpu().numpy()
+    assert chan_err(flat_c(got), flat_c(ref_trk)) < NET_TOL
+    # decode with one gap threshold per frame (no oracle score within float noise of it): unconditional comparison
+    thr = np.array([gap_threshold(oracle_scores(ref_trk[t], C).ravel(), 0.3, 0.25, 0.35) for t in range(T)], dtype=np.float32)
+    r = trk.model.ctx.decode(res["netout"][0], thr, 0.45, ANCHORS, C)
+    cnt = r["counts"].cpu().numpy()
     for t in range(T):
-        rows, _ = orc.decode_netout(ref_trk[t], 0.3, 0.45, ANCHORS, C)
-        gb = res["boxes"][0, t, :cnt[t]].cpu().numpy()
-        if len(rows) == cnt[t] and np.array_equal(gb[:, 7], rows[:, 7]):
-            assert box_err(gb, rows) < 1e-3
-        else:   # a score within float noise of the threshold may flip membership; sets must still nearly agree
-            assert abs(len(rows) - int(cnt[t])) <= max(2, len(rows) // 50)
+        rows, _ = orc.decode_netout(ref_trk[t], thr[t], 0.45, ANCHORS, C)
+        assert len(rows) == cnt[t]
+        gb = r["boxes"][t, :cnt[t]].cpu().numpy()
+        assert np.array_equal(gb[:, 7], rows[:, 7]) and np.array_equal(gb[:, 5], rows[:, 5])
+        assert box_err(gb, rows) < 1e-3
+        assert len(rows) == 0 or iou_rows(gb[:, :4], rows[:, :4]).min() >= 0.999
     assert cnt.sum() > 0
 
 
@@ -997,8 +1045,8 @@ def test_detector_non_square_odd_grid_vs_oracle(ctx, monkeypatch, mode):
     c = det.model.ctx
     net, feat = c.detect_forward(dev(frames, c), want_feat=True)
     assert net.shape == (5, 11, 9, 5, 17)
-    assert relerr(net.cpu().numpy(), ref_net) < 1e-3
-    assert relerr(feat.cpu().numpy(), ref_feat) < 1e-3
+    assert chan_err(flat_c(net.cpu().numpy()), flat_c(ref_net)) < NET_TOL
+    assert chan_err(feat.cpu().numpy(), ref_feat) < NET_TOL
 
 
 def test_winograd_randomized_shapes_vs_oracle(ctx, monkeypatch):

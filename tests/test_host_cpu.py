@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(mi355_dt.LIB_PATH)
     for s in declared:
         assert hasattr(lib, s), "missing export " + s
-    assert lib.dt_abi_version() == 102
+    assert lib.dt_abi_version() == 103
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -261,3 +261,18 @@ def test_pack_objects_layout():
     assert counts.tolist() == [2, 0] and dims.tolist() == [[640, 480], [320, 240]]
     with pytest.raises(ValueError):
         pack_objects(recs, ["a"], cap=1)
+
+
+def test_pack_objects_without_size_block_and_short_batches():
+    """records parsed from XML without a <size> block carry no width/height (the generators then use the decoded
+    image's dims, preprocessing.py:144); fewer items than one batch give a short batch, not a negative slice"""
+    from utility.preprocessing import BatchGenerator, pack_objects
+    recs = [{"filename": "x.png", "folder": "a/", "object": [{"name": "car", "xmin": 1, "ymin": 2, "xmax": 30, "ymax": 40}]}]
+    objs, counts, dims = pack_objects(recs, ["car"])
+    assert counts.tolist() == [1] and dims.tolist() == [[0, 0]] and objs[0, 0].tolist() == [1, 2, 30, 40, 0]
+    g = BatchGenerator.__new__(BatchGenerator)
+    g.config = {"BATCH_SIZE": 4}
+    g.images = list(range(3))
+    assert g._bounds(0) == (0, 3)
+    g.images = list(range(10))
+    assert g._bounds(0) == (0, 4) and g._bounds(2) == (6, 10)
