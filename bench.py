@@ -43,7 +43,7 @@ import torch.distributed as dist
 import object_tracking_amd  # noqa: F401
 from models_detection.KerasYOLO import KerasYOLO
 from models_tracking.MultiObjDetTracker import MultiObjDetTracker
-from parallel import gather_detections, init_from_env
+from parallel import gather_detections, init_from_env, track_clips_frame_sharded
 from utility import synth
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
@@ -92,25 +92,56 @@ def build_tracker(H, W, T, target_boxes, frames_for_calib):
 
 
 def cpu_baseline_track(blob, tw, H, W, n_frames):
-    """The CPU oracle ("port" of the Keras graph, not Keras itself -- SURVEY.md
-    section 0.1) on a bounded sample: one clip of n_frames frames through the
-    detector, ConvLSTM, 1x1, decode and association."""
+    """The CPU statements of the path ("port" of the Keras graph, not Keras itself -- SURVEY.md section 0.1) on a
+    bounded sample: one clip of n_frames frames through detector, ConvLSTM, 1x1, decode and association.  Two
+    variants are timed -- oracle/oracle.c (C + OpenMP loop nest) and oracle/torch_cpu.py (ATen/oneDNN convolutions) --
+    and the FASTER one is the reported baseline.  Returns {variant: (frames/s, seconds)}."""
     from oracle import oracle as orc
+    from oracle import torch_cpu
     C = 12
     layers, _ = orc.parse_darknet_blob(blob, C)
     frames = synth.synth_clip(n_frames, H, W, 32, seed=999)
-    t0 = time.perf_counter()
-    trk, _ = orc.tracker_forward(orc.normalize_u8(frames), layers, tw)
-    cap = trk.shape[1] * trk.shape[2] * 5
-    rb = np.zeros((n_frames, cap, 8), dtype=np.float32)
-    rc = np.zeros(n_frames, dtype=np.int32)
-    for t in range(n_frames):
-        rows, _ = orc.decode_netout(trk[t], 0.5, 0.45, MultiObjDetTracker.ANCHORS, C)
-        rb[t, :len(rows)] = rows
-        rc[t] = len(rows)
-    orc.associate_clip(rb, rc, 0.3)
-    dt = time.perf_counter() - t0
-    return n_frames / dt, dt
+    out = {}
+    for name, fwd in (("oracle_c_openmp", orc.tracker_forward), ("torch_cpu_onednn", torch_cpu.tracker_forward)):
+        t0 = time.perf_counter()
+        trk, _ = fwd(orc.normalize_u8(frames), layers, tw)
+        cap = trk.shape[1] * trk.shape[2] * 5
+        rb = np.zeros((n_frames, cap, 8), dtype=np.float32)
+        rc = np.zeros(n_frames, dtype=np.int32)
+        for t in range(n_frames):
+            rows, _ = orc.decode_netout(trk[t], 0.5, 0.45, MultiObjDetTracker.ANCHORS, C)
+            rb[t, :len(rows)] = rows
+            rc[t] = len(rows)
+        orc.associate_clip(rb, rc, 0.3)
+        dt = time.perf_counter() - t0
+        out[name] = (n_frames / dt, dt)
+    return out
+
+
+def detect_batch8_extra(device, H, W, seed0):
+    """BASELINE.json configs[1] under the same clock: YOLOv2 C=80 forward + decode/NMS on 8 frames, plain launches
+    and hipGraph replay, in its own context, after the main timed region."""
+    C, B = 80, 8
+    blob = synth.synth_darknet_blob(C, seed=1234)
+    det = KerasYOLO({'LABELS': KerasYOLO.LABELS_COCO, 'BATCH_SIZE': B, 'IMAGE_H': H, 'IMAGE_W': W,
+                     'GRID_H': H // 32, 'GRID_W': W // 32}, weights=blob)
+    frames = make_frames(1, B, H, W, device, seed0=seed0)[0].contiguous()
+    out = {"workload": "BASELINE.json configs[1]: YOLOv2 C=80 forward + decode/NMS, batch 8, %dx%d uint8" % (H, W)}
+    for label, graphs in (("plain", False), ("graphs", True)):
+        det.model.ctx.graph_enable(graphs)
+        for _ in range(5):
+            det.detect(frames)
+        torch.cuda.synchronize()
+        n = 50
+        t0 = time.perf_counter()
+        for _ in range(n):
+            det.detect(frames)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n
+        out[label] = {"ms_per_batch": ms, "frames_per_s": B / (ms * 1e-3),
+                      "direct_form_tflops": B * GFLOP_DETECT_416_C80 * (H * W) / (416.0 * 416.0) / ms}
+    det.model.ctx.graph_enable(False)
+    return out
 
 
 def load_traffic(clips, T, size):
@@ -157,6 +188,11 @@ def _run():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--h2d", action="store_true", help="also copy the frames from pinned host memory every step (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--cpu-frames", type=int, default=30)
+    ap.add_argument("--shard", choices=["clip", "frame"], default="clip",
+                    help="N>1 (track): clip = each rank owns --clips whole clips (weak scaling, no data-path collective); "
+                         "frame = --clips clips in TOTAL, every rank runs the detector on its time steps of all of them, "
+                         "per-frame rows all-gathered, recurrence on each clip's owner (strong scaling; configs[4])")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] extra block")
     ap.add_argument("--layer-report", default=None, help="write a per-layer table (HIP-event times) to this file")
     args = ap.parse_args()
 
@@ -167,10 +203,12 @@ def _run():
     H = W = args.size
 
     if args.workload == "track":
-        frames = make_frames(args.clips, args.T, H, W, device, seed0=42 + 100 * rank)
+        frame_shard = args.shard == "frame" and world > 1
+        # frame-shard: every rank holds the SAME --clips clips (it touches only its own time steps of them)
+        frames = make_frames(args.clips, args.T, H, W, device, seed0=42 + (0 if frame_shard else 100 * rank))
         trk, blob, tw = build_tracker(H, W, args.T, args.boxes, frames)
         ctx = trk.model.ctx
-        frames_per_step = args.clips * args.T
+        frames_per_step = args.clips * args.T / (world if frame_shard else 1)
         gflop_per_frame = GFLOP_TRACK_416 * (H * W) / (416.0 * 416.0)
 
         host_frames = frames.cpu().pin_memory() if args.h2d else None
@@ -179,9 +217,11 @@ def _run():
             src = frames
             if host_frames is not None:
                 frames.copy_(host_frames, non_blocking=True)     # same stream: serialised in front of the step
+            if frame_shard:
+                return track_clips_frame_sharded(trk, src, cap=max(128, 2 * args.boxes))
             res = trk.track_clips(src, cap=max(128, 2 * args.boxes))
             if world > 1:
-                res = gather_detections(res)
+                res = gather_detections(res, n_clips_max=args.clips)
             return res
     elif args.workload == "tiny":
         # BASELINE.json configs[3]: TinyTracker (ROLO-style) over 64-frame sequences, FRAME-sharded:
@@ -263,7 +303,10 @@ def _run():
     # direct-form FLOPs (SURVEY.md 8d figures) of the layers those launches computed; > executed where the
     # wide 3x3 layers run in Winograd form.  Time base: the MFMA kernel alone / with its transform kernels.
     direct_form = ctx.profile_read("conv_direct_form")["flops"]
-    wino_ms = ctx.profile_read("wino_input")["ms"] + ctx.profile_read("wino_output")["ms"]
+    direct_form_bytes = ctx.profile_read("conv_direct_form")["bytes"]
+    wino_in, wino_out = ctx.profile_read("wino_input"), ctx.profile_read("wino_output")
+    wino_ms = wino_in["ms"] + wino_out["ms"]
+    fused = ctx.profile_read("conv_fused")
     # split the family's launches by arithmetic intensity (executed FLOP per algorithmic byte): below the ridge
     # of the chip (157.3 TFLOP/s over ~6.3 TB/s achievable = 25 FLOP/B; 40 used as the class boundary) a launch is
     # HBM-bound whatever the kernel does, and is priced against the HBM roof instead
@@ -298,7 +341,8 @@ def _run():
             "metric": {"track": "frames/sec detect+track @416x416", "detect": "frames/sec detect @416x416",
                        "tiny": "frames/sec detect + single-object LSTM track @416x416"}[args.workload],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if args.workload == "tiny" else "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if (args.workload == "tiny" or (args.workload == "track" and args.shard == "frame" and world > 1)) else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[2]: MultiObjDetTracker (YOLOv2 C=12 + ConvLSTM2D(512) + 1x1 "
                                     "+ decode/NMS + track ids), %d clips x %d frames per GPU per step, %dx%d uint8"
@@ -307,12 +351,24 @@ def _run():
                         % (args.batch, H, W)) if args.workload == "detect" else
                        ("BASELINE.json configs[3]: TinyTracker, %d sequences x 64 frames, frame-sharded x%d: YOLOv2 C=80 "
                         "+ act_13 global max-pool + decode/top box per frame, LSTM(512)+Dense(4) over T" % (args.seqs, world)),
-                       "frames_per_step_per_gpu": frames_per_step, "parallelism": "clip-shard x%d" % world,
+                       "frames_per_step_per_gpu": frames_per_step,
+                       "parallelism": ("frame-shard x%d (detector on t mod N, rows all-gathered, recurrence on the clip owner)" % world)
+                       if (args.workload == "track" and args.shard == "frame" and world > 1) else "clip-shard x%d" % world,
                        "gflop_per_frame": gflop_per_frame, "boxes_per_frame": boxes_per_frame},
             "whole_path_tflops": fps * gflop_per_frame / 1e3, "h2d_included": bool(args.h2d),
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32 implicit GEMM)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "frac_executed": achieved / PEAK_F32_MFMA_TFLOPS,
+                         # the transform kernels exist only because of the Winograd form: charge them to the conv path
+                         "frac_incl_transforms": (ig["flops"] / ((ig["ms"] + wino_ms) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)
+                         if ig["ms"] > 0 else None,
+                         "transform_ms_per_step": wino_ms / max(1, args.steps),
+                         # conv family as a whole (MFMA GEMMs + transforms + fused conv_2): direct-form bytes the
+                         # reference's layers need (in + W + out, fp32) vs the bytes this implementation's kernels
+                         # move by their own algorithmic count (V + U + M' for the GEMMs, the transforms' reads+writes)
+                         "direct_form_bytes_per_step": direct_form_bytes / max(1, args.steps),
+                         "implementation_bytes_per_step": (ig["bytes"] + wino_in["bytes"] + wino_out["bytes"] + fused["bytes"]) / max(1, args.steps),
+                         "traffic": None, "traffic_per_step": None,
                          "launches_per_step": ig["launches"] / max(1, args.steps),
                          "avg_launch_ms": ig["ms"] / max(1, ig["launches"]),
                          "executed_gflop_per_launch": ig["flops"] / max(1, ig["launches"]) / 1e9,
@@ -344,16 +400,23 @@ def _run():
         tr = load_traffic(args.clips, args.T, args.size) if args.workload == "track" else None
         if tr is not None:
             out["roofline"]["traffic"] = tr[1]["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_per_step"] = tr[1].get("traffic_bytes_per_step")
             out["roofline"]["traffic_unit"] = "bytes/launch (FETCH_SIZE x in-run calibration + WRITE_SIZE; beyond-L2, incl. Infinity Cache hits)"
             out["roofline"]["traffic_source"] = os.path.relpath(tr[0], ROOT)
+        if world == 1 and not args.no_extra and args.workload == "track":
+            out["extra"] = {"detect_batch8": detect_batch8_extra(device, H, W, seed0=4242)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "track":
             from oracle import oracle as orc
             orc.lib()
-            cpu_fps, cpu_s = cpu_baseline_track(blob, tw, H, W, args.cpu_frames)
-            out["cpu_baseline"] = {"value": cpu_fps, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-                                   "sample": "CPU restatement (oracle/, C + OpenMP; NOT Keras/TF, which cannot run "
-                                             "here): 1 clip x %d frames %dx%d through detector+ConvLSTM+1x1+decode+"
-                                             "association, %.1f s" % (args.cpu_frames, H, W, cpu_s)}
+            variants = cpu_baseline_track(blob, tw, H, W, args.cpu_frames)
+            best = max(variants, key=lambda k: variants[k][0])
+            out["cpu_baseline"] = {"value": variants[best][0], "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                                   "variant": best,
+                                   "variants": {k: {"frames_per_s": v[0], "seconds": v[1]} for k, v in variants.items()},
+                                   "sample": "CPU restatement of the graph (NOT Keras/TF, which cannot run here), the faster of "
+                                             "oracle/oracle.c (C + OpenMP) and oracle/torch_cpu.py (ATen/oneDNN): 1 clip x %d "
+                                             "frames %dx%d through detector+ConvLSTM+1x1+decode+association, %.1f s"
+                                             % (args.cpu_frames, H, W, variants[best][1])}
     else:
         out = None
     if world > 1:

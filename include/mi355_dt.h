@@ -142,6 +142,18 @@ DT_API int dt_tracker_load(dt_ctx *ctx, int units, const float *h_kernel,
 DT_API int dt_track_forward(dt_ctx *ctx, const void *d_frames, int frames_dtype,
                      int n_clips, int T, float *d_trk, float *d_det);
 
+/* The two halves of dt_track_forward, exposed so that ONE stream can use several GPUs (frame-shard, SURVEY.md 8e row 3,
+ * BASELINE.json configs[4]): each rank runs the TimeDistributed detector (MultiObjDetTracker.py:166-171) on its share
+ * of the frames, the per-frame rows z = [conv_feat 1024 | x_bbox Cb | zero pad] are exchanged (RCCL all-gather), and
+ * the owner of a clip runs ConvLSTM2D + tconv_2 (:175-183) on the stitched rows.  dt_track_row_width = floats per grid
+ * cell of a row (1024 + Cb rounded up to 32).
+ *   dt_track_detect:    d_frames [n_frames,H,W,3]      -> d_z [n_frames, G, G, row_width]
+ *   dt_track_recurrent: d_z [n_clips, T, G, G, row_width] -> d_trk [n_clips,T,G,G,Cb] (+ d_det, may be NULL)
+ * dt_track_forward == dt_track_detect on all frames followed by dt_track_recurrent. */
+DT_API int dt_track_row_width(dt_ctx *ctx);
+DT_API int dt_track_detect(dt_ctx *ctx, const void *d_frames, int frames_dtype, int n_frames, float *d_z);
+DT_API int dt_track_recurrent(dt_ctx *ctx, const float *d_z, int n_clips, int T, float *d_trk, float *d_det);
+
 /* Track identity (BUILD-DEFINED, DESIGN.md "Track identity"; the reference has
  * none).  d_boxes [n_clips,T,cap,8], d_counts [n_clips,T]
  * -> d_ids [n_clips,T,cap] int32 (-1 unused), d_nids [n_clips] ids opened. */

@@ -361,9 +361,11 @@ extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t 
 // "conv_direct_form": direct-form FLOPs (2*M*K*N of the reference's convolution) of every layer a
 // conv_igemm launch computes, whichever form it runs in -- bench.py divides it by the kernel family's
 // time for the algorithmic-equivalent rate next to the executed one.
-static void prof_direct_form(dt_ctx *ctx, double flops)
+static void prof_direct_form(dt_ctx *ctx, double flops, double bytes)
 {
-    if (ctx->prof) ctx->prof_tab["conv_direct_form"].flops += flops;
+    if (!ctx->prof) return;
+    ctx->prof_tab["conv_direct_form"].flops += flops;
+    ctx->prof_tab["conv_direct_form"].bytes += bytes;   // in + weights + out of the reference's layer, float32
 }
 
 // ---------------------------------------------------------------------------
@@ -520,7 +522,9 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
         // that on whole tiles: 4x for F(4x4,3x3), 2.25x for F(2x2,3x3)); bytes = V + U + M'
         ProfScope ps(ctx, "conv_igemm", 2.0 * P * mt * (double)cin * N,
                      4.0 * P * ((double)mt * cin + (double)cin * N + (double)mt * N), tag);
-        prof_direct_form(ctx, 2.0 * B * H * W * 9.0 * cin * N);
+        prof_direct_form(ctx, 2.0 * B * H * W * 9.0 * cin * N,
+                         4.0 * ((double)B * H * W * cin + 9.0 * cin * N + (io.out ? (double)B * H * W * N : 0.0) +
+                                (io.out2 ? (double)B * H * W * N / 4.0 : 0.0) + (io.cstate ? 4.0 * B * H * W * N / 4.0 : 0.0)));
         int cfg = pick_cfg_gemm(w.Mt, N, P);
         if (ctx->pol.wino_cfg >= 0) cfg = ctx->pol.wino_cfg;               // A/B runs
         if (ctx->pol.wino_gn >= 0) a.tile_gn = -ctx->pol.wino_gn - 1;      // A/B runs: column-group width (see launch_conv_igemm)
@@ -584,7 +588,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
             // executed MFMA FLOPs: 16 positions x (tiles x 32 x 64) x 2; bytes: input once (+halo) and the pooled output
             ProfScope ps(ctx, "conv_fused", 2.0 * 16.0 * B * (H / 2.0) * (W / 2.0) * 32.0 * 64.0,
                          4.0 * ((double)B * H * W * 32.0 * 1.27 + (double)B * (H / 2) * (W / 2) * 64.0), tag);
-            prof_direct_form(ctx, flops);
+            prof_direct_form(ctx, flops, bytes);
             const int rc = launch_wino2_fused_pool(ctx->stream, f);
             if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused Winograd launch failed", tag);
             return DT_OK;
@@ -604,7 +608,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
     // combine deterministically; the split count minimises a simple round model
     //   time(s) ~ rounds(tiles*s) / s + 0.003*s,  rounds(n) = full rounds + cost of the partial one
     // (a half-empty round still costs ~0.6 of a full one: single workgroups per CU run faster).
-    prof_direct_form(ctx, flops);
+    prof_direct_form(ctx, flops, bytes);
     int ksplit = 1;
     if (epi == EPI_PLAIN && order == ORD_LINEAR && cfg != CFG_128x64) {
         const int tiles = ((a.M + 127) / 128) * ((L.cout + 127) / 128);
@@ -1072,7 +1076,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
         ProfScope ps(ctx, "conv_igemm", 2.0 * a.M * 9.0 * (ctx->cb + 1024) * N4,
                      4.0 * ((double)a.M * Cx + (double)a.K * N4 + (double)a.M * N4), "convlstm_xproj");
         a.npad = N4;
-        prof_direct_form(ctx, 2.0 * a.M * 9.0 * (ctx->cb + 1024) * N4);
+        prof_direct_form(ctx, 2.0 * a.M * 9.0 * (ctx->cb + 1024) * N4, 4.0 * ((double)a.M * Cx + (double)a.K * N4 + (double)a.M * N4));
         if (launch_igemm(ctx, a, 3, ORD_LINEAR, EPI_PLAIN, pick_cfg(a.M, N4, 3)))
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM input projection launch failed");
     }
@@ -1106,12 +1110,33 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
         ProfScope ps(ctx, "conv_igemm", 2.0 * a.M * (double)a.K * N4,
                      4.0 * ((double)a.M * U + (double)a.K * N4 + (double)a.M * N4 + 3.0 * a.M * U), "convlstm_step");
         a.npad = N4;
-        prof_direct_form(ctx, 2.0 * a.M * (double)a.K * N4);
+        prof_direct_form(ctx, 2.0 * a.M * (double)a.K * N4, 4.0 * ((double)a.M * U + (double)a.K * N4 + (double)a.M * N4 + 3.0 * a.M * U));
         if (launch_igemm(ctx, a, 3, ORD_LINEAR, EPI_GATES, pick_cfg(a.M, N4, 3)))
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM step launch failed");
     }
     return DT_OK;
     });
+}
+
+// the recurrent head on z [n_clips][T][G*G][Cx] (library- or caller-owned): ConvLSTM2D over T, then tconv_2
+static int track_recurrent_internal(dt_ctx *ctx, const float *z, int n_clips, int T, float *d_trk)
+{
+    const int gh = ctx->image_h / 32, gw = ctx->image_w / 32, GG = gh * gw;
+    const int F = n_clips * T, U = ctx->trk_units, Cx = ctx->trk_cx, Cb = ctx->cb;
+    float *hseq = ws_get(ctx, "trk_h", (size_t)F * GG * U * sizeof(float));
+    if (!hseq) return DT_ERR_DEVICE;
+    int rc = convlstm_sequence(ctx, z, Cx, n_clips, T, gh, gw, U, ctx->trk_wx, ctx->trk_bx, ctx->trk_wh, hseq, ctx->trk_wx_wino,
+                               ctx->trk_wh_wino);
+    if (rc) return rc;
+    float *trk = d_trk;
+    if (!trk) {
+        trk = ws_get(ctx, "trk_out", (size_t)F * GG * Cb * sizeof(float));
+        if (!trk) return DT_ERR_DEVICE;
+    }
+    // TimeDistributed(Conv2D(Cb,(1,1)))  'tconv_2'  (MultiObjDetTracker.py:182)
+    ConvLayer L;
+    L.idx = 102; L.ks = 1; L.cin = U; L.cout = Cb; L.npad = ctx->trk_wo_npad; L.wt = ctx->trk_wo; L.bias = ctx->trk_bo;
+    return run_conv(ctx, L, hseq, U, F, gh, gw, trk, Cb, ORD_LINEAR, EPI_PLAIN, 1.0f);
 }
 
 extern "C" int dt_track_forward(dt_ctx *ctx, const void *d_frames, int frames_dtype, int n_clips, int T,
@@ -1121,29 +1146,51 @@ extern "C" int dt_track_forward(dt_ctx *ctx, const void *d_frames, int frames_dt
     if (!ctx->trk_loaded) return dt_fail(ctx, DT_ERR_STATE, "tracker weights not loaded");
     if (n_clips <= 0 || T <= 0) return dt_fail(ctx, DT_ERR_ARG, "n_clips and T must be positive");
     const int gh = ctx->image_h / 32, gw = ctx->image_w / 32, GG = gh * gw;
-    const int F = n_clips * T, U = ctx->trk_units, Cx = ctx->trk_cx, Cb = ctx->cb;
+    const int F = n_clips * T, Cx = ctx->trk_cx, Cb = ctx->cb;
     float *z = ws_get(ctx, "trk_z", (size_t)F * GG * Cx * sizeof(float), /*zero_on_grow=*/true);
-    float *hseq = ws_get(ctx, "trk_h", (size_t)F * GG * U * sizeof(float));
-    if (!z || !hseq) return DT_ERR_DEVICE;
+    if (!z) return DT_ERR_DEVICE;
     int rc = detect_internal(ctx, d_frames, frames_dtype, F, Dest{z, Cx}, Dest{z + 1024, Cx});
     if (rc) return rc;
-    rc = convlstm_sequence(ctx, z, Cx, n_clips, T, gh, gw, U, ctx->trk_wx, ctx->trk_bx, ctx->trk_wh, hseq, ctx->trk_wx_wino,
-                           ctx->trk_wh_wino);
+    rc = track_recurrent_internal(ctx, z, n_clips, T, d_trk);
     if (rc) return rc;
-    float *trk = d_trk;
-    if (!trk) {
-        trk = ws_get(ctx, "trk_out", (size_t)F * GG * Cb * sizeof(float));
-        if (!trk) return DT_ERR_DEVICE;
-    }
-    {   // TimeDistributed(Conv2D(Cb,(1,1)))  'tconv_2'  (MultiObjDetTracker.py:182)
-        ConvLayer L;
-        L.idx = 102; L.ks = 1; L.cin = U; L.cout = Cb; L.npad = ctx->trk_wo_npad; L.wt = ctx->trk_wo; L.bias = ctx->trk_bo;
-        rc = run_conv(ctx, L, hseq, U, F, gh, gw, trk, Cb, ORD_LINEAR, EPI_PLAIN, 1.0f);
-        if (rc) return rc;
-    }
     if (d_det) {
         ProfScope ps(ctx, "misc", 0.0, 8.0 * F * GG * (double)Cb);
         if (launch_copy_cols(ctx->stream, z + 1024, Cx, d_det, Cb, (long long)F * GG, Cb))
+            return dt_fail(ctx, DT_ERR_DEVICE, "detection copy launch failed");
+    }
+    return DT_OK;
+}
+
+// The two halves of dt_track_forward for a FRAME-sharded deployment (BASELINE.json configs[4]):
+// every rank runs the detector on its share of the frames and emits their z rows; the rows are exchanged (RCCL
+// all-gather, 13*13*1120*4 = 757 KB per frame at 416); the owner of a clip runs the recurrence on the stitched rows.
+extern "C" int dt_track_row_width(dt_ctx *ctx)
+{
+    return (ctx && ctx->trk_loaded) ? ctx->trk_cx : 0;
+}
+
+extern "C" int dt_track_detect(dt_ctx *ctx, const void *d_frames, int frames_dtype, int n_frames, float *d_z)
+{
+    if (!ctx || !d_frames || !d_z) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (!ctx->trk_loaded) return dt_fail(ctx, DT_ERR_STATE, "tracker weights not loaded");
+    if (n_frames <= 0) return dt_fail(ctx, DT_ERR_ARG, "n_frames must be positive");
+    const int GG = (ctx->image_h / 32) * (ctx->image_w / 32), Cx = ctx->trk_cx, Cb = ctx->cb;
+    if (Cx > 1024 + Cb)   // zero the pad columns [1024+Cb, Cx) of the caller's rows (the ConvLSTM kernel reads them)
+        HIP_TRY(ctx, hipMemset2DAsync(d_z + 1024 + Cb, (size_t)Cx * sizeof(float), 0, (size_t)(Cx - 1024 - Cb) * sizeof(float),
+                                      (size_t)n_frames * GG, ctx->stream));
+    return detect_internal(ctx, d_frames, frames_dtype, n_frames, Dest{d_z, Cx}, Dest{d_z + 1024, Cx});
+}
+
+extern "C" int dt_track_recurrent(dt_ctx *ctx, const float *d_z, int n_clips, int T, float *d_trk, float *d_det)
+{
+    if (!ctx || !d_z) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (!ctx->trk_loaded) return dt_fail(ctx, DT_ERR_STATE, "tracker weights not loaded");
+    if (n_clips <= 0 || T <= 0) return dt_fail(ctx, DT_ERR_ARG, "n_clips and T must be positive");
+    int rc = track_recurrent_internal(ctx, d_z, n_clips, T, d_trk);
+    if (rc) return rc;
+    if (d_det) {
+        const int GG = (ctx->image_h / 32) * (ctx->image_w / 32);
+        if (launch_copy_cols(ctx->stream, d_z + 1024, ctx->trk_cx, d_det, ctx->cb, (long long)n_clips * T * GG, ctx->cb))
             return dt_fail(ctx, DT_ERR_DEVICE, "detection copy launch failed");
     }
     return DT_OK;

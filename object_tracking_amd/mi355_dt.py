@@ -26,6 +26,7 @@ SYMBOLS = [
     "dt_decode", "dt_bbox_iou", "dt_tracker_load", "dt_track_forward", "dt_associate",
     "dt_tiny_load", "dt_tiny_forward", "dt_tiny_features", "dt_tiny_sequence", "dt_top_box", "dt_heatmap_from_boxes", "dt_heatmap_from_xywh64", "dt_rect_from_heatmap", "dt_encode_targets", "dt_graph_enable", "dt_conv2d", "dt_convlstm_step",
     "dt_profile_enable", "dt_profile_reset", "dt_profile_read", "dt_profile_names", "dt_policy_reload", "dt_detector_extract", "dt_decode_per_frame",
+    "dt_track_row_width", "dt_track_detect", "dt_track_recurrent",
 ]
 
 _lib = None
@@ -65,6 +66,9 @@ def load_library():
     L.dt_tracker_load.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     L.dt_track_forward.argtypes = [vp, vp, ci, ci, ci, vp, vp]
     L.dt_associate.argtypes = [vp, vp, vp, ci, ci, ci, cf, vp, vp]
+    L.dt_track_row_width.argtypes = [vp]
+    L.dt_track_detect.argtypes = [vp, vp, ci, ci, vp]
+    L.dt_track_recurrent.argtypes = [vp, vp, ci, ci, vp, vp]
     L.dt_tiny_load.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, vp]
     L.dt_heatmap_from_boxes.argtypes = [vp, vp, ci, ci, vp]
     L.dt_heatmap_from_xywh64.argtypes = [vp, vp, ci, ci, vp]
@@ -295,6 +299,30 @@ class Context(object):
         self._sync_stream()
         self._check(self.lib.dt_track_forward(self.h, _dptr(frames), self._frames_dtype(frames), n_clips, T,
                                               _dptr(trk), _dptr(det)), "dt_track_forward")
+        return (trk, det) if want_det else trk
+
+    def track_row_width(self):
+        return int(self.lib.dt_track_row_width(self.h))
+
+    def track_detect(self, frames):
+        """frames [F,H,W,3] -> z rows [F,G,G,row_width] = [conv_feat | x_bbox | pad] (frame-shard half 1)."""
+        assert frames.is_cuda and frames.is_contiguous() and frames.dim() == 4
+        F = frames.shape[0]
+        gh, gw = self.grid
+        z = self._f32(F, gh, gw, self.lib.dt_track_row_width(self.h))
+        self._sync_stream()
+        self._check(self.lib.dt_track_detect(self.h, _dptr(frames), self._frames_dtype(frames), F, _dptr(z)), "dt_track_detect")
+        return z
+
+    def track_recurrent(self, z, want_det=False):
+        """z [n_clips,T,G,G,row_width] -> tracking grid [n_clips,T,G,G,NB,5+C] (frame-shard half 2)."""
+        assert z.is_cuda and z.is_contiguous() and z.dim() == 5 and z.dtype == self.torch.float32
+        n_clips, T = z.shape[:2]
+        gh, gw = self.grid
+        trk = self._f32(n_clips, T, gh, gw, self.nb_box, 5 + self.nb_class)
+        det = self._f32(n_clips, T, gh, gw, self.nb_box, 5 + self.nb_class) if want_det else None
+        self._sync_stream()
+        self._check(self.lib.dt_track_recurrent(self.h, _dptr(z), n_clips, T, _dptr(trk), _dptr(det)), "dt_track_recurrent")
         return (trk, det) if want_det else trk
 
     # ---- tiny tracker ---------------------------------------------------

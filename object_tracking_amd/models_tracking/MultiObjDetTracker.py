@@ -192,8 +192,12 @@ class MultiObjDetTracker(object):
           nids   [n_clips]          ids opened per clip
         One dt_track_forward (YOLOv2 x T, ConvLSTM recurrence, 1x1), one dt_decode
         over all frames, one dt_associate."""
+        return self.decode_and_associate(self.model.forward(frames, want_det=False), cap=cap)
+
+    def decode_and_associate(self, trk, cap=None):
+        """tracking grid [n_clips,T,G,G,BOX,5+C] (device) -> the track_clips result dict: one dt_decode over all frames
+        (OBJ_THRESHOLD / NMS_THRESHOLD may be arrays of one value per frame, clip-major), one dt_associate."""
         ctx = self.model.ctx
-        trk = self.model.forward(frames, want_det=False)
         n_clips, T = trk.shape[:2]
         flat = trk.reshape((n_clips * T,) + tuple(trk.shape[2:]))
         if cap is None:
@@ -203,6 +207,16 @@ class MultiObjDetTracker(object):
         counts = r["counts"].reshape(n_clips, T)
         ids, nids = ctx.associate(boxes, counts, self.ASSOC_THRESHOLD)
         return dict(boxes=boxes, counts=counts, ids=ids, nids=nids, netout=trk)
+
+    def empty_result(self, T, cap=None):
+        """result dict for zero clips (a rank that owns no clip in a frame-sharded run)"""
+        import torch
+        ctx = self.model.ctx
+        if cap is None:
+            cap = self.GRID_H * self.GRID_W * self.BOX
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=ctx.device)
+        return dict(boxes=z((0, T, cap, mi355_dt.DT_BOX_FLOATS), torch.float32), counts=z((0, T), torch.int32),
+                    ids=z((0, T, cap), torch.int32), nids=z((0,), torch.int32), netout=None)
 
     @staticmethod
     def boxes_from_result(res, clip=0):

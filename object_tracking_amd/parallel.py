@@ -54,33 +54,101 @@ def global_track_ids(ids, nids):
     return torch.where(ids >= 0, g, torch.full_like(g, -1))
 
 
+def _pack_rows(boxes, counts, ids, nids, n_pad):
+    """One int32 row per clip: [boxes T*cap*8 (float bits) | ids T*cap | counts T | nids | valid]; rows beyond the
+    local clips are empty (valid = 0).  One buffer -> ONE collective per step (the exchange is latency-bound)."""
+    n, T, cap = ids.shape
+    row = T * cap * 8 + T * cap + T + 2
+    buf = torch.zeros((n_pad, row), dtype=torch.int32, device=boxes.device)
+    o = 0
+    buf[:n, o:o + T * cap * 8] = boxes.contiguous().view(torch.int32).reshape(n, T * cap * 8); o += T * cap * 8
+    buf[:n, o:o + T * cap] = ids.reshape(n, T * cap); o += T * cap
+    buf[:n, o:o + T] = counts.reshape(n, T); o += T
+    buf[:n, o] = nids
+    buf[:n, o + 1] = 1
+    return buf
+
+
+def _unpack_rows(buf, T, cap):
+    keep = buf[:, -1] == 1
+    buf = buf[keep]
+    n = buf.shape[0]
+    o = 0
+    boxes = buf[:, o:o + T * cap * 8].contiguous().view(torch.float32).reshape(n, T, cap, 8); o += T * cap * 8
+    ids = buf[:, o:o + T * cap].reshape(n, T, cap).contiguous(); o += T * cap
+    counts = buf[:, o:o + T].contiguous(); o += T
+    nids = buf[:, o].contiguous()
+    return boxes, counts, ids, nids
+
+
 def gather_detections(res, n_clips_max=None, group=None):
     """Cross-stream exchange.  `res` is MultiObjDetTracker.track_clips output for
-    this rank's clips (device tensors).  Every rank must pass the same number of
-    clips or give `n_clips_max` (rows are padded with empty clips).  Returns the
-    dict for ALL clips of all ranks in global clip order with an extra `gids`
-    tensor of globally unique track ids.  Without an initialised process group
+    this rank's clips (device tensors).  Returns the dict for ALL clips of all ranks in global clip
+    order with an extra `gids` tensor of globally unique track ids.  Shards may be uneven: rows are padded to
+    `n_clips_max` clips per rank (pass it when known, e.g. ceil(total / world) -- otherwise one extra scalar
+    all-reduce finds it).  ONE all-gather of one packed buffer per step.  Without an initialised process group
     (single process) only the id globalisation is applied."""
     boxes, counts, ids, nids = res["boxes"], res["counts"], res["ids"], res["nids"]
     n_local = boxes.shape[0]
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        n_pad = n_clips_max if n_clips_max is not None else n_local
-        valid = torch.zeros((n_pad,), dtype=torch.int32, device=boxes.device)
-        valid[:n_local] = 1
-
-        def pad(t, fill):
-            if t.shape[0] == n_pad:
-                return t
-            p = torch.full((n_pad - t.shape[0],) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=t.device)
-            return torch.cat([t, p], 0)
-
-        boxes = _all_gather_cat(pad(boxes, 0.0), group)
-        counts = _all_gather_cat(pad(counts, 0), group)
-        ids = _all_gather_cat(pad(ids, -1), group)
-        nids = _all_gather_cat(pad(nids, 0), group)
-        keep = _all_gather_cat(valid, group).bool()
-        boxes, counts, ids, nids = boxes[keep], counts[keep], ids[keep], nids[keep]
+        if n_clips_max is None:
+            m = torch.tensor([n_local], dtype=torch.int64, device=boxes.device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+            n_clips_max = int(m.item())
+        T, cap = ids.shape[1], ids.shape[2]
+        allrows = _all_gather_cat(_pack_rows(boxes, counts, ids, nids, n_clips_max), group)
+        boxes, counts, ids, nids = _unpack_rows(allrows, T, cap)
     return dict(boxes=boxes, counts=counts, ids=ids, nids=nids, gids=global_track_ids(ids, nids))
+
+
+# ---- frame-shard of the detect+track path (SURVEY.md 8e row 3; BASELINE.json configs[4]) --------------------
+def frame_shard_times(T, rank, world):
+    """time steps whose DETECTOR pass runs on `rank`: t = rank, rank + world, ... (round-robin keeps every rank's
+    share within one frame of the others for any T)."""
+    return list(range(rank, T, world))
+
+
+def stitch_frame_rows(gathered, T, world):
+    """gathered [world, n_clips, Tl, ...] (rank r holds times r, r+world, ...; slots past T are padding) ->
+    [n_clips, T, ...] in time order."""
+    w, n_clips, Tl = gathered.shape[:3]
+    assert w == world
+    out = gathered.permute(1, 2, 0, *range(3, gathered.dim()))          # [n_clips, Tl, world, ...]: t = j*world + r
+    out = out.reshape((n_clips, Tl * world) + tuple(gathered.shape[3:]))
+    return out[:, :T].contiguous()
+
+
+def track_clips_frame_sharded(trk, frames, cap=None, group=None):
+    """MultiObjDetTracker on clips whose frames are spread over the ranks of `group`: ONE stream can use all GPUs.
+      1. detector (the 74 % of a frame's FLOPs) on this rank's time steps of EVERY clip (dt_track_detect),
+      2. all-gather of the per-frame rows z = [conv_feat | x_bbox] (757 KB/frame at 416x416; over xGMI this is
+         ~0.3 GB/s per GPU at 375 frames/s -- far below one link) and stitching into time order,
+      3. ConvLSTM recurrence + 1x1 + decode + association on the OWNER of each clip (contiguous block partition of
+         the clips, shard_range): the recurrence is sequential in T, so it cannot be split further,
+      4. the cross-stream detection all-gather of gather_detections.
+    `frames` [n_clips,T,H,W,3] must be the same on every rank (a rank only touches its own time steps).  Returns
+    the global table like gather_detections.  Single process: identical to track_clips + gather_detections."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return gather_detections(trk.track_clips(frames, cap=cap))
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ctx = trk.model.ctx
+    frames = trk.detector.model.to_device(frames)
+    n_clips, T = frames.shape[:2]
+    mine = frame_shard_times(T, rank, world)
+    Tl = (T + world - 1) // world
+    gh, gw = ctx.grid
+    z_local = torch.zeros((n_clips, Tl, gh, gw, ctx.track_row_width()), dtype=torch.float32, device=ctx.device)
+    if mine:
+        sub = frames[:, mine].contiguous()
+        z = ctx.track_detect(sub.reshape((n_clips * len(mine),) + tuple(frames.shape[2:])))
+        z_local[:, :len(mine)] = z.reshape((n_clips, len(mine)) + tuple(z.shape[1:]))
+    z_all = stitch_frame_rows(_all_gather_cat(z_local.unsqueeze(0), group), T, world)
+    lo, hi = shard_range(n_clips, rank, world)
+    if hi > lo:
+        res = trk.decode_and_associate(ctx.track_recurrent(z_all[lo:hi].contiguous()), cap=cap)
+    else:
+        res = trk.empty_result(T, cap)
+    return gather_detections(res, n_clips_max=(n_clips + world - 1) // world, group=group)
 
 
 def gather_frame_rows(rows_local, group=None):

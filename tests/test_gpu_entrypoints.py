@@ -185,7 +185,7 @@ def test_trainer_entry_points(tmp_path, monkeypatch):
     from models_tracking.MultiObjDetTracker import MultiObjDetTracker
     monkeypatch.chdir(tmp_path)
     os.makedirs("darknet/data"); os.makedirs("models")
-    blob = synth.synth_darknet_blob(80, head_std=0.3)
+    blob = synth.synth_darknet_blob(80, head_std=0.05)
     blob.tofile("darknet/yolov2.weights")
     rs = np.random.RandomState(8)
     imgs = {}

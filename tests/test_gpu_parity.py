@@ -627,10 +627,15 @@ def test_track_608_vs_oracle(ctx):
     r = trk.model.ctx.decode(res["netout"][0], thr, 0.45, ANCHORS, C)
     cnt = r["counts"].cpu().numpy()
     for t in range(T):
-        rows, _ = orc.decode_netout(ref_trk[t], thr[t], 0.45, ANCHORS, C)
+        rows, post = orc.decode_netout(ref_trk[t], thr[t], 0.45, ANCHORS, C)
         assert len(rows) == cnt[t]
         gb = r["boxes"][t, :cnt[t]].cpu().numpy()
-        assert np.array_equal(gb[:, 7], rows[:, 7]) and np.array_equal(gb[:, 5], rows[:, 5])
+        assert np.array_equal(gb[:, 7], rows[:, 7])
+        # label = arg-max over the post-NMS class scores: must agree wherever the oracle's best two classes are not
+        # within float32 noise of each other (this head is not peaky: ~1100 boxes per frame, some have near-ties)
+        cls = np.sort(post.reshape(-1, 5 + C)[rows[:, 7].astype(int), 5:], axis=1)
+        clear = (cls[:, -1] - cls[:, -2]) > 1e-4 * cls[:, -1]
+        assert clear.mean() > 0.99 and np.array_equal(gb[clear, 5], rows[clear, 5])
         assert box_err(gb, rows) < 1e-3
         assert len(rows) == 0 or iou_rows(gb[:, :4], rows[:, :4]).min() >= 0.999
     assert cnt.sum() > 0

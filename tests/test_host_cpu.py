@@ -276,3 +276,91 @@ def test_pack_objects_without_size_block_and_short_batches():
     assert g._bounds(0) == (0, 3)
     g.images = list(range(10))
     assert g._bounds(0) == (0, 4) and g._bounds(2) == (6, 10)
+
+
+_WORKER_FRAMESHARD = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import object_tracking_amd
+from parallel import gather_detections, global_track_ids, track_clips_frame_sharded, init_from_env, frame_shard_times
+rank, world, _ = init_from_env("gloo")
+
+class Ctx(object):                         # torch-CPU stand-in for the two halves of dt_track_forward
+    grid = (2, 3)
+    device = torch.device("cpu")
+    calls = []
+    def track_row_width(self): return 8
+    def track_detect(self, fr):            # per-frame rows: a function of that frame only
+        self.calls.append(fr.shape[0])
+        m = fr.float().mean(dim=(1, 2, 3))
+        return m.view(-1, 1, 1, 1) * torch.ones(fr.shape[0], 2, 3, 8) + torch.arange(8.0)
+    def track_recurrent(self, z):          # a recurrence over T: running sum
+        return torch.cumsum(z, dim=1)
+
+class Det(object):
+    class model(object):
+        @staticmethod
+        def to_device(x): return x
+
+class Trk(object):
+    detector = Det()
+    class model(object):
+        ctx = Ctx()
+    def decode_and_associate(self, g, cap=None):
+        n, T = g.shape[:2]
+        boxes = g.reshape(n, T, -1)[:, :, :cap * 8].reshape(n, T, cap, 8).contiguous()
+        counts = (g.reshape(n, T, -1).sum(-1) % 3).to(torch.int32)
+        ids = (boxes[..., 0] % 5).to(torch.int32)
+        nids = torch.full((n,), 5, dtype=torch.int32)
+        return dict(boxes=boxes, counts=counts, ids=ids, nids=nids, netout=g)
+    def empty_result(self, T, cap=None):
+        return dict(boxes=torch.zeros(0, T, cap, 8), counts=torch.zeros(0, T, dtype=torch.int32),
+                    ids=torch.zeros(0, T, cap, dtype=torch.int32), nids=torch.zeros(0, dtype=torch.int32), netout=None)
+    def track_clips(self, frames, cap=None):
+        n, T = frames.shape[:2]
+        z = self.model.ctx.track_detect(frames.reshape((n * T,) + tuple(frames.shape[2:])))
+        return self.decode_and_associate(self.model.ctx.track_recurrent(z.reshape(n, T, 2, 3, 8)), cap=cap)
+
+torch.manual_seed(1)
+ok = True
+for (n_clips, T) in [(3, 5), (1, 4), (4, 2)]:      # uneven time shards, fewer clips than ranks, T == world
+    frames = torch.randint(0, 255, (n_clips, T, 4, 4, 3), dtype=torch.uint8)
+    trk = Trk()
+    want = trk.track_clips(frames, cap=4)          # the single-process table, no collective
+    want["gids"] = global_track_ids(want["ids"], want["nids"])
+    Ctx.calls = []
+    got = track_clips_frame_sharded(trk, frames, cap=4)
+    ok &= all(torch.equal(got[k], want[k]) for k in ("boxes", "counts", "ids", "nids", "gids"))
+    ok &= Ctx.calls == ([n_clips * len(frame_shard_times(T, rank, world))] if frame_shard_times(T, rank, world) else [])
+print("RANK", rank, "OK" if ok else "MISMATCH", flush=True)
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+def test_frame_sharded_tracker_gloo_world2(tmp_path):
+    """configs[4] split (SURVEY.md 8e row 3): detector frame-shard {t : t mod N = r}, all-gather of the per-frame rows,
+    recurrence on the clip's owner, detection gather -- with a torch-CPU stand-in for the two library halves, two gloo
+    ranks give exactly the single-process table (also: each rank ran the detector on its own frames only)."""
+    script = tmp_path / "worker_fs.py"
+    script.write_text(_WORKER_FRAMESHARD)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29735", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "RANK %d OK" % r in o, o
+
+
+def test_gather_detections_finds_padding_itself(tmp_path):
+    """uneven shards without n_clips_max: one scalar all-reduce finds the padding"""
+    script = tmp_path / "worker_auto.py"
+    script.write_text(_WORKER.replace("out = gather_detections(res, n_clips_max=n_max)", "out = gather_detections(res)"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29737", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "RANK %d OK" % r in o, o

@@ -189,3 +189,19 @@ def test_oracle_sequence_windows_match_reference_golden(golden_dir):
         else:
             assert orc.sequence_windows(folders, T) == z["starts_%d" % i].tolist()
     assert seen_err
+
+
+def test_oracle_tracker_vs_torch_cpu_graph_mid_size():
+    """the C port against the torch-CPU (oneDNN) statement of the same graph at 128x160, T=3 -- both float32, two
+    independent convolution implementations (bench.py times the faster one as the CPU baseline)"""
+    from oracle import torch_cpu
+    from utility import synth
+    C = 12
+    layers, _ = orc.parse_darknet_blob(synth.synth_darknet_blob(C), C)
+    tw = synth.synth_tracker_weights(C)
+    x = orc.normalize_u8(synth.synth_clip(3, 128, 160, 2, seed=3))
+    a_trk, a_det = orc.tracker_forward(x, layers, tw)
+    b_trk, b_det = torch_cpu.tracker_forward(x, layers, tw)
+    for a, b in ((a_trk, b_trk), (a_det, b_det)):
+        assert a.shape == b.shape
+        assert (np.abs(a - b) / np.maximum(1.0, np.abs(a))).max() < 2e-4
