@@ -21,6 +21,7 @@ SOURCES = {
     "conv1.hip": [],
     "winograd.hip": [],
     "wino_fused.hip": [],
+    "wino4_fused.hip": [],
     "ingest.hip": [],
     "extract.hip": [],
     "decode.hip": ["-ffp-contract=off"],

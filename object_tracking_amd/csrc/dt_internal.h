@@ -111,6 +111,24 @@ struct WinoFusedArgs {
     float slope;
     float *out;          // [B][H/2][W/2][64]
 };
+// fused Winograd F(4x4,3x3) for the early wide layers (Cin 64 / 128 -> Cout 128 / 256), wino4_fused.hip
+struct Wino4FusedArgs {
+    const float *in;     // NHWC, pixel stride in_ld, frame stride in_bs
+    long long in_bs;
+    int in_ld;
+    int B, H, W, Cin, N;
+    const float *u;      // wino4_fused_pack layout
+    const float *bias;   // [N]
+    float slope;
+    float *out;          // full-resolution output (pixel stride out_ld, frame stride out_bs) or null
+    long long out_bs;
+    int out_ld;
+    float *out2;         // 2x2 max-pooled output [B][H/2][W/2][out2_ld] or null (exactly one of out / out2)
+    int out2_ld;
+    int nby, nbx;        // set by the launcher
+};
+int launch_wino4_fused(hipStream_t st, const Wino4FusedArgs &a);
+void wino4_fused_pack(const float *u36, int npad, int cin, int cout, float *dst);
 int launch_wino2_fused_pool(hipStream_t st, const WinoFusedArgs &a);
 void wino2_fused_pack(const float *hwio, const float *scale, float *dst);
 int launch_wino_input(hipStream_t st, const WinoArgs &a);
@@ -188,6 +206,7 @@ struct ConvLayer {
     float *wino = nullptr;               // device, [P][npad][cin] Winograd-domain weights (wide 3x3 layers) or null
     int wino_ts = 0;                     // their output tile size (2, 4 or 6)
     float *fused = nullptr;              // device, fused-Winograd weights (32 -> 64 pooled layer: conv_2) or null
+    float *fused4 = nullptr;             // device, fused F(4x4,3x3) weights (Cin 64/128 -> Cout 128/256: conv_3/5/6/8) or null
     float *bias = nullptr;               // device, [npad]
     float *scale = nullptr;              // device, [cout]: folded BatchNorm scale (dt_detector_extract un-folds with it) or null
     bool scale_has_zero = false;
@@ -203,6 +222,7 @@ struct Policy {
     double wino_ws_gb = 96.0;   // DT_WINO_WS_GB: V + M' workspace above this -> direct form
     int mosaic = -1;         // DT_WINO_MOSAIC: 1 never, 2/3/4 force, -1 = fewest tiles
     int fused = 1;           // DT_WINO_FUSED: 0 never / 1 from 512 workgroups / 2 always
+    int fused4 = 1;          // DT_WINO_FUSED4: the fused F(4x4) kernel of conv_3/5/6/8: 0 never / 1 from 1024 blocks / 2 always
     int wino_cfg = -1, wino_gn = -1;   // DT_WINO_CFG / DT_WINO_GN (A/B runs)
     int ksplit = 0;          // DT_KSPLIT
     int conv_cfg = -1;       // DT_CONV_CFG

@@ -200,6 +200,7 @@ extern "C" void dt_destroy(dt_ctx *ctx)
         if (ctx->layers[i].bias) (void)hipFree(ctx->layers[i].bias);
         if (ctx->layers[i].wino) (void)hipFree(ctx->layers[i].wino);
         if (ctx->layers[i].fused) (void)hipFree(ctx->layers[i].fused);
+        if (ctx->layers[i].fused4) (void)hipFree(ctx->layers[i].fused4);
         if (ctx->layers[i].scale) (void)hipFree(ctx->layers[i].scale);
     }
     float *singles[] = {ctx->conv1_w, ctx->conv1_b, ctx->lut255, ctx->anchors_dev, ctx->trk_wx, ctx->trk_bx,
@@ -283,6 +284,14 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
     }
     if (L.wino) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino); L.wino = nullptr; }
     if (L.fused) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused); L.fused = nullptr; }
+    if (L.fused4) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused4); L.fused4 = nullptr; }
+    if (ks == 3 && (cin == 64 || cin == 128) && cout % 128 == 0 && cout <= 256 && ctx->pol.wino != 0 && ctx->pol.fused4 != 0) {
+        // conv_3 / conv_5 / conv_6 / conv_8's shapes: fused F(4x4,3x3) kernel (wino4_fused.hip)
+        std::vector<float> u36((size_t)36 * L.npad * cin), uf((size_t)36 * cin * cout);
+        wino_pack_weights(4, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale, u36.data());
+        wino4_fused_pack(u36.data(), L.npad, cin, cout, uf.data());
+        if ((rc = upload(ctx, &L.fused4, uf))) return rc;
+    }
     if (ks == 3 && cin == 32 && cout == 64 && ctx->pol.wino != 0) {   // conv_2's shape: fused F(2x2,3x3) + pool kernel
         std::vector<float> uf((size_t)16 * 2 * 32 * 2 * 16);
         wino2_fused_pack(hwio, scale, uf.data());
@@ -388,6 +397,7 @@ void policy_from_env(Policy &p)
     { const char *e = getenv("DT_WINO_WS_GB"); p.wino_ws_gb = e ? atof(e) : d.wino_ws_gb; }
     p.mosaic = geti("DT_WINO_MOSAIC", d.mosaic);
     p.fused = geti("DT_WINO_FUSED", d.fused);
+    p.fused4 = geti("DT_WINO_FUSED4", d.fused4);
     p.wino_cfg = geti("DT_WINO_CFG", d.wino_cfg);
     p.wino_gn = geti("DT_WINO_GN", d.wino_gn);
     p.ksplit = geti("DT_KSPLIT", d.ksplit);
@@ -591,6 +601,27 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
             prof_direct_form(ctx, flops, bytes);
             const int rc = launch_wino2_fused_pool(ctx->stream, f);
             if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused Winograd launch failed", tag);
+            return DT_OK;
+        }
+    }
+    // conv_3/5/6/8's shapes: the fused F(4x4,3x3) kernel (V and M' stay on the CU) once there are enough 16x16-pixel
+    // blocks to fill the chip several times over; below that the unfused forms win (few, half-empty workgroups)
+    if (L.fused4 && in_ld % 4 == 0 && ((epi == EPI_PLAIN && order == ORD_LINEAR) || (epi == EPI_POOL && !((H | W) & 1)))) {
+        const long long blocks = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * (L.cout / 128);
+        if (ctx->pol.fused4 == 2 || (ctx->pol.fused4 == 1 && blocks >= 1024)) {
+            Wino4FusedArgs f;
+            memset(&f, 0, sizeof(f));
+            f.in = in; f.in_bs = a.in_bs; f.in_ld = in_ld; f.B = B; f.H = H; f.W = W; f.Cin = L.cin; f.N = L.cout;
+            f.u = L.fused4; f.bias = L.bias; f.slope = slope;
+            if (epi == EPI_POOL) { f.out2 = out; f.out2_ld = out_ld; }
+            else { f.out = out; f.out_ld = out_ld; f.out_bs = a.out_bs; }
+            // executed MFMA FLOPs: 36 positions x (whole 4x4 tiles) x Cin x N x 2; bytes: input once (+ halo 27 %) and the output
+            const double tiles = (double)B * ((H + 3) / 4) * ((W + 3) / 4);
+            ProfScope ps(ctx, "conv_fused", 2.0 * 36.0 * tiles * L.cin * L.cout,
+                         4.0 * ((double)B * H * W * L.cin * 1.27 * (L.cout / 128) + (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0)), tag);
+            prof_direct_form(ctx, flops, bytes);
+            const int rc = launch_wino4_fused(ctx->stream, f);
+            if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused F(4x4) launch failed", tag);
             return DT_OK;
         }
     }

@@ -1,0 +1,151 @@
+"""GPU suite, part 4 (-m gpu): the multi-process path on the ONE GPU a test box has.
+
+  * RCCL itself: backend "nccl" initialises and runs the collectives parallel.py uses (all_gather_into_tensor,
+    all_reduce) at world size 1; at world size 2 with both ranks on cuda:0 if RCCL accepts two ranks per device
+    (it may refuse with "Duplicate GPU detected" -- then the test is skipped with that message: an 8-GPU node is the
+    only place two RCCL ranks can really meet).
+  * frame-shard of MultiObjDetTracker (SURVEY.md 8e row 3 / BASELINE.json configs[4]): two ranks (gloo, both on
+    cuda:0) split the time axis of every clip for the detector, all-gather the rows, run the recurrence on the clip
+    owner and gather detections -- the global table must carry the SAME track ids as the single-process run.
+  * bench.py --shard frame under torch.distributed.run with two ranks.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_ranks(script, world, env_extra, port, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=timeout)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append(p.communicate()[0] + "\n<timeout>")
+    return procs, outs
+
+
+_NCCL = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import object_tracking_amd
+from parallel import _all_gather_cat, gather_detections, global_track_ids, shard_range
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+assert dist.get_backend() == "nccl"
+dev = torch.device("cuda", 0)
+x = torch.arange(6, dtype=torch.int32, device=dev).reshape(2, 3) + 100 * rank
+g = _all_gather_cat(x)                                       # all_gather_into_tensor on the device
+want = torch.cat([torch.arange(6, dtype=torch.int32).reshape(2, 3) + 100 * r for r in range(world)]).to(dev)
+ok = torch.equal(g, want)
+t = torch.tensor([float(rank + 1)], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); ok &= float(t) == world
+# the packed detection gather, uneven shards
+torch.manual_seed(0)
+N, T, cap = 5, 3, 4
+boxes = torch.rand(N, T, cap, 8, device=dev); counts = torch.randint(0, cap + 1, (N, T), dtype=torch.int32, device=dev)
+ids = torch.randint(-1, 3, (N, T, cap), dtype=torch.int32, device=dev); nids = torch.randint(1, 4, (N,), dtype=torch.int32, device=dev)
+a, b = shard_range(N, rank, world)
+out = gather_detections(dict(boxes=boxes[a:b], counts=counts[a:b], ids=ids[a:b], nids=nids[a:b]))
+ok &= torch.equal(out["boxes"], boxes) and torch.equal(out["ids"], ids) and torch.equal(out["gids"], global_track_ids(ids, nids))
+torch.cuda.synchronize()
+print("RANK", rank, "OK" if ok else "MISMATCH", flush=True)
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+def test_rccl_backend_world1(tmp_path):
+    script = tmp_path / "nccl1.py"
+    script.write_text(_NCCL)
+    procs, outs = _run_ranks(script, 1, {}, 29751)
+    assert procs[0].returncode == 0 and "RANK 0 OK" in outs[0], outs[0][-3000:]
+
+
+def test_rccl_backend_world2_on_one_device(tmp_path):
+    script = tmp_path / "nccl2.py"
+    script.write_text(_NCCL)
+    procs, outs = _run_ranks(script, 2, {}, 29753, timeout=300)
+    if all(p.returncode == 0 for p in procs):
+        assert "RANK 0 OK" in outs[0] and "RANK 1 OK" in outs[1]
+        return
+    text = "\n".join(outs)
+    refused = any(k in text for k in ("Duplicate GPU", "duplicate GPU", "invalid usage", "ncclInvalidUsage", "<timeout>"))
+    assert refused, text[-4000:]
+    pytest.skip("RCCL does not run two ranks on one device here: " + [l for l in text.splitlines() if "uplicate" in l or "nvalid" in l or "timeout" in l][:1][0][:200])
+
+
+_FRAMESHARD = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import object_tracking_amd
+from parallel import gather_detections, global_track_ids, track_clips_frame_sharded, init_from_env
+from utility import synth
+from models_tracking.MultiObjDetTracker import MultiObjDetTracker
+rank, world, _ = init_from_env()
+H = W = 96; T = 5; N = 3; C = 12                      # odd T: uneven time shards; 3 clips on 2 owners
+class Trk(MultiObjDetTracker):
+    IMAGE_H, IMAGE_W = H, W
+    GRID_H, GRID_W = 3, 3
+    SEQUENCE_LENGTH = T
+    LOAD_MODEL = False
+    OBJ_THRESHOLD = 0.3
+tw = synth.synth_tracker_weights(C); tw["out_kernel"] = tw["out_kernel"] * 40.0; tw["out_bias"][4::17] = 1.5
+trk = Trk(detector_weights=synth.synth_darknet_blob(C), tracker_weights=tw)
+frames = np.stack([synth.synth_clip(T, H, W, 2, seed=500 + i) for i in range(N)])
+out = track_clips_frame_sharded(trk, frames)
+ref = trk.track_clips(frames)
+# the two halves run the layers at other batch sizes than the one-process forward (split-K / Winograd choice): values
+# agree to rounding, everything discrete -- counts, cells, labels, track ids -- is exact
+ok = (torch.equal(out["counts"], ref["counts"]) and torch.equal(out["boxes"][..., 5], ref["boxes"][..., 5])
+      and torch.equal(out["boxes"][..., 7], ref["boxes"][..., 7])
+      and torch.allclose(out["boxes"], ref["boxes"], rtol=1e-4, atol=1e-5)
+      and torch.equal(out["ids"], ref["ids"]) and torch.equal(out["gids"], global_track_ids(ref["ids"], ref["nids"]))
+      and int(ref["counts"].sum()) > 0)
+# and the halves compose to the whole: detect + recurrent == forward, bit for bit at equal batch
+ctx = trk.model.ctx
+d = trk.detector.model.to_device(frames)
+z = ctx.track_detect(d.reshape(N * T, H, W, 3))
+halves = ctx.track_recurrent(z.reshape(N, T, 3, 3, -1))
+ok &= torch.equal(halves, ctx.track_forward(d, want_det=False))
+print("RANK", rank, "OK" if ok else "MISMATCH", int(ref["counts"].sum()), flush=True)
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+def test_frame_sharded_tracker_two_ranks_one_gpu(tmp_path):
+    script = tmp_path / "fs.py"
+    script.write_text(_FRAMESHARD)
+    procs, outs = _run_ranks(script, 2, {"DT_ONE_DEVICE": "1", "DT_DIST_BACKEND": "gloo"}, 29755)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("RANK %d OK" % r) in o, o[-3000:]
+
+
+@pytest.mark.parametrize("shard", ["clip", "frame"])
+def test_bench_two_ranks_on_one_gpu(shard):
+    """bench.py under torch.distributed.run with 2 ranks (gloo, one device): the N>1 code of both shard modes runs and
+    rank 0 prints one JSON line with the contract's keys."""
+    env = dict(os.environ, DT_ONE_DEVICE="1", DT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29757" if shard == "clip" else "29759", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--clips", "2", "--T", "4", "--size", "96", "--boxes", "4", "--shard", shard, "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == ("strong" if shard == "frame" else "weak")
+    frames_total = 2 * 4 * (1 if shard == "frame" else 2)
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - frames_total) < 1e-6 * frames_total
