@@ -1092,3 +1092,44 @@ def test_winograd_randomized_shapes_vs_oracle(ctx, monkeypatch):
         else:
             e = max(relerr(got[0].cpu().numpy(), ref), relerr(got[1].cpu().numpy(), orc.maxpool2(ref)))
         assert e < {2: 2e-5, 4: 1e-4, 6: 3e-4}[ts], (it, ts, B, H, W, Cin, Cout, pool, mos, e)
+
+
+# ---- conv_3/5/6/8 as one fused Winograd F(4x4,3x3) kernel (csrc/wino4_fused.hip) ---------------------------
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [
+    (2, 16, 16, 64, 128, 0),      # exactly one 16x16-pixel block per frame
+    (3, 32, 48, 64, 128, 1),      # pooled output only (conv_5's epilogue), several blocks
+    (1, 26, 22, 64, 128, 0),      # partial blocks and partial tiles on both edges
+    (2, 18, 34, 128, 256, 1),     # conv_8's shape class: four channel groups, two 128-wide output halves, pooled
+    (1, 13, 13, 128, 256, 0),     # odd size, smaller than a block
+    (5, 104, 104, 64, 128, 0),    # conv_3's real geometry (6.5 blocks per side)
+])
+def test_conv_fused_f4x4_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool):
+    monkeypatch.setenv("DT_WINO_FUSED4", "2")
+    rs = np.random.RandomState(B * 100 + H + W + Cin)
+    x = rs.randn(B, H, W, Cin).astype(np.float32)
+    w = (rs.randn(3, 3, Cin, Cout) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32)
+    ref = orc.conv2d(x, w, b)
+    ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
+    if pool:
+        ref = orc.maxpool2(ref)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=pool)
+    ctx.profile_enable(False)
+    assert ctx.profile_read("conv_fused")["launches"] == 1 and ctx.profile_read("wino_input")["launches"] == 0
+    assert relerr(got.cpu().numpy(), ref) < 1e-4            # F(4x4,3x3): ~15x the direct form's rounding error
+    monkeypatch.setenv("DT_WINO_FUSED4", "0")
+    other = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=pool)
+    assert relerr(got.cpu().numpy(), other.cpu().numpy()) < 2e-4
+
+
+def test_conv_fused_f4x4_one_hot(ctx, monkeypatch):
+    """one-hot taps on small integers: every position / tile offset / channel slot of the fused kernel must line up"""
+    monkeypatch.setenv("DT_WINO_FUSED4", "2")
+    B, H, W, Cin, Cout = 2, 20, 36, 64, 128
+    x = (np.arange(B * H * W * Cin, dtype=np.float32).reshape(B, H, W, Cin) % 251)
+    w = np.zeros((3, 3, Cin, Cout), dtype=np.float32)
+    for n in range(Cout):
+        w[n % 3, (n // 3) % 3, (n * 7) % Cin, n] = 1.0
+    got = ctx.conv2d(dev(x, ctx), w, None, leaky_slope=1.0, pool=0).cpu().numpy()
+    assert np.abs(got - orc.conv2d(x, w)).max() < 0.05       # integers up to 250: a misplaced tap is off by >= 1
