@@ -222,7 +222,7 @@ struct Policy {
     double wino_ws_gb = 96.0;   // DT_WINO_WS_GB: V + M' workspace above this -> direct form
     int mosaic = -1;         // DT_WINO_MOSAIC: 1 never, 2/3/4 force, -1 = fewest tiles
     int fused = 1;           // DT_WINO_FUSED: 0 never / 1 from 512 workgroups / 2 always
-    int fused4 = 1;          // DT_WINO_FUSED4: the fused F(4x4) kernel of conv_3/5/6/8: 0 never / 1 from 1024 blocks / 2 always
+    int fused4 = 1;          // DT_WINO_FUSED4: the fused F(4x4) kernel: 0 never / 1 conv_3/5 (Cin 64) from 1024 blocks / 3 also conv_6/8 / 2 always
     int wino_cfg = -1, wino_gn = -1;   // DT_WINO_CFG / DT_WINO_GN (A/B runs)
     int ksplit = 0;          // DT_KSPLIT
     int conv_cfg = -1;       // DT_CONV_CFG

@@ -608,7 +608,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
     // blocks to fill the chip several times over; below that the unfused forms win (few, half-empty workgroups)
     if (L.fused4 && in_ld % 4 == 0 && ((epi == EPI_PLAIN && order == ORD_LINEAR) || (epi == EPI_POOL && !((H | W) & 1)))) {
         const long long blocks = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * (L.cout / 128);
-        if (ctx->pol.fused4 == 2 || (ctx->pol.fused4 == 1 && blocks >= 1024)) {
+        if (ctx->pol.fused4 == 2 || ((ctx->pol.fused4 == 1 && L.cin == 64 || ctx->pol.fused4 == 3) && blocks >= 1024)) {
             Wino4FusedArgs f;
             memset(&f, 0, sizeof(f));
             f.in = in; f.in_bs = a.in_bs; f.in_ld = in_ld; f.B = B; f.H = H; f.W = W; f.Cin = L.cin; f.N = L.cout;

@@ -4,12 +4,12 @@
 # WRITE_SIZE separately; --kernel-trace only).  Outputs land in gpurun_out/<tag>/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r01}
+TAG=${1:-r02}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/pytest_gpu.txt
+  timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -25 | tee $O/pytest_gpu.txt
 fi
 timeout 600 python bench.py --layer-report $O/bench_layers.txt 2>$O/bench.err | tail -1 | tee $O/bench.json
 cd /tmp && export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-step timestamps of the fused F(4x4) kernel's persistent loop (debug build: -DDT_W4_TIMING, tools/w4_timing.sh).
+"""Timestamps inside the fused F(4x4) kernel (debug build: -DDT_W4_TIMING, tools/w4_timing.sh): workgroups 2048..2303.
    MI355_DT_LIB=.../libmi355_dt_w4tt.so python tools/w4_timing.py conv_3 480"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,23 +28,23 @@ ctx.profile_reset(); ctx.profile_enable(True)
 ctx.conv2d(x, w, b, leaky_slope=0.1, pool=pool)
 ctx.profile_enable(False)
 ms = ctx.profile_read("conv_fused")["ms"]
-buf = np.zeros(256 * 2 * 48 * 6, dtype=np.uint64)
+NS = 24
+buf = np.zeros(256 * 2 * NS * 6, dtype=np.uint64)
 assert lib.dt_debug_w4_times(buf.ctypes.data_as(ctypes.c_void_p), 0) == 0
-t = buf.reshape(256, 2, 48, 6).astype(np.int64)
-nhg = Cin // 16
-print("%s %d frames: launch %.3f ms" % (name, B, ms))
+t = buf.reshape(256, 2, NS, 6).astype(np.int64)
+nst = Cin // 8
+print("%s %d frames: launch %.3f ms; %d stages per workgroup" % (name, B, ms, nst))
 for wv, label in ((0, "wave 0 (transforms)"), (1, "wave 4")):
     tt = t[:, wv]
-    used = tt[:, :, 0] > 0
-    step = (tt[:, 1:, 0] - tt[:, :-1, 0])[used[:, 1:]]
-    tr = (tt[:, :, 1] - tt[:, :, 0])[used]
-    mf = (tt[:, :, 2] - tt[:, :, 1])[used]
-    ep = (tt[:, :, 3] - tt[:, :, 2])[used]
-    ba = (tt[:, :, 4] - tt[:, :, 3])[used]
-    # steps with an epilogue: h == nhg-1
-    idx = np.arange(48) % nhg == nhg - 1
-    epi_steps = (tt[:, :, 3] - tt[:, :, 2])[:, idx][used[:, idx]]
-    print("  %s: cycles per step %8.0f | zero+transform %7.0f | 4 K-steps %7.0f (MFMA-only bound %d for 2 waves/SIMD) | epilogue (avg over steps) %7.0f, on block-end steps %7.0f | barrier wait %7.0f" % (
-        label, step.mean(), tr.mean(), mf.mean(), 2 * 4 * 36 * 32, ep.mean(), epi_steps.mean(), ba.mean()))
-span = (t[:, 0, :, 4].max(1) - t[:, 0, 0, 0])
-print("  steps recorded per WG:", int((t[:, 0, :, 0] > 0).sum(1).mean()))
+    ok = tt[:, 0, 0] > 0
+    tt = tt[ok]
+    pro = tt[:, 0]
+    print("  %s: prologue: loads+stores %6.0f | barrier %6.0f | transform0+barrier %6.0f" % (
+        label, (pro[:, 1] - pro[:, 0]).mean(), (pro[:, 2] - pro[:, 1]).mean(), (pro[:, 3] - pro[:, 2]).mean()))
+    st = tt[:, 1:1 + nst]
+    print("     per stage: transform %6.0f | 2 K-steps %6.0f (MFMA-only bound %d) | barrier wait %6.0f | stage total %6.0f" % (
+        (st[:, :, 1] - st[:, :, 0]).mean(), (st[:, :, 2] - st[:, :, 1]).mean(), 2 * 2 * 36 * 32, (st[:, :, 3] - st[:, :, 2]).mean(),
+        (st[:, :, 3] - st[:, :, 0]).mean()))
+    ep = tt[:, 1 + nst]
+    print("     epilogue: block 0 %6.0f | block 1 %6.0f | whole workgroup %7.0f cycles (MFMA-only bound %d)" % (
+        (ep[:, 1] - ep[:, 0]).mean(), (ep[:, 2] - ep[:, 1]).mean(), (ep[:, 2] - pro[:, 0]).mean(), nst * 2 * 2 * 36 * 32))
