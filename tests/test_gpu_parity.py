@@ -605,26 +605,23 @@ def test_predict_drop_in_on_image_files(ctx, tmp_path):
 
 
 def test_track_608_vs_oracle(ctx):
-    """BASELINE.json configs[4] shape: 608x608 -> 19x19 grid (1805 cells, the decode kernel's
-    largest supported grid), C=12, one 2-frame clip through detector + ConvLSTM + 1x1 + decode."""
+    """BASELINE.json configs[4] shape, quick version (tests/test_gpu_configs.py runs 4 clips x 30 frames): 608x608 ->
+    19x19 grid (1805 cells, the decode kernel's largest supported grid), C=12, one 2-frame clip through detector +
+    ConvLSTM + 1x1 + decode, head calibrated like bench.py's (peaky class scores, ~128 candidates per frame)."""
+    import bench
     H = W = 608
     T, C = 2, 12
-    trk, blob, tw = _tracker(H, W, T, C)
-    tw = dict(tw)
-    tw["out_kernel"] = tw["out_kernel"] * 40.0
-    ob = tw["out_bias"].copy(); ob[4::17] = -1.0; tw["out_bias"] = ob
-    trk.model.set_weights(tw)
-    trk.OBJ_THRESHOLD = 0.3
+    frames = torch.from_numpy(synth.synth_clip(T, H, W, 4, seed=608)[None]).to(ctx.device)
+    trk, blob, tw = bench.build_tracker(H, W, T, 128, frames)
     layers, _ = orc.parse_darknet_blob(blob, C)
-    frames = synth.synth_clip(T, H, W, 4, seed=608)[None]
     res = trk.track_clips(frames)
-    ref_trk, _ = orc.tracker_forward(orc.normalize_u8(frames[0]), layers, tw)
+    ref_trk, _ = orc.tracker_forward(orc.normalize_u8(frames[0].cpu().numpy()), layers, tw)
     got = res["netout"][0].cpu().numpy()
     assert got.shape == (T, 19, 19, 5, 17)
     assert chan_err(flat_c(got), flat_c(ref_trk)) < NET_TOL
-    # decode with gap thresholds per frame (no oracle score / candidate-pair IoU within float noise of its threshold;
-    # this head is not peaky: ~1100 boxes and ~600,000 same-frame IoUs per frame): unconditional comparison
-    thr = np.array([gap_threshold(oracle_scores(ref_trk[t], C).ravel(), 0.3, 0.25, 0.35) for t in range(T)], dtype=np.float32)
+    # decode with gap thresholds per frame (no oracle score / candidate-pair IoU within float noise of its threshold):
+    # unconditional comparison of the box set, order, labels and coordinates
+    thr = np.array([gap_threshold(oracle_scores(ref_trk[t], C).ravel(), 0.5, 0.45, 0.55) for t in range(T)], dtype=np.float32)
     nms = np.zeros(T, dtype=np.float32)
     for t in range(T):
         cand, _ = orc.decode_netout(ref_trk[t], thr[t], 2.0, ANCHORS, C)
@@ -633,18 +630,13 @@ def test_track_608_vs_oracle(ctx):
     r = trk.model.ctx.decode(res["netout"][0], thr, nms, ANCHORS, C)
     cnt = r["counts"].cpu().numpy()
     for t in range(T):
-        rows, post = orc.decode_netout(ref_trk[t], thr[t], nms[t], ANCHORS, C)
+        rows, _ = orc.decode_netout(ref_trk[t], thr[t], nms[t], ANCHORS, C)
         assert len(rows) == cnt[t]
         gb = r["boxes"][t, :cnt[t]].cpu().numpy()
-        assert np.array_equal(gb[:, 7], rows[:, 7])
-        # label = arg-max over the post-NMS class scores: must agree wherever the oracle's best two classes are not
-        # within float32 noise of each other
-        cls = np.sort(post.reshape(-1, 5 + C)[rows[:, 7].astype(int), 5:], axis=1)
-        clear = (cls[:, -1] - cls[:, -2]) > 1e-4 * cls[:, -1]
-        assert clear.mean() > 0.99 and np.array_equal(gb[clear, 5], rows[clear, 5])
+        assert np.array_equal(gb[:, 7], rows[:, 7]) and np.array_equal(gb[:, 5], rows[:, 5])
         assert box_err(gb, rows) < 1e-3
         assert len(rows) == 0 or iou_rows(gb[:, :4], rows[:, :4]).min() >= 0.999
-    assert cnt.sum() > 0
+    assert cnt.sum() > 20
 
 
 def test_decode_nonsquare_grid_and_three_anchors(ctx):
