@@ -13,7 +13,7 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then
 fi
 timeout 600 python bench.py --layer-report $O/bench_layers.txt 2>$O/bench.err | tail -1 | tee $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/prof_stats.log 2>&1
 tail -1 $O/prof_stats.log
 python $R/tools/rocprof_summary.py stats $O/prof_stats > $O/rocprof_kernel_stats.txt 2>&1
 head -12 $O/rocprof_kernel_stats.txt
