@@ -16,7 +16,7 @@
 // sweep spread over the 64 lanes.
 #include "dt_internal.h"
 
-#define DEC_THREADS 256
+#define DEC_THREADS 1024           // 16 waves: the frame is read with few bytes in flight per thread, so more threads = shorter passes
 #define DEC_MAX_CELLS 1920        // 19*19*5 = 1805 fits; (5+16)*mc*4 B of LDS must stay under 160 KiB
 #define DEC_CHUNK_BYTES (96 * 1024)
 
@@ -65,7 +65,7 @@ __device__ __forceinline__ float wave_min(float v)
 }
 
 // block-wide exclusive prefix of a 0/1 flag, in thread order; returns prefix and total
-__device__ __forceinline__ int block_flag_scan(bool flag, int *s_wave_tot /*[4]*/, int &total)
+__device__ __forceinline__ int block_flag_scan(bool flag, int *s_wave_tot /*[DEC_THREADS / 64]*/, int &total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long bal = __ballot(flag);
@@ -97,6 +97,7 @@ struct DecodeArgs {
     float *classes;
     float *post;        // [batch][ncell][S] (user buffer or internal scratch)
     int chunk_cells;
+    int nms_waves;      // wavefronts that run the per-class NMS (each needs 4 x mc floats of LDS)
     int mc;             // ncell rounded up to 64: stride of the LDS candidate / sort arrays
     int ncp;            // NC rounded up to 4: per-class candidate counters in LDS
 };
@@ -118,10 +119,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
     const int MC = p.mc;
     int *s_cell = reinterpret_cast<int *>(smem);              // [MC]
     float *s_bx = smem + MC;                                  // [4][MC]
-    float *s_red = s_bx + 4 * MC;                             // [16]
-    int *s_tot = reinterpret_cast<int *>(s_red + 8);          // [4] (+pad)
-    int *s_ccnt = reinterpret_cast<int *>(s_red + 16);        // [ncp] candidates with a non-zero score per class
-    float *s_dyn = s_red + 16 + p.ncp;                        // chunk / sort lists
+    float *s_red = s_bx + 4 * MC;                             // [32]: per-wave max, per-wave min
+    int *s_tot = reinterpret_cast<int *>(s_red + 32);         // [16]
+    int *s_ccnt = reinterpret_cast<int *>(s_red + 48);        // [ncp] candidates with a non-zero score per class
+    float *s_dyn = s_red + 48 + p.ncp;                        // chunk / sort lists
 
     // ---- phase 1: global max / min of the class logits (utils.py:263-264) ----
     float vmax = -INFINITY, vmin = INFINITY;
@@ -129,22 +130,22 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
     for (int c = tid; c < p.ncp; c += DEC_THREADS) s_ccnt[c] = 0;
     {
         // channel of element e is e % S; advance it incrementally (DEC_THREADS % S per step) and keep
-        // four independent loads in flight instead of one dependent load + integer modulo per element
+        // eight independent loads in flight instead of one dependent load + integer modulo per element
         const int step = DEC_THREADS % S;
         int ch = tid % S;
         int e = tid;
-        for (; e + 3 * DEC_THREADS < nelem; e += 4 * DEC_THREADS) {
-            float v[4];
-            int c4[4];
+        for (; e + 7 * DEC_THREADS < nelem; e += 8 * DEC_THREADS) {
+            float v[8];
+            int c4[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 v[u] = net[e + u * DEC_THREADS];
                 c4[u] = ch;
                 ch += step;
                 if (ch >= S) ch -= S;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 8; ++u)
                 if (c4[u] >= 5) { vmax = fmaxf(vmax, v[u]); vmin = fminf(vmin, v[u]); }
         }
         for (; e < nelem; e += DEC_THREADS) {
@@ -155,10 +156,12 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
     }
     vmax = wave_max(vmax);
     vmin = wave_min(vmin);
-    if (lane == 0) { s_red[wave] = vmax; s_red[4 + wave] = vmin; }
+    if (lane == 0) { s_red[wave] = vmax; s_red[16 + wave] = vmin; }
     __syncthreads();
-    const float gmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    const float gmin = fminf(fminf(s_red[4], s_red[5]), fminf(s_red[6], s_red[7])) - gmax;  // min(x - max)
+    float gmax = s_red[0], gmn = s_red[16];
+#pragma unroll
+    for (int w = 1; w < DEC_THREADS / 64; ++w) { gmax = fmaxf(gmax, s_red[w]); gmn = fminf(gmn, s_red[16 + w]); }
+    const float gmin = gmn - gmax;  // min(x - max)
     const bool rescale = gmin < -100.0f;   // utils.py:265-266
 
     // ---- phase 2: conf / class scores / threshold, candidate boxes -----------
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
         volatile int *l_id = reinterpret_cast<volatile int *>(s_dyn + wave * (4 * MC) + MC);
         volatile float *u_sc = s_dyn + wave * (4 * MC) + 2 * MC;
         volatile int *u_id = reinterpret_cast<volatile int *>(s_dyn + wave * (4 * MC) + 3 * MC);
-        for (int c = wave; c < p.NC; c += DEC_THREADS / 64) {
+        for (int c = wave; c < p.NC && wave < p.nms_waves; c += p.nms_waves) {
             if (s_ccnt[c] < 2) continue;   // fewer than two boxes carry this class: nothing to suppress (wave-uniform)
             // gather candidates with a non-zero score for class c
             int n = 0;
@@ -335,10 +338,13 @@ int launch_decode(hipStream_t st, const float *netout, long long frame_stride, i
     a.boxes = boxes; a.counts = counts; a.classes = classes; a.post = post; a.chunk_cells = chunk;
     const int mc = ((ncell + 63) / 64) * 64;
     a.mc = mc;
-    const size_t sort_bytes = (size_t)(DEC_THREADS / 64) * 4 * mc * sizeof(float);
+    int nms_waves = (int)((96 * 1024) / ((size_t)4 * mc * sizeof(float)));
+    nms_waves = nms_waves < 1 ? 1 : (nms_waves > DEC_THREADS / 64 ? DEC_THREADS / 64 : nms_waves);
+    a.nms_waves = nms_waves;
+    const size_t sort_bytes = (size_t)nms_waves * 4 * mc * sizeof(float);
     const size_t chunk_bytes = (size_t)chunk * S * sizeof(float);
     a.ncp = (NC + 3) / 4 * 4;
-    const size_t lds = (size_t)(5 * mc + 16 + a.ncp) * sizeof(float) + (sort_bytes > chunk_bytes ? sort_bytes : chunk_bytes);
+    const size_t lds = (size_t)(5 * mc + 48 + a.ncp) * sizeof(float) + (sort_bytes > chunk_bytes ? sort_bytes : chunk_bytes);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(decode_nms_kernel),

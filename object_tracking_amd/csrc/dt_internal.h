@@ -205,6 +205,7 @@ struct ConvLayer {
     float *wt = nullptr;                 // device, packed
     float *wino = nullptr;               // device, [P][npad][cin] Winograd-domain weights (wide 3x3 layers) or null
     int wino_ts = 0;                     // their output tile size (2, 4 or 6)
+    float *wino_alt = nullptr;           // device, F(4x4) weights kept next to F(6x6) ones for small-batch launches, or null
     float *fused = nullptr;              // device, fused-Winograd weights (32 -> 64 pooled layer: conv_2) or null
     float *fused4 = nullptr;             // device, fused F(4x4,3x3) weights (Cin 64/128 -> Cout 128/256: conv_3/5/6/8) or null
     float *bias = nullptr;               // device, [npad]

@@ -199,6 +199,7 @@ extern "C" void dt_destroy(dt_ctx *ctx)
         if (ctx->layers[i].wt) (void)hipFree(ctx->layers[i].wt);
         if (ctx->layers[i].bias) (void)hipFree(ctx->layers[i].bias);
         if (ctx->layers[i].wino) (void)hipFree(ctx->layers[i].wino);
+        if (ctx->layers[i].wino_alt) (void)hipFree(ctx->layers[i].wino_alt);
         if (ctx->layers[i].fused) (void)hipFree(ctx->layers[i].fused);
         if (ctx->layers[i].fused4) (void)hipFree(ctx->layers[i].fused4);
         if (ctx->layers[i].scale) (void)hipFree(ctx->layers[i].scale);
@@ -283,6 +284,7 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
         if ((rc = upload(ctx, &L.scale, sc))) return rc;
     }
     if (L.wino) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino); L.wino = nullptr; }
+    if (L.wino_alt) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino_alt); L.wino_alt = nullptr; }
     if (L.fused) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused); L.fused = nullptr; }
     if (L.fused4) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused4); L.fused4 = nullptr; }
     if (ks == 3 && (cin == 64 || cin == 128) && cout % 128 == 0 && cout <= 256 && ctx->pol.wino != 0 && ctx->pol.fused4 != 0) {
@@ -302,6 +304,12 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
         L.wino_ts = wino_tile(ctx, false);
         rc = upload_wino(ctx, &L.wino, L.wino_ts, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale);
         if (rc) return rc;
+        // small batches of the 13x13 / 26x26 layers: F(4x4) needs 36 GEMMs of ONE (partly filled) row tile where F(6x6)
+        // needs 64 -- keep both weight sets and choose per launch (run_conv); only with the default tile policy
+        if (L.wino_ts == 6 && ctx->pol.wino_tile == 0 && cin >= 256) {
+            rc = upload_wino(ctx, &L.wino_alt, 4, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale);
+            if (rc) return rc;
+        }
     }
     return upload(ctx, &L.bias, bias);
 }
@@ -477,27 +485,37 @@ struct WinoIO {
     float *cstate; long long c_bs; int c_ld;
 };
 
+// Tile geometry of a Winograd launch.  Mosaic factor g: g x g frames with zero separators share one virtual image
+// (winograd.hip:vpixel) when that needs fewer tiles per frame (13x13 F(4x4): 12.25 instead of 16); pooled outputs need
+// frame-aligned tiles.
+struct WinoGeom { int g, th, tw, Mt; };
+static WinoGeom wino_geometry(const dt_ctx *ctx, int ts, int B, int H, int W, bool pooled)
+{
+    WinoGeom q;
+    q.g = 1;
+    const int g_env = ctx->pol.mosaic;   // 1: never (tests, A/B), 2 / 3 / 4: force
+    double best = (double)((H + ts - 1) / ts) * ((W + ts - 1) / ts);
+    for (int g = 2; g <= 4 && !pooled && g_env != 1; ++g) {
+        const double t = (double)((g * (H + 1) + ts - 1) / ts) * ((g * (W + 1) + ts - 1) / ts) / (g * g);
+        if ((t < best * 0.97 && B >= g * g) || g_env == g) { best = t; q.g = g; }
+    }
+    if (q.g == 1) { q.th = (H + ts - 1) / ts; q.tw = (W + ts - 1) / ts; q.Mt = B * q.th * q.tw; }
+    else {
+        q.th = (q.g * (H + 1) + ts - 1) / ts; q.tw = (q.g * (W + 1) + ts - 1) / ts;
+        q.Mt = ((B + q.g * q.g - 1) / (q.g * q.g)) * q.th * q.tw;
+    }
+    return q;
+}
+
 static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias, int cin, int N, int npad, int B, int H,
                     int W, const WinoIO &io, float slope, const char *tag)
 {
     WinoArgs w;
     memset(&w, 0, sizeof(w));
     w.B = B; w.H = H; w.W = W; w.ts = ts;
-    // mosaic factor g: g x g frames with zero separators share one virtual image (winograd.hip:vpixel) when
-    // that needs fewer tiles per frame (13x13: 12.25 instead of 16); pooled outputs need frame-aligned tiles
-    w.g = 1;
     {
-        const int g_env = ctx->pol.mosaic;   // 1: never (tests, A/B), 2 / 3 / 4: force
-        double best = (double)((H + ts - 1) / ts) * ((W + ts - 1) / ts);
-        for (int g = 2; g <= 4 && !io.out2 && g_env != 1; ++g) {
-            const double t = (double)((g * (H + 1) + ts - 1) / ts) * ((g * (W + 1) + ts - 1) / ts) / (g * g);
-            if ((t < best * 0.97 && B >= g * g) || g_env == g) { best = t; w.g = g; }
-        }
-    }
-    if (w.g == 1) { w.th = (H + ts - 1) / ts; w.tw = (W + ts - 1) / ts; w.Mt = B * w.th * w.tw; }
-    else {
-        w.th = (w.g * (H + 1) + ts - 1) / ts; w.tw = (w.g * (W + 1) + ts - 1) / ts;
-        w.Mt = ((B + w.g * w.g - 1) / (w.g * w.g)) * w.th * w.tw;
+        const WinoGeom q = wino_geometry(ctx, ts, B, H, W, io.out2 != nullptr);
+        w.g = q.g; w.th = q.th; w.tw = q.tw; w.Mt = q.Mt;
     }
     if (ctx->prof && !ctx->capturing) {   // which mosaic / tile size a launch took (asserted by the configuration parity tests)
         char mtag[40];
@@ -631,7 +649,17 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
         io.in = in; io.in_ld = in_ld; io.in_bs = a.in_bs;
         if (epi == EPI_POOL) { io.out2 = out; io.out2_ld = out_ld; }
         else { io.out = out; io.out_ld = out_ld; io.out_bs = a.out_bs; io.out2 = out2; io.out2_ld = out2_ld; }
-        return run_wino(ctx, L.wino, L.wino_ts, L.bias, L.cin, L.cout, L.npad, B, H, W, io, slope, tag);
+        // GEMM cost ~ positions x row tiles of 128: at small batch (one partly filled row tile either way) the 36
+        // positions of F(4x4) beat the 64 of F(6x6); from two F(4x4) row tiles up F(6x6)'s fewer rows win
+        const float *wt = L.wino;
+        int ts = L.wino_ts;
+        if (L.wino_alt) {
+            const bool pooled = io.out2 != nullptr;
+            const WinoGeom q6 = wino_geometry(ctx, 6, B, H, W, pooled), q4 = wino_geometry(ctx, 4, B, H, W, pooled);
+            const long long c6 = 64ll * ((q6.Mt + 127) / 128), c4 = 36ll * ((q4.Mt + 127) / 128);
+            if (c4 < c6 && q4.Mt <= 128) { wt = L.wino_alt; ts = 4; }      // one row tile: the regime the model was measured in
+        }
+        return run_wino(ctx, wt, ts, L.bias, L.cin, L.cout, L.npad, B, H, W, io, slope, tag);
     }
     // Wave quantisation for small batches (few frames at 13x13 / 26x26): with 512 resident
     // workgroup slots (256 CUs x 2) a layer of a few hundred output tiles leaves the chip
