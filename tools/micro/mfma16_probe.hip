@@ -1,11 +1,15 @@
 // micro-probe: issue rate of v_mfma_f32_16x16x4_f32 with 36 independent accumulators, 8 waves per CU (2 per SIMD),
-// optionally with one global_load / ds_read per MFMA interleaved.   hipcc --offload-arch=gfx950 -O3 mfma16_probe.hip -o mfma16_probe
+// with operand traffic interleaved: mode 1 = one global_load_dword per MFMA (the B stream of a fused Winograd kernel),
+// mode 8 = one ds_read2 + one global_load_dword per TWO MFMAs (wino4_fused.hip's position-split layout), for 1..32
+// private copies of the streamed buffer (same rate: the limit is per CU, not an L2 hot spot).  Measured on MI355X:
+// no operand traffic 149 TFLOP/s, mode 1 85, mode 8 110.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/mfma16_probe.hip -o tools/micro/mfma16_probe && tools/micro/mfma16_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>
-__global__ __launch_bounds__(512) void probe(const float *u, float *out, int iters)
+__global__ __launch_bounds__(512) void probe(const float *u, float *out, int iters, int ncopy)
 {
     __shared__ float lds[36 * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -15,8 +19,8 @@ __global__ __launch_bounds__(512) void probe(const float *u, float *out, int ite
 #pragma unroll
     for (int q = 0; q < 36; ++q) acc[q] = f32x4{0, 0, 0, 0};
     float b[36], a[36];
-    const float *ub = u + wave * 36 * 64 + lane;
-    const float *ub4 = u + wave * 36 * 64 + lane * 4;
+    const float *ub = u + (long long)(blockIdx.x % ncopy) * (16ll * 8 * 36 * 64) + wave * 36 * 64 + lane;
+    const float *ub4 = u + (long long)(blockIdx.x % ncopy) * (16ll * 8 * 36 * 64) + wave * 36 * 64 + lane * 4;
 #pragma unroll
     for (int q = 0; q < 36; ++q) { b[q] = ub[q * 64]; a[q] = lds[q * 256 + lane]; }
 #pragma unroll 1
@@ -56,28 +60,29 @@ __global__ __launch_bounds__(512) void probe(const float *u, float *out, int ite
 int main()
 {
     float *u, *out;
-    hipMalloc(&u, 16ll * 8 * 36 * 64 * 4 + 4096);
-    hipMemset(u, 0, 16ll * 8 * 36 * 64 * 4 + 4096);
+    hipMalloc(&u, 32 * 16ll * 8 * 36 * 64 * 4 + 4096);
+    hipMemset(u, 0, 32 * 16ll * 8 * 36 * 64 * 4 + 4096);
     hipMalloc(&out, 256 * 512 * 4 * 4);
     const int iters = 2000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 9; ++mode) {
+    for (int ncopy = 1; ncopy <= 32; ncopy *= 2)
+    for (int mode = 1; mode < 9; mode += 7) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
-            if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(256), dim3(512), 0, 0, u, out, iters);
-            if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(256), dim3(512), 0, 0, u, out, iters);
-            if (mode == 2) hipLaunchKernelGGL(probe<2>, dim3(256), dim3(512), 0, 0, u, out, iters);
-            if (mode == 3) hipLaunchKernelGGL(probe<3>, dim3(256), dim3(512), 0, 0, u, out, iters);
-            if (mode == 4) hipLaunchKernelGGL(probe<4>, dim3(256), dim3(512), 0, 0, u, out, iters);
+            if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(256), dim3(512), 0, 0, u, out, iters, ncopy);
+            if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(256), dim3(512), 0, 0, u, out, iters, ncopy);
+            if (mode == 2) hipLaunchKernelGGL(probe<2>, dim3(256), dim3(512), 0, 0, u, out, iters, ncopy);
+            if (mode == 3) hipLaunchKernelGGL(probe<3>, dim3(256), dim3(512), 0, 0, u, out, iters, ncopy);
+            if (mode == 4) hipLaunchKernelGGL(probe<4>, dim3(256), dim3(512), 0, 0, u, out, iters, ncopy);
             if (mode == 5 || mode == 7) continue;
-            if (mode == 8) hipLaunchKernelGGL(probe<8>, dim3(256), dim3(512), 0, 0, u, out, iters);
-            if (mode == 6) hipLaunchKernelGGL(probe<6>, dim3(256), dim3(512), 0, 0, u, out, iters);
+            if (mode == 8) hipLaunchKernelGGL(probe<8>, dim3(256), dim3(512), 0, 0, u, out, iters, ncopy);
+            if (mode == 6) hipLaunchKernelGGL(probe<6>, dim3(256), dim3(512), 0, 0, u, out, iters, ncopy);
             hipEventRecord(e1); hipEventSynchronize(e1);
         }
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double fl = 256.0 * 8 * iters * 36 * 16 * 16 * 4 * 2;
-        printf("mode %d (1: +global_load_dword per MFMA, 2: +ds_read per MFMA, 4: +global_load_dwordx4 per 4 MFMAs): %.3f ms  %.1f TFLOP/s\n", mode, ms, fl / ms / 1e9);
+        printf("copies %d mode %d (1: +global_load_dword per MFMA, 2: +ds_read per MFMA, 4: +global_load_dwordx4 per 4 MFMAs): %.3f ms  %.1f TFLOP/s\n", ncopy, mode, ms, fl / ms / 1e9);
     }
     return 0;
 }
