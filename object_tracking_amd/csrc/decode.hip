@@ -19,6 +19,7 @@
 #define DEC_THREADS 1024           // 16 waves: the frame is read with few bytes in flight per thread, so more threads = shorter passes
 #define DEC_MAX_CELLS 1920        // 19*19*5 = 1805 fits; (5+16)*mc*4 B of LDS must stay under 160 KiB
 #define DEC_CHUNK_BYTES (96 * 1024)
+#define DEC_NZ_CAP 4096           // kept (cell, class) scores held in LDS for the NMS (8 B each + 16 B of sort lists)
 
 __device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -64,6 +65,8 @@ __device__ __forceinline__ float wave_min(float v)
     return v;
 }
 
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
 // block-wide exclusive prefix of a 0/1 flag, in thread order; returns prefix and total
 __device__ __forceinline__ int block_flag_scan(bool flag, int *s_wave_tot /*[DEC_THREADS / 64]*/, int &total)
 {
@@ -84,6 +87,18 @@ __device__ __forceinline__ int block_flag_scan(bool flag, int *s_wave_tot /*[DEC
     return base + within;
 }
 
+#ifdef DT_DEC_TIMING
+// debug build only (tools/dec_timing.py): phase timestamps of frame 0's workgroup
+__device__ unsigned long long g_dec_times[16];
+extern "C" __attribute__((visibility("default"))) int dt_debug_dec_times(unsigned long long *dst)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dec_times), sizeof(g_dec_times)) == hipSuccess ? 0 : 1;
+}
+#define DEC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_dec_times[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DEC_STAMP(k) do { } while (0)
+#endif
+
 struct DecodeArgs {
     const float *netout;
     long long frame_stride;
@@ -100,6 +115,7 @@ struct DecodeArgs {
     int nms_waves;      // wavefronts that run the per-class NMS (each needs 4 x mc floats of LDS)
     int mc;             // ncell rounded up to 64: stride of the LDS candidate / sort arrays
     int ncp;            // NC rounded up to 4: per-class candidate counters in LDS
+    int nzcap;          // capacity of the LDS list of non-zero (cell, class) scores; more than that: NMS gathers from global memory
 };
 
 __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
@@ -114,45 +130,72 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
     const float *net = p.netout + (long long)frame * p.frame_stride;
     float *post = p.post + (long long)frame * ncell * S;
 
-    // LDS carve: candidate arrays first (persistent), then a region that is the
-    // staging chunk in phase 2 and the per-wave sort lists in phase 3.
+    // LDS carve: candidate arrays first (persistent), then a region that is the staging chunk in phase 2 and the
+    // per-class sort lists in phase 3.
     const int MC = p.mc;
-    int *s_cell = reinterpret_cast<int *>(smem);              // [MC]
-    float *s_bx = smem + MC;                                  // [4][MC]
-    float *s_red = s_bx + 4 * MC;                             // [32]: per-wave max, per-wave min
+    int *s_cell = reinterpret_cast<int *>(smem);              // [MC] cell of candidate k
+    float *s_bx = smem + MC;                                  // [4][MC] box of candidate k
+    int *s_kof = reinterpret_cast<int *>(smem + 5 * MC);      // [MC] per cell: 'any class kept' flag, then its candidate index
+    float *s_conf = smem + 6 * MC;                            // [MC] objectness of candidate k
+    float *s_red = smem + 7 * MC;                             // [32]: per-wave max, per-wave min
     int *s_tot = reinterpret_cast<int *>(s_red + 32);         // [16]
-    int *s_ccnt = reinterpret_cast<int *>(s_red + 48);        // [ncp] candidates with a non-zero score per class
-    float *s_dyn = s_red + 48 + p.ncp;                        // chunk / sort lists
+    int *s_nzn = reinterpret_cast<int *>(s_red + 48);         // [0]: number of non-zero (cell, class) scores
+    int *s_ccnt = reinterpret_cast<int *>(s_red + 64);        // [ncp] candidates with a non-zero score per class
+    int *s_coff = s_ccnt + p.ncp;                             // [ncp] start of the class's segment in the sort lists
+    int *s_cfill = s_coff + p.ncp;                            // [ncp]
+    float *s_sum = s_red + 64 + 3 * p.ncp;                    // [DEC_THREADS] softmax denominators of the chunk's cells
+    unsigned *s_nzk = reinterpret_cast<unsigned *>(s_sum + DEC_THREADS);   // [nzcap] cell | class << 11
+    float *s_nzs = reinterpret_cast<float *>(s_nzk + p.nzcap);             // [nzcap] score
+    float *s_dyn = s_nzs + p.nzcap;                           // chunk / sort lists
+    // [MC] per candidate: max over its classes of (score bits << 32 | ~class) after the NMS; takes the place of the
+    // (cell, class, score) list once that has been bucketed (8 nzcap >= 8 MC bytes: launch_decode)
+    unsigned long long *s_key = reinterpret_cast<unsigned long long *>(s_nzk);
 
+    DEC_STAMP(0);
     // ---- phase 1: global max / min of the class logits (utils.py:263-264) ----
     float vmax = -INFINITY, vmin = INFINITY;
     const int nelem = ncell * S;
-    for (int c = tid; c < p.ncp; c += DEC_THREADS) s_ccnt[c] = 0;
+    for (int c = tid; c < p.ncp; c += DEC_THREADS) { s_ccnt[c] = 0; s_cfill[c] = 0; }
+    if (tid == 0) s_nzn[0] = 0;
+    // 16-byte loads (a CU streams dword loads at ~12 B/clk only): frames are 4-byte aligned, so up to three leading
+    // elements (channels 0..2 of cell 0: never class logits) and up to three trailing ones are taken apart
+    const int head = (4 - (int)((reinterpret_cast<uintptr_t>(net) >> 2) & 3)) & 3;
     {
-        // channel of element e is e % S; advance it incrementally (DEC_THREADS % S per step) and keep
-        // eight independent loads in flight instead of one dependent load + integer modulo per element
-        const int step = DEC_THREADS % S;
-        int ch = tid % S;
-        int e = tid;
-        for (; e + 7 * DEC_THREADS < nelem; e += 8 * DEC_THREADS) {
-            float v[8];
-            int c4[8];
+        // channel of element e is e % S; advance it incrementally and keep eight independent loads in flight
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 *vp = reinterpret_cast<const f4 *>(net + head);
+        const int nvec = (nelem - head) >> 2;
+        const int step = (4 * DEC_THREADS) % S;
+        int ch = (head + 4 * tid) % S;
+        auto upd4 = [&](const f4 &v, int c0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int c = c0 + q;
+                if (c >= S) c -= S;
+                if (c >= 5) { vmax = fmaxf(vmax, v[q]); vmin = fminf(vmin, v[q]); }
+            }
+        };
+        int i = tid;
+        for (; i + 7 * DEC_THREADS < nvec; i += 8 * DEC_THREADS) {
+            f4 v[8];
+            int c8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                v[u] = net[e + u * DEC_THREADS];
-                c4[u] = ch;
+                v[u] = vp[i + u * DEC_THREADS];
+                c8[u] = ch;
                 ch += step;
                 if (ch >= S) ch -= S;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (c4[u] >= 5) { vmax = fmaxf(vmax, v[u]); vmin = fminf(vmin, v[u]); }
+            for (int u = 0; u < 8; ++u) upd4(v[u], c8[u]);
         }
-        for (; e < nelem; e += DEC_THREADS) {
-            if (ch >= 5) { const float v = net[e]; vmax = fmaxf(vmax, v); vmin = fminf(vmin, v); }
+        for (; i < nvec; i += DEC_THREADS) {
+            upd4(vp[i], ch);
             ch += step;
             if (ch >= S) ch -= S;
         }
+        const int e = head + 4 * nvec + tid;      // up to three trailing elements
+        if (e < nelem && e % S >= 5) { const float v = net[e]; vmax = fmaxf(vmax, v); vmin = fminf(vmin, v); }
     }
     vmax = wave_max(vmax);
     vmin = wave_min(vmin);
@@ -164,50 +207,105 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
     const float gmin = gmn - gmax;  // min(x - max)
     const bool rescale = gmin < -100.0f;   // utils.py:265-266
 
+    DEC_STAMP(1);
     // ---- phase 2: conf / class scores / threshold, candidate boxes -----------
+    // Per staged chunk: (a) exp / sigmoid element-parallel, (b) the softmax denominator per cell, summed in class
+    // order like the reference's row sum, (c) conf * (e / sum) and the threshold element-parallel -- kept scores also
+    // go to the LDS list the NMS reads -- (d) one thread per cell: box of a cell with any kept class, compaction.
     int ncand = 0;
+    float *const cbuf = s_dyn + ((4 - head) & 3);   // element `head` of a chunk -- 16-byte aligned in global memory -- is 16-byte aligned in LDS too
+    const unsigned c_magic = 0xFFFFFFFFu / (unsigned)p.NC + 1u;   // e2 / NC == umulhi(e2, magic) for e2 * NC < 2^32 (chunk elements < 2^15); NC == 1: identity
     for (int c0 = 0; c0 < ncell; c0 += p.chunk_cells) {
         const int cn = min(p.chunk_cells, ncell - c0);
+        const int ne = cn * S;
+        const float *src = net + (long long)c0 * S;
         __syncthreads();
-        for (int e = tid; e < cn * S; e += DEC_THREADS) s_dyn[e] = net[(long long)c0 * S + e];
+        {   // chunk_cells is a multiple of 64, so the chunk starts at the frame's alignment
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 *vp = reinterpret_cast<const f4 *>(src + head);
+            const int nvec = (ne - head) >> 2;
+            int i = tid;
+            for (; i + 3 * DEC_THREADS < nvec; i += 4 * DEC_THREADS) {
+                f4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = vp[i + u * DEC_THREADS];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *reinterpret_cast<f4 *>(cbuf + head + 4 * (i + u * DEC_THREADS)) = v[u];
+            }
+            for (; i < nvec; i += DEC_THREADS) {
+                *reinterpret_cast<f4 *>(cbuf + head + 4 * i) = vp[i];
+            }
+            if (tid < head) cbuf[tid] = src[tid];
+            const int e = head + 4 * nvec + tid;
+            if (e < ne) cbuf[e] = src[e];
+        }
         __syncthreads();
-        for (int lc0 = 0; lc0 < cn; lc0 += DEC_THREADS) {
-            const int lc = lc0 + tid;
-            bool any = false;
+        if (c0 == 0) DEC_STAMP(9);
+        const int nce = cn * p.NC;                               // class elements of the chunk: (cell lc, class c) <- e2 = lc * NC + c
+        for (int e2 = tid; e2 < nce; e2 += DEC_THREADS) {       // (a)
+            const int lc = p.NC == 1 ? e2 : (int)__umulhi((unsigned)e2, c_magic);
+            const int e = e2 + 5 * (lc + 1);                    // lc * S + 5 + c
+            float v = cbuf[e] - gmax;
+            if (rescale) v = v / gmin * -100.0f;
+            cbuf[e] = expf(v);
+        }
+        __syncthreads();
+        if (c0 == 0) DEC_STAMP(10);
+        if (tid < cn) {                                         // (b)
+            float *r = cbuf + tid * S + 5;
+            float sum = 0.0f;
+            int c = 0;
+            for (; c + 8 <= p.NC; c += 8) {                     // reads batched, adds in class order
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = r[c + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += v[u];
+            }
+            for (; c < p.NC; ++c) sum += r[c];
+            s_sum[tid] = sum;
+            r[-1] = sigmoid_ref(r[-1]);                         // utils.py:214
+            s_kof[c0 + tid] = 0;
+        }
+        __syncthreads();
+        if (c0 == 0) DEC_STAMP(11);
+        for (int e2 = tid; e2 < nce; e2 += DEC_THREADS) {       // (c)
+            const int lc = p.NC == 1 ? e2 : (int)__umulhi((unsigned)e2, c_magic);
+            const int c = e2 - lc * p.NC;
+            const int e = e2 + 5 * (lc + 1);
+            const float pr = cbuf[lc * S + 4] * (cbuf[e] / s_sum[lc]);   // :215
+            const float keep = pr > obj_thr ? pr : 0.0f;                   // :216
+            cbuf[e] = keep;
+            if (keep != 0.0f) {
+                s_kof[c0 + lc] = 1;
+                atomicAdd(&s_ccnt[c], 1);
+                const int at = atomicAdd(&s_nzn[0], 1);
+                if (at < p.nzcap) { s_nzk[at] = (unsigned)(c0 + lc) | ((unsigned)c << 11); s_nzs[at] = keep; }
+            }
+        }
+        __syncthreads();
+        if (c0 == 0) DEC_STAMP(12);
+        {                                                       // (d): chunk_cells <= DEC_THREADS
+            const int lc = tid;
+            const bool any = lc < cn && s_kof[c0 + lc] != 0;
             float bx = 0, by = 0, bw = 0, bh = 0;
-            if (lc < cn) {
-                float *r = s_dyn + lc * S;
-                const float conf = sigmoid_ref(r[4]);   // utils.py:214
-                r[4] = conf;
-                float sum = 0.0f;
-                for (int c = 0; c < p.NC; ++c) {
-                    float v = r[5 + c] - gmax;
-                    if (rescale) v = v / gmin * -100.0f;
-                    v = expf(v);
-                    r[5 + c] = v;
-                    sum += v;
-                }
-                for (int c = 0; c < p.NC; ++c) {
-                    const float pr = conf * (r[5 + c] / sum);   // :215
-                    const float keep = pr > obj_thr ? pr : 0.0f;   // :216
-                    r[5 + c] = keep;
-                    if (keep != 0.0f) { any = true; atomicAdd(&s_ccnt[c], 1); }
-                }
-                if (any) {   // :227-231
-                    const int cell = c0 + lc;
-                    const int b = cell % p.NB;
-                    const int col = (cell / p.NB) % p.GW;
-                    const int row = cell / (p.NB * p.GW);
-                    bx = ((float)col + sigmoid_ref(r[0])) / (float)p.GW;
-                    by = ((float)row + sigmoid_ref(r[1])) / (float)p.GH;
-                    bw = p.anchors[2 * b + 0] * expf(r[2]) / (float)p.GW;
-                    bh = p.anchors[2 * b + 1] * expf(r[3]) / (float)p.GH;
-                }
+            if (any) {   // :227-231
+                const float *r = cbuf + lc * S;
+                const int cell = c0 + lc;
+                const int b = cell % p.NB;
+                const int col = (cell / p.NB) % p.GW;
+                const int row = cell / (p.NB * p.GW);
+                bx = ((float)col + sigmoid_ref(r[0])) / (float)p.GW;
+                by = ((float)row + sigmoid_ref(r[1])) / (float)p.GH;
+                bw = p.anchors[2 * b + 0] * expf(r[2]) / (float)p.GW;
+                bh = p.anchors[2 * b + 1] * expf(r[3]) / (float)p.GH;
             }
             int tot;
             const int slot = ncand + block_flag_scan(any, s_tot, tot);
             if (any) {
                 s_cell[slot] = c0 + lc;
+                s_kof[c0 + lc] = slot;
+                s_conf[slot] = cbuf[lc * S + 4];
                 s_bx[0 * MC + slot] = bx;
                 s_bx[1 * MC + slot] = by;
                 s_bx[2 * MC + slot] = bw;
@@ -215,13 +313,129 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
             }
             ncand += tot;
         }
-        __syncthreads();
-        for (int e = tid; e < cn * S; e += DEC_THREADS) post[(long long)c0 * S + e] = s_dyn[e];
+        if (c0 == 0) DEC_STAMP(13);
+        {
+            float *dst = post + (long long)c0 * S;
+            for (int e = tid; e < ne; e += DEC_THREADS) dst[e] = cbuf[e];
+        }
+        if (c0 == 0) DEC_STAMP(14);
     }
     __syncthreads();   // post[] and candidate arrays visible to the whole workgroup
 
+    DEC_STAMP(2);
     // ---- phase 3: greedy NMS, one class per wavefront (utils.py:239-252) -----
-    {
+    const int nzn = s_nzn[0];
+    if (nzn <= p.nzcap) {
+        // the kept (cell, class, score) triples are in LDS: bucket them by class -- each class's segment of U is its
+        // unsorted list, the same segment of L its sorted list -- and let all 16 wavefronts take classes
+        float *u_sc0 = s_dyn;
+        int *u_id0 = reinterpret_cast<int *>(s_dyn + p.nzcap);
+        float *l_sc0 = s_dyn + 2 * p.nzcap;
+        int *l_id0 = reinterpret_cast<int *>(s_dyn + 3 * p.nzcap);
+        if (wave == 0) {   // exclusive prefix of the per-class counts
+            int running = 0;
+            for (int cb = 0; cb < p.NC; cb += 64) {
+                const int v = cb + lane < p.NC ? s_ccnt[cb + lane] : 0;
+                int inc = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(inc, o);
+                    if (lane >= o) inc += t;
+                }
+                if (cb + lane < p.NC) s_coff[cb + lane] = running + inc - v;
+                running += __builtin_amdgcn_readlane(inc, 63);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nzn; i += DEC_THREADS) {
+            const unsigned key = s_nzk[i];
+            const int c = (int)(key >> 11);
+            const int at = s_coff[c] + atomicAdd(&s_cfill[c], 1);
+            u_sc0[at] = s_nzs[i];
+            u_id0[at] = s_kof[key & 2047u];
+        }
+        __syncthreads();
+        for (int k = tid; k < ncand; k += DEC_THREADS) s_key[k] = 0ull;
+        __syncthreads();
+        for (int c = wave; c < p.NC; c += DEC_THREADS / 64) {
+            const int n = s_ccnt[c];
+            if (n == 0) continue;   // wave-uniform
+            volatile float *u_sc = u_sc0 + s_coff[c];
+            volatile int *u_id = u_id0 + s_coff[c];
+            volatile float *l_sc = l_sc0 + s_coff[c];
+            volatile int *l_id = l_id0 + s_coff[c];
+            const unsigned long long ctag = 0xFFFFFFFFull - (unsigned long long)c;   // equal scores: the lower class wins (np.argmax)
+            if (n == 1) {   // nothing to suppress
+                if (lane == 0) atomicMax(&s_key[u_id[0]], ((unsigned long long)__float_as_uint(u_sc[0]) << 32) | ctag);
+                continue;
+            }
+            if (n <= 64) {
+                // the whole class in one wavefront's registers: lane = list entry; rank by lane broadcasts, one LDS
+                // exchange into sorted order, then the greedy sweep with the suppressed set as a wave-uniform bit mask
+                const bool in = lane < n;
+                const float si = in ? u_sc[lane] : 0.0f;
+                const int ki = in ? u_id[lane] : -1;
+                int rank = 0;
+                for (int j = 0; j < n; ++j) {
+                    const float sj = readlane_f(si, j);
+                    const int kj = __builtin_amdgcn_readlane(ki, j);
+                    rank += (sj > si || (sj == si && kj > ki)) ? 1 : 0;
+                }
+                if (in) { l_sc[rank] = si; l_id[rank] = ki; }
+                const float sc = in ? l_sc[lane] : 0.0f;
+                const int kk = in ? l_id[lane] : 0;
+                const float bx = s_bx[kk], by = s_bx[MC + kk], bw = s_bx[2 * MC + kk], bh = s_bx[3 * MC + kk];
+                unsigned long long dead = 0ull;
+                for (int i = 0; i < n - 1; ++i) {
+                    if ((dead >> i) & 1ull) continue;   // wave-uniform
+                    const float ax = readlane_f(bx, i), ay = readlane_f(by, i), aw = readlane_f(bw, i), ah = readlane_f(bh, i);
+                    const bool hit = in && lane > i && bbox_iou_ref(ax, ay, aw, ah, bx, by, bw, bh) >= nms_thr;
+                    dead |= __ballot(hit);
+                    if (hit) post[(long long)s_cell[kk] * S + 5 + c] = 0.0f;   // :252
+                }
+                // survivors of this class compete for their box's label (BoundBox.get_label / get_score, utils.py:128-136)
+                if (in && !((dead >> lane) & 1ull)) atomicMax(&s_key[kk], ((unsigned long long)__float_as_uint(sc) << 32) | ctag);
+                continue;
+            }
+            // rank sort: descending score, ties -> higher candidate index first (the order within U does not matter)
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int i = i0 + lane;
+                if (i < n) {
+                    const float si = u_sc[i];
+                    const int ki = u_id[i];
+                    int rank = 0;
+                    for (int j = 0; j < n; ++j) {
+                        const float sj = u_sc[j];
+                        const int kj = u_id[j];
+                        rank += (sj > si || (sj == si && kj > ki)) ? 1 : 0;
+                    }
+                    l_sc[rank] = si;
+                    l_id[rank] = ki;
+                }
+            }
+            // greedy sweep: i sequential, j over lanes; l_sc[j] = 0 marks suppressed
+            for (int i = 0; i < n - 1; ++i) {
+                if (l_sc[i] == 0.0f) continue;   // wave-uniform
+                const int ki = l_id[i];
+                const float ax = s_bx[ki], ay = s_bx[MC + ki];
+                const float aw = s_bx[2 * MC + ki], ah = s_bx[3 * MC + ki];
+                for (int j = i + 1 + lane; j < n; j += 64) {
+                    const int kj = l_id[j];
+                    const float iou = bbox_iou_ref(ax, ay, aw, ah, s_bx[kj], s_bx[MC + kj],
+                                                   s_bx[2 * MC + kj], s_bx[3 * MC + kj]);
+                    if (iou >= nms_thr) {
+                        l_sc[j] = 0.0f;
+                        post[(long long)s_cell[kj] * S + 5 + c] = 0.0f;   // :252
+                    }
+                }
+            }
+            for (int j = lane; j < n; j += 64) {   // survivors -> label keys, as above
+                const float sc = l_sc[j];
+                if (sc != 0.0f) atomicMax(&s_key[l_id[j]], ((unsigned long long)__float_as_uint(sc) << 32) | ctag);
+            }
+        }
+    } else {
+        // more kept scores than the LDS list holds: gather each class's scores from post[] (global memory)
         // per wavefront: sorted (score,id) list + unsorted staging list, MC entries each
         volatile float *l_sc = s_dyn + wave * (4 * MC);
         volatile int *l_id = reinterpret_cast<volatile int *>(s_dyn + wave * (4 * MC) + MC);
@@ -281,6 +495,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
     }
     __syncthreads();
 
+    DEC_STAMP(3);
     // ---- phase 4: final filter, output in creation order (utils.py:255) ------
     int nout = 0;
     for (int k0 = 0; k0 < ncand; k0 += DEC_THREADS) {
@@ -288,7 +503,12 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
         bool keep = false;
         int lab = 0;
         float best = 0.0f;
-        if (k < ncand) {
+        if (k < ncand && nzn <= p.nzcap) {
+            const unsigned long long key = s_key[k];   // 0: every class of this box was suppressed -> score 0, label 0
+            best = __uint_as_float((unsigned)(key >> 32));
+            lab = key ? (int)(0xFFFFFFFFu - (unsigned)key) : 0;
+            keep = best > obj_thr;
+        } else if (k < ncand) {
             const float *r = post + (long long)s_cell[k] * S;
             best = r[5];
             for (int c = 1; c < p.NC; ++c) {
@@ -306,7 +526,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
             o[1] = s_bx[MC + k];
             o[2] = s_bx[2 * MC + k];
             o[3] = s_bx[3 * MC + k];
-            o[4] = post[(long long)cell * S + 4];
+            o[4] = s_conf[k];
             o[5] = (float)lab;
             o[6] = best;
             o[7] = (float)cell;
@@ -318,6 +538,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
         nout += tot;
     }
     if (tid == 0) p.counts[frame] = nout;
+    DEC_STAMP(4);
+#ifdef DT_DEC_TIMING
+    if (tid == 0 && frame == 0) g_dec_times[8] = (unsigned long long)ncand;
+#endif
 }
 
 int launch_decode(hipStream_t st, const float *netout, long long frame_stride, int batch, int GH, int GW, int NB,
@@ -327,24 +551,34 @@ int launch_decode(hipStream_t st, const float *netout, long long frame_stride, i
     const int S = 5 + NC;
     const int ncell = GH * GW * NB;
     if (ncell > DEC_MAX_CELLS || batch <= 0) return 2;
-    int chunk = DEC_CHUNK_BYTES / (S * (int)sizeof(float));
+    const int mc = ((ncell + 63) / 64) * 64;
+    const int ncp = (NC + 3) / 4 * 4;
+    // LDS budget: candidate arrays [7][mc], counters, softmax denominators, the list of kept (cell, class, score)
+    // triples, and one region that is the staging chunk in phase 2 and the sort lists in phase 3
+    const size_t fixed = (size_t)(7 * mc + 64 + 3 * ncp + DEC_THREADS) * sizeof(float);
+    int nzcap = DEC_NZ_CAP;
+    while (nzcap > 256 && fixed + (size_t)nzcap * 8 + (size_t)nzcap * 16 > 160 * 1024) nzcap /= 2;
+    size_t dyn = 160 * 1024 - fixed - (size_t)nzcap * 8;
+    if (dyn > DEC_CHUNK_BYTES) dyn = DEC_CHUNK_BYTES;
+    if (dyn < (size_t)nzcap * 16 || nzcap < mc) return 2;
+    int chunk = (int)((dyn - 16) / (S * sizeof(float)));   // up to three floats of alignment padding in front of the chunk
     chunk = (chunk / 64) * 64;
     if (chunk > DEC_THREADS) chunk = DEC_THREADS;
     if (chunk < 64) return 2;   // class count too large for the LDS staging chunk
+    if ((long long)chunk * S * S >= (1ll << 32)) return 2;   // range of the kernel's multiply-high division by S
     DecodeArgs a;
     a.netout = netout; a.frame_stride = frame_stride;
     a.GH = GH; a.GW = GW; a.NB = NB; a.NC = NC;
     a.obj_thr = obj_thr; a.nms_thr = nms_thr; a.frame_thr = frame_thr; a.anchors = anchors_dev; a.cap = cap;
     a.boxes = boxes; a.counts = counts; a.classes = classes; a.post = post; a.chunk_cells = chunk;
-    const int mc = ((ncell + 63) / 64) * 64;
     a.mc = mc;
-    int nms_waves = (int)((96 * 1024) / ((size_t)4 * mc * sizeof(float)));
-    nms_waves = nms_waves < 1 ? 1 : (nms_waves > DEC_THREADS / 64 ? DEC_THREADS / 64 : nms_waves);
-    a.nms_waves = nms_waves;
-    const size_t sort_bytes = (size_t)nms_waves * 4 * mc * sizeof(float);
-    const size_t chunk_bytes = (size_t)chunk * S * sizeof(float);
-    a.ncp = (NC + 3) / 4 * 4;
-    const size_t lds = (size_t)(5 * mc + 48 + a.ncp) * sizeof(float) + (sort_bytes > chunk_bytes ? sort_bytes : chunk_bytes);
+    a.ncp = ncp;
+    a.nzcap = nzcap;
+    // overflow path of the NMS (more kept scores than nzcap): per-wave lists of 4 x mc floats in the same region
+    int nms_waves = (int)(dyn / ((size_t)4 * mc * sizeof(float)));
+    if (nms_waves < 1) return 2;
+    a.nms_waves = nms_waves > DEC_THREADS / 64 ? DEC_THREADS / 64 : nms_waves;
+    const size_t lds = fixed + (size_t)nzcap * 8 + dyn;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(decode_nms_kernel),

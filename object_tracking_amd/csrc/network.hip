@@ -460,9 +460,21 @@ static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int 
 // everywhere, so the wide tile is taken whenever wave quantisation does not eat the gain.
 static int pick_cfg_gemm(int Mt, int N, int P)
 {
+    const long long t128 = (long long)P * ((Mt + 127) / 128) * ((N + 127) / 128);
+    if (t128 <= 4096) {
+        // small problems (a few frames per call): what counts is the busiest CU.  cost = rounds over the 256 CUs x tile
+        // area / relative efficiency of the tile (measured at batch 8, tools/batch8_layers.py: the 13x13 layers' 36 x 8
+        // tiles of 128x128 leave 224 CUs with one tile and 32 with two; 36 x 16 tiles of 128x64 take 112 instead of 139 us)
+        const long long t64 = (long long)P * ((Mt + 127) / 128) * ((N + 63) / 64);
+        const long long t256 = (long long)P * ((Mt + 255) / 256) * ((N + 255) / 256);
+        const double c128 = (double)((t128 + 255) / 256);
+        const double c64 = (double)((t64 + 255) / 256) * 0.5 / 0.92;
+        const double c256 = N % 256 == 0 ? (double)((t256 + 255) / 256) * 4.0 / 1.03 : 1e30;
+        if (N % 64 == 0 && c64 < c128 && c64 < c256) return CFG_128x64;
+        return c256 < c128 ? CFG_256x256 : CFG_128x128;
+    }
     if (N % 256 == 0) {
         const long long t256 = (long long)P * ((Mt + 255) / 256) * (N / 256);
-        const long long t128 = (long long)P * ((Mt + 127) / 128) * (N / 128);
         const double e256 = (double)Mt / (((Mt + 255) / 256) * 256.0) * (double)t256 / (double)(((t256 + 255) / 256) * 256);
         const double e128 = (double)Mt / (((Mt + 127) / 128) * 128.0) * (double)t128 / (double)(((t128 + 511) / 512) * 512);
         if (e256 * 1.03 > e128) return CFG_256x256;

@@ -171,9 +171,20 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_fused_kernel(Wino4FusedArgs 
 #pragma unroll
         for (int i = 0; i < 18; ++i) acc[g][i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // B operand stream of this wave: [nq][k-step][ph][wn][18][64]
+    // B operand stream of this wave: [nq][k-step][ph][wn][1152]; the 1152 floats of one K-step are the lane's operands of
+    // positions 0..15 as four float4 ([quad][lane][4]) followed by positions 16, 17 as one float2 ([lane][2]): 16-byte
+    // loads deliver the stream at a higher rate than dword loads do (tools/micro/mfma16_probe.hip: 127 vs 111 TFLOP/s)
     const int nsteps = nst * 2;
-    const float *ub = p.u + (((long long)nq * nsteps * 2 + ph) * 4 + wn) * (18 * 64) + lane;
+    const float *ub = p.u + (((long long)nq * nsteps * 2 + ph) * 4 + wn) * (18 * 64);
+    auto bload = [&](const float *src, int quad, float (&b)[18]) {     // quad 0..3: positions 4 quad ..+3; quad 4: positions 16, 17
+        if (quad < 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(src + quad * 256 + lane * 4);
+            b[4 * quad] = t[0]; b[4 * quad + 1] = t[1]; b[4 * quad + 2] = t[2]; b[4 * quad + 3] = t[3];
+        } else {
+            const float2 t = *reinterpret_cast<const float2 *>(src + 1024 + lane * 2);
+            b[16] = t.x; b[17] = t.y;
+        }
+    };
     const long long u_s = 2ll * 4 * 18 * 64;    // k-step stride
 
     float bq[18];
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_fused_kernel(Wino4FusedArgs 
 #pragma unroll
         for (int k = 0; k < NQ; ++k) pq[1][k] = nst > 1 ? quad_load(1, k) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < 18; ++i) bq[i] = ub[i * 64];
+        for (int q = 0; q < 5; ++q) bload(ub, q, bq);
 #pragma unroll
         for (int k = 0; k < NQ; ++k) quad_store(0, k, pq[0][k]);
 #pragma unroll
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_fused_kernel(Wino4FusedArgs 
 #endif
 
     // one K-step = 36 MFMAs: this wave's 18 positions x the two blocks, one B register per position (reloaded for the
-    // next K-step right after its pair of MFMAs), A operand pairs fetched from LDS six positions ahead
+    // next K-step, four positions per 16-byte load, right after the fourth's MFMAs), A operand pairs fetched from LDS six positions ahead
     auto kstep = [&](int st, int s, const float *va) {
         const int gs = st * 2 + s;
         const bool stage = st + 2 < nst && !(DT_W4_ABLATE & 8);
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(W4_THREADS) void wino4_fused_kernel(Wino4FusedArgs 
         for (int i = 0; i < 18; ++i) {
             acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i % 6], bq[i], acc[0][i], 0, 0, 0);
             acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i % 6], bq[i], acc[1][i], 0, 0, 0);
-            if (!(DT_W4_ABLATE & 1)) bq[i] = un[i * 64];
+            if (!(DT_W4_ABLATE & 1) && ((i & 3) == 3 || i == 17)) bload(un, i >> 2, bq);
             if (i + 6 < 18) fetch(i + 6, i % 6);
         }
         if (stage) {
@@ -366,7 +377,7 @@ int launch_wino4_fused(hipStream_t st, const Wino4FusedArgs &a_in)
 }
 
 // Host: u36 = wino_pack_weights(4, ...) output [36][npad][cin] (U_p[n][c]) -> the kernel's B-operand stream
-//   dst[nq][k-step][ph 2][wn 4][i 18][kq 4][16]:  element = U_{18 ph + i}[c = 4 kstep + kq][n = 64 nq + 16 wn + j]
+//   dst[nq][k-step][ph 2][wn 4][1152], 1152 = [quad 4][lane = kq*16 + j][4 positions] ++ [lane][2 positions (16, 17)]:  element = U_{18 ph + i}[c = 4 kstep + kq][n = 64 nq + 16 wn + j]
 void wino4_fused_pack(const float *u36, int npad, int cin, int cout, float *dst)
 {
     const int nsteps = cin / 4, nquart = cout / 64;
@@ -379,7 +390,9 @@ void wino4_fused_pack(const float *u36, int npad, int cin, int cout, float *dst)
                         for (int kq = 0; kq < 4; ++kq)
                             for (int j = 0; j < 16; ++j) {
                                 const int c = 4 * gs + kq, n = nq * 64 + wn * 16 + j, pos = 18 * ph + i;
-                                dst[((((((size_t)nq * nsteps + gs) * 2 + ph) * 4 + wn) * 18 + i) * 4 + kq) * 16 + j] =
+                                const int ln = kq * 16 + j;
+                                const size_t off = i < 16 ? (size_t)(i >> 2) * 256 + ln * 4 + (i & 3) : (size_t)1024 + ln * 2 + (i - 16);
+                                dst[((((size_t)nq * nsteps + gs) * 2 + ph) * 4 + wn) * 1152 + off] =
                                     u36[(size_t)pos * plane + (size_t)n * cin + c];
                             }
 }

@@ -150,6 +150,33 @@ def test_decode_batch_vs_oracle(ctx, G, C, n_obj, B):
         assert np.all(np.diff(got[:, 7]) > 0), "creation (row,col,b) order"
 
 
+@pytest.mark.parametrize("C,thr", [(3, 1e-4), (20, 1e-4), (80, 2e-3)])
+def test_decode_dense_low_threshold(ctx, C, thr):
+    """Thousands of kept (cell, class) scores per frame: C=3 fills the kernel's LDS score list almost to its capacity
+    (845 x 3 of 4096: per-class lists of 845 boxes), C=20 overflows it (16.9 k: the NMS gathers from global memory
+    instead), C=80 at 2e-3 is a mix across frames.  Same boxes, order and surviving scores as the oracle."""
+    B, G = 3, 13
+    rs = np.random.RandomState(77 + C)
+    grids = rs.randn(B, G, G, 5, 5 + C).astype(np.float32)
+    grids[..., 4] -= 2.0
+    grids[..., 2:4] *= 0.5
+    r = ctx.decode(dev(grids, ctx), thr, 0.45, ANCHORS, C, want_post=True)
+    counts = r["counts"].cpu().numpy()
+    boxes = r["boxes"].cpu().numpy()
+    post = r["post"].cpu().numpy()
+    kept = 0
+    for i in range(B):
+        rows, opost = orc.decode_netout(grids[i], thr, 0.45, ANCHORS, C)
+        kept += int((opost[..., 5:] > 0).sum())
+        assert counts[i] == len(rows) and len(rows) > 100
+        got = boxes[i, :counts[i]]
+        assert np.array_equal(got[:, 5], rows[:, 5]) and np.array_equal(got[:, 7], rows[:, 7])
+        np.testing.assert_allclose(got[:, :7], rows[:, :7], rtol=2e-6, atol=1e-6)
+        assert np.array_equal(post[i][..., 5:] > 0, opost[..., 5:] > 0), "suppressed set differs"
+        np.testing.assert_allclose(post[i], opost, rtol=2e-6, atol=1e-7)
+    print("decode dense: C=%d, %d scores survive NMS in %d frames" % (C, kept, B))
+
+
 def test_decode_properties_full_size(ctx):
     """Size-independent properties on 64 frames of the 19x19 / 128-object case:
     batch invariance, cap truncation keeps a prefix, survivors are above threshold,

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(512) void probe(const float *u, float *out, int ite
 #pragma unroll
     for (int q = 0; q < 36; ++q) { b[q] = ub[q * 64]; a[q] = lds[q * 256 + lane]; }
 #pragma unroll 1
-    for (int it = 0; it < (MODE == 8 ? 0 : iters); ++it) {
+    for (int it = 0; it < (MODE >= 8 ? 0 : iters); ++it) {
         const float *un = ub + (long long)((it + 1) & 15) * 8 * 36 * 64;
 #pragma unroll
         for (int q = 0; q < 36; ++q) {
@@ -51,6 +51,27 @@ __global__ __launch_bounds__(512) void probe(const float *u, float *out, int ite
             }
         }
     }
+    if (MODE == 16) {     // position split, B as dwordx4: one load per 8 MFMAs (18 positions = 4 quads + 1 pair)
+#pragma unroll 1
+        for (int it = 0; it < iters; ++it) {
+            const float *un = ub4 + (long long)((it + 1) & 15) * 8 * 36 * 64;
+            const float *va = lds + ((it & 1) * 18) * 256 + lane;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                const float x0 = va[i * 256], x1 = va[i * 256 + 128];
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, b[i], acc[i], 0, 0, 0);
+                acc[18 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, b[i], acc[18 + i], 0, 0, 0);
+                if ((i & 3) == 3) {
+                    const f32x4 t = *reinterpret_cast<const f32x4 *>(un + (i >> 2) * 256);
+                    b[i - 3] = t[0]; b[i - 2] = t[1]; b[i - 1] = t[2]; b[i] = t[3];
+                }
+                if (i == 17) {
+                    const float2 t = *reinterpret_cast<const float2 *>(un + 4 * 256 - 2 * lane);
+                    b[16] = t.x; b[17] = t.y;
+                }
+            }
+        }
+    }
     float s = 0;
 #pragma unroll
     for (int q = 0; q < 36; ++q) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
@@ -66,8 +87,9 @@ int main()
     const int iters = 2000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int ncopy = 1; ncopy <= 32; ncopy *= 2)
-    for (int mode = 1; mode < 9; mode += 7) {
+    const int modes[] = {0, 1, 4, 8, 16};
+    for (int ncopy = 1; ncopy <= 32; ncopy *= 32)
+    for (int mode : modes) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(256), dim3(512), 0, 0, u, out, iters, ncopy);
@@ -77,6 +99,7 @@ int main()
             if (mode == 4) hipLaunchKernelGGL(probe<4>, dim3(256), dim3(512), 0, 0, u, out, iters, ncopy);
             if (mode == 5 || mode == 7) continue;
             if (mode == 8) hipLaunchKernelGGL(probe<8>, dim3(256), dim3(512), 0, 0, u, out, iters, ncopy);
+            if (mode == 16) hipLaunchKernelGGL(probe<16>, dim3(256), dim3(512), 0, 0, u, out, iters, ncopy);
             if (mode == 6) hipLaunchKernelGGL(probe<6>, dim3(256), dim3(512), 0, 0, u, out, iters, ncopy);
             hipEventRecord(e1); hipEventSynchronize(e1);
         }
