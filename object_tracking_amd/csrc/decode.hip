@@ -65,6 +65,19 @@ __device__ __forceinline__ float wave_min(float v)
     return v;
 }
 
+// maximum of an unsigned value over the 64 lanes (wave-uniform result): four DPP row shifts leave each row's maximum in
+// its last lane (lanes shifted in from outside a row read 0), four lane reads and scalar max finish
+__device__ __forceinline__ unsigned wave_umax_dpp(unsigned v)
+{
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 15), b = (unsigned)__builtin_amdgcn_readlane((int)v, 31);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 47), d = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+    return max(max(a, b), max(c, d));
+}
+
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 // block-wide exclusive prefix of a 0/1 flag, in thread order; returns prefix and total
@@ -644,21 +657,27 @@ __global__ __launch_bounds__(64) void associate_kernel(const float *boxes, const
         __builtin_amdgcn_wave_barrier();
         for (int i = 0; i < n; ++i) {
             const float ax = cb[i], ay = cb[cap + i], aw = cb[2 * cap + i], ah = cb[3 * cap + i], al = cb[4 * cap + i];
-            float best = -1.0f;
-            int bj = 0x7fffffff;
-            for (int j = lane; j < np; j += 64) {
-                if (pid[j] < 0 || pb[4 * cap + j] != al) continue;      // claimed, or another label
-                const float iou = bbox_iou_ref(ax, ay, aw, ah, pb[j], pb[cap + j], pb[2 * cap + j], pb[3 * cap + j]);
-                if (iou >= thr && iou > best) { best = iou; bj = j; }   // ascending j per lane: keeps lowest j on ties
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ob = __shfl_xor(best, o);
-                const int oj = __shfl_xor(bj, o);
-                if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+            // best = largest IoU among the unclaimed same-label boxes of the previous frame, ties -> lowest j.  Per chunk
+            // of 64 candidates: key = IoU bits + 1 (0 = not eligible; IoU >= 0, so the bit pattern orders like the value),
+            // wave maximum by DPP row shifts + four lane reads, lowest lane holding it by ballot; a later chunk must be
+            // strictly better to replace an earlier one.
+            unsigned bestk = 0u;
+            int bj = 0;
+            for (int j0 = 0; j0 < np; j0 += 64) {
+                const int j = j0 + lane;
+                unsigned key = 0u;
+                if (j < np && pid[j] >= 0 && pb[4 * cap + j] == al) {
+                    const float iou = bbox_iou_ref(ax, ay, aw, ah, pb[j], pb[cap + j], pb[2 * cap + j], pb[3 * cap + j]);
+                    if (iou >= thr) key = __float_as_uint(iou) + 1u;
+                }
+                const unsigned m = wave_umax_dpp(key);
+                if (m > bestk) {
+                    bestk = m;
+                    bj = j0 + __ffsll((long long)__ballot(key == m)) - 1;
+                }
             }
             int my_id;
-            if (best >= 0.0f) {
+            if (bestk != 0u) {
                 my_id = pid[bj];
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0) pid[bj] = -1;            // claimed

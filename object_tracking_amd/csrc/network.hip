@@ -597,6 +597,10 @@ static int pick_cfg(int M, int cout, int ks)
         const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
         if (e256 * 1.05 > e128) return CFG_256x256;
     }
+    // 1x1 layers over a whole batch (short K, thousands of row tiles): the 256-row tile halves the weight staging per
+    // MFMA -- conv_7 2.43 -> 2.33, conv_10/12 2.19/2.14 -> 2.10/2.05, conv_15/17 2.03/2.01 -> 1.97/1.93 ms per 1440
+    // frames; 256x256 is worse for N = 512 and unusable for N = 128
+    if (ks == 1 && cout >= 128 && (long long)((M + 255) / 256) * ((cout + 127) / 128) >= 4096) return CFG_256x128;
     return CFG_128x128;
 }
 
