@@ -3,17 +3,9 @@
 //   -> folded BatchNorm -> LeakyReLU(0.1) -> MaxPooling2D(2,2)
 // (models_detection/KerasYOLO.py:278-282).
 //
-// Cin = 3, K = 27: not a dense contraction worth an MFMA tile, and the frame is
-// read exactly once -- this is a direct convolution on the packed-FMA VALU path.  A
-// workgroup owns an 8x8 tile of POOLED output pixels (16x16 conv pixels, 18x18x3 input
-// patch staged in LDS as RGBx float4, uint8 -> float through a 256-entry table so that
-// the result equals the reference's float64 x/255. rounded to float32).  Wave = one group
-// of 8 output channels, lane = pooled pixel: the 27 x 8 weights of a wave are wave-uniform,
-// so they arrive through scalar loads and feed v_pk_fma_f32 from SGPRs -- no LDS reads
-// for weights in the inner loop (the first version read them from LDS per thread and
-// spent half its cycles there).  4 conv positions x 8 channels accumulate in registers,
-// the 2x2 max is taken in registers; the four waves of a workgroup complete each pixel's
-// 128-byte NHWC line.
+// Cin = 3, K = 27 and the frame is read exactly once.  A workgroup walks 8x8-POOLED-pixel tiles (16x16 conv pixels,
+// 18x18x3 input patch) along a row of the frame; uint8 -> float goes through a 256-entry table so that the result
+// equals the reference's float64 x/255. rounded to float32.
 #include "dt_internal.h"
 
 struct Conv1Args {
@@ -25,97 +17,127 @@ struct Conv1Args {
     const float *lut;    // [256]
     float slope;
     float *out;          // [B][H/2][W/2][32]
+    int tpw;             // tiles a workgroup walks along x
 };
 
-__global__ __launch_bounds__(256) void conv1_direct_kernel(Conv1Args p)
+// K = 27 is short, but the fp32 MFMA peak equals the packed-FMA peak and an MFMA is ONE issue slot per 64 cycles: the
+// staging, table and epilogue instructions of the other waves run beside it instead of competing for the VALU (the
+// round-1 kernel -- v_pk_fma_f32 with the weights as SGPR operands, lane = pooled pixel -- took 6.0 ms per 1440
+// frames = 45 % of the VALU peak; this one 4.8 ms).  v_mfma_f32_32x32x2_f32: row = conv pixel,
+// column = output channel, k = (ky,kx,ci) padded to 28 -> 14 MFMAs per group of 32 pixels.  A group is one pooled row
+// (two conv rows x 16 pixels) ordered so that rows 4w..4w+3 of the MFMA are the 2x2 pooling window w: a lane's four
+// accumulators (4h + 8j .. +3) are then exactly one window of its channel -- the max is taken in registers and a
+// wave-instruction stores two pooled pixels x 32 channels (2 x 128 B).  The patch lies in LDS as three planes
+// (lanes walk x: conflict-free b32 reads), one read per MFMA; the 14 B operands (weights) live in registers.
+#define C1_PL 328            // plane stride (18 x 18 = 324, padded)
+#define C1_TPW 26            // most tiles a workgroup walks along x: the next tile's pixels are in flight during this tile's MFMAs
+
+__global__ __launch_bounds__(256) void conv1_mfma_kernel(Conv1Args p)
 {
-    __shared__ __attribute__((aligned(16))) float s_patch[18 * 18 * 4];
+    __shared__ float s_plane[3 * C1_PL];
     __shared__ float s_lut[256];
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H2 = p.H >> 1, W2 = p.W >> 1;
-    const int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z;
-    const int cy0 = by * 16 - 1, cx0 = bx * 16 - 1;   // patch origin in input pixels
+    const int by = blockIdx.y, b = blockIdx.z;
+    const int ntx = (W2 + 7) / 8;
+    const int bx_first = blockIdx.x * p.tpw;
+    const int bx_last = min(bx_first + p.tpw, ntx);
+    const int cy0 = by * 16 - 1;                      // patch origin row in input pixels
 
-    s_lut[tid] = p.lut[tid];          // 256 threads, 256 entries: the x/255 table moves to LDS once per workgroup
-    __syncthreads();
-    for (int i = tid; i < 18 * 18; i += 256) {
-        const int r = i / 18, c = i - r * 18;
-        const int y = cy0 + r, x = cx0 + c;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-        if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
-            const long long off = (((long long)b * p.H + y) * p.W + x) * 3;
-            if (p.dtype == DT_FRAMES_U8) {
-                const unsigned char *s = reinterpret_cast<const unsigned char *>(p.frames) + off;
-                v0 = s_lut[s[0]]; v1 = s_lut[s[1]]; v2 = s_lut[s[2]];
-            } else {
-                const float *s = reinterpret_cast<const float *>(p.frames) + off;
-                v0 = s[0]; v1 = s[1]; v2 = s[2];
+    s_lut[tid] = p.lut[tid];
+
+    // patch pixels of this thread: i0 = tid, i1 = tid + 256 (< 324 for tid < 68)
+    const int r0 = tid / 18, c0 = tid - r0 * 18;
+    const int i1 = tid + 256, r1 = i1 / 18, c1 = i1 - r1 * 18;
+    const bool has1 = i1 < 18 * 18;
+    const int y0 = cy0 + r0, y1 = cy0 + r1;
+    const bool yok0 = y0 >= 0 && y0 < p.H, yok1 = has1 && y1 >= 0 && y1 < p.H;
+    const long long row0 = ((long long)b * p.H + y0) * p.W, row1 = ((long long)b * p.H + y1) * p.W;
+    float raw[2][3];      // u8 frames: the bytes as floats' bit patterns (table index); f32 frames: the values
+    auto fetch = [&](int bx) {
+        const int x0 = bx * 16 - 1 + c0, x1 = bx * 16 - 1 + c1;
+        const bool ok0 = yok0 && x0 >= 0 && x0 < p.W, ok1 = yok1 && x1 >= 0 && x1 < p.W;
+        if (p.dtype == DT_FRAMES_U8) {
+            const unsigned char *f = reinterpret_cast<const unsigned char *>(p.frames);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                raw[0][c] = __int_as_float(ok0 ? (int)f[(row0 + x0) * 3 + c] : -1);
+                raw[1][c] = __int_as_float(ok1 ? (int)f[(row1 + x1) * 3 + c] : -1);
+            }
+        } else {
+            const float *f = reinterpret_cast<const float *>(p.frames);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                raw[0][c] = ok0 ? f[(row0 + x0) * 3 + c] : 0.0f;
+                raw[1][c] = ok1 ? f[(row1 + x1) * 3 + c] : 0.0f;
             }
         }
-        f32x4 v = {v0, v1, v2, 0.f};
-        *reinterpret_cast<f32x4 *>(&s_patch[i * 4]) = v;
-    }
-    __syncthreads();
-
-    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);   // channel group (8 channels): wave-uniform
-    const int pp = tid & 63;                                  // pooled pixel in tile
-    const int py = pp >> 3, px = pp & 7;
-    const float *wg = p.w + g * 8;                            // uniform address -> scalar loads
-
-    float in[4][4][3];
+    };
+    auto stage = [&]() {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_patch[((2 * py + r) * 18 + 2 * px + c) * 4]);
-            in[r][c][0] = v[0]; in[r][c][1] = v[1]; in[r][c][2] = v[2];
+        for (int c = 0; c < 3; ++c) {
+            float v0 = raw[0][c], v1 = raw[1][c];
+            if (p.dtype == DT_FRAMES_U8) {
+                const int q0 = __float_as_int(v0), q1 = __float_as_int(v1);
+                v0 = q0 >= 0 ? s_lut[q0] : 0.0f;
+                v1 = q1 >= 0 ? s_lut[q1] : 0.0f;
+            }
+            s_plane[c * C1_PL + tid] = v0;
+            if (has1) s_plane[c * C1_PL + i1] = v1;
         }
+    };
 
-    float acc[4][8];
+    // lane geometry: MFMA row m = lane & 31 -> window w = m >> 2, (dy, dx) = (m >> 1) & 1, m & 1; k half h = lane >> 5
+    const int m = lane & 31, h = lane >> 5, n = lane & 31;
+    const int px0 = 2 * (m >> 2) + (m & 1), dy = (m >> 1) & 1;
+    float bw[14];
+    int aoff[14];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[q][c] = 0.0f;
+    for (int s = 0; s < 14; ++s) {
+        const int k0 = 2 * s, k1 = 2 * s + 1;                   // compile-time per step; the lane half picks one
+        const int o0 = (k0 % 3) * C1_PL + (k0 / 9) * 18 + (k0 / 3) % 3;
+        const int o1 = k1 < 27 ? (k1 % 3) * C1_PL + (k1 / 9) * 18 + (k1 / 3) % 3 : 0;
+        aoff[s] = (h ? o1 : o0) + dy * 18 + px0;
+        const int k = h ? k1 : k0;
+        bw[s] = k < 27 ? p.w[k * 32 + n] : 0.0f;               // k = 27: the zero row of the padded K
+    }
+    const float bias = p.bias[n];
 
+    fetch(bx_first);
+    __syncthreads();                                            // the x/255 table is in LDS
+    for (int bx = bx_first; bx < bx_last; ++bx) {
+        stage();
+        __syncthreads();
+        if (bx + 1 < bx_last) fetch(bx + 1);                    // in flight under the MFMAs below
+        {
+            const float *pa = s_plane + (4 * wave) * 18;        // pooled rows g = 2 wave, 2 wave + 1 of the tile: two independent MFMA chains
+            f32x16 acc0, acc1;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+            for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+            for (int s = 0; s < 14; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[aoff[s]], bw[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[aoff[s] + 36], bw[s], acc1, 0, 0, 0);
+            }
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                const int t = (ky * 3 + kx) * 3 + ci;
-                const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wg + t * 32);
-                const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wg + t * 32 + 4);
+            for (int gi = 0; gi < 2; ++gi) {
+                const int oy = by * 8 + wave * 2 + gi;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float x = in[(q >> 1) + ky][(q & 1) + kx][ci];
+                for (int j = 0; j < 4; ++j) {                   // window w = h + 2 j
+                    float mx = -INFINITY;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        acc[q][c] = __fmaf_rn(x, w0[c], acc[q][c]);
-                        acc[q][4 + c] = __fmaf_rn(x, w1[c], acc[q][4 + c]);
+                    for (int q = 0; q < 4; ++q) {
+                        float v = (gi ? acc1[4 * j + q] : acc0[4 * j + q]) + bias;
+                        v = v > 0.0f ? v : v * p.slope;
+                        mx = fmaxf(mx, v);
                     }
+                    const int ox = bx * 8 + h + 2 * j;
+                    if (oy < H2 && ox < W2) p.out[(((long long)b * H2 + oy) * W2 + ox) * 32 + n] = mx;
                 }
             }
-
-    const int oy = by * 8 + py, ox = bx * 8 + px;
-    if (oy < H2 && ox < W2) {
-        f32x4 o0, o1;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float bv = p.bias[g * 8 + c];
-            float m = -INFINITY;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v = acc[q][c] + bv;
-                v = v > 0.0f ? v : v * p.slope;
-                m = fmaxf(m, v);
-            }
-            if (c < 4) o0[c] = m; else o1[c - 4] = m;
         }
-        float *o = p.out + ((((long long)b * H2 + oy) * W2 + ox) * 32 + g * 8);
-        *reinterpret_cast<f32x4 *>(o) = o0;
-        *reinterpret_cast<f32x4 *>(o + 4) = o1;
+        __syncthreads();                                        // every wave is done reading the planes
     }
 }
 
@@ -127,7 +149,14 @@ int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, in
     a.frames = frames; a.dtype = dtype; a.B = B; a.H = H; a.W = W;
     a.w = w_packed; a.bias = bias; a.lut = lut; a.slope = slope; a.out = out;
     const int H2 = H / 2, W2 = W / 2;
-    dim3 grid((unsigned)((W2 + 7) / 8), (unsigned)((H2 + 7) / 8), (unsigned)B);
-    hipLaunchKernelGGL(conv1_direct_kernel, grid, dim3(256), 0, st, a);
+    // whole rows per workgroup when there are thousands of rows (the walk hides each tile's load latency); with a few
+    // frames per call shorter walks keep every CU busy
+    const long long rows = (long long)B * ((H2 + 7) / 8);
+    const int ntx = (W2 + 7) / 8;
+    int tpw = C1_TPW;
+    while (tpw > 1 && rows * ((ntx + tpw - 1) / tpw) < 2048) tpw = (tpw + 1) / 2;
+    a.tpw = tpw;
+    const dim3 grid((unsigned)((ntx + tpw - 1) / tpw), (unsigned)((H2 + 7) / 8), (unsigned)B);
+    hipLaunchKernelGGL(conv1_mfma_kernel, grid, dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
