@@ -16,6 +16,9 @@
 // only adds, subtracts and halves).  Wave = 32 tiles x 32 output channels, four waves per workgroup.
 #include "dt_internal.h"
 
+#ifndef WF_ABLATE
+#define WF_ABLATE 0                  // timing-only ablation builds (tools/ablate_wf.sh): 1 no B reloads (-6.5 %), 2 no A formation (-2 %); both at once lets the compiler fold the positions
+#endif
 #define WF_T 8                       // tiles per workgroup side
 #define WF_P (2 * WF_T + 2)          // patch side in pixels (18)
 #define WF_C 32                      // input channels
@@ -101,7 +104,8 @@ __global__ __launch_bounds__(256, 2) void wino2_fused_pool_kernel(WinoFusedArgs 
         f32x4 bn[4], vn[4];
         if (pos < 15) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bn[q] = wf_ld4(ub + (pos + 1) * ustride + q * 4);
+            for (int q = 0; q < 4; ++q) bn[q] = (WF_ABLATE & 1) ? bq[q] : wf_ld4(ub + (pos + 1) * ustride + q * 4);
+            if (WF_ABLATE & 2) { for (int q = 0; q < 4; ++q) vn[q] = vq[q]; } else
             form_v(pos + 1, vn);
         }
         // At = [[1,1,1,0],[0,1,-1,-1]]: Y[a][c] += At[a][xi] * At[c][nu] * M'
