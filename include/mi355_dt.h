@@ -102,7 +102,8 @@ DT_API int dt_ingest_resize(dt_ctx *ctx, const uint8_t *d_src, int n, int src_h,
 
 /* ---- decode_netout + NMS (utility/utils.py:208-257) -------------------- */
 /*   d_netout  [batch, GH, GW, NB, 5+NC]  raw logits (NOT modified)
- *   d_boxes   [batch, cap, DT_BOX_FLOATS] surviving boxes in (row,col,b) order
+ *   d_boxes   [batch, cap, DT_BOX_FLOATS] surviving boxes in (row,col,b) order; rows from
+ *             min(count, cap) on are zero-filled (the buffer may be uninitialised)
  *   d_counts  [batch] int32: number of survivors (may exceed cap; extra dropped)
  *   d_classes [batch, cap, NC] post-NMS class scores per box (may be NULL)
  *   d_post    [batch, GH, GW, NB, 5+NC] the reference's in-place-mutated netout

@@ -551,6 +551,11 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
         nout += tot;
     }
     if (tid == 0) p.counts[frame] = nout;
+    {   // rows past the last box read as zero (callers may hand over uninitialised memory)
+        const int first = min(nout, p.cap) * DT_BOX_FLOATS, total = p.cap * DT_BOX_FLOATS;
+        float *o = p.boxes + (long long)frame * total;
+        for (int e = first + tid; e < total; e += DEC_THREADS) o[e] = 0.0f;
+    }
     DEC_STAMP(4);
 #ifdef DT_DEC_TIMING
     if (tid == 0 && frame == 0) g_dec_times[8] = (unsigned long long)ncand;

@@ -242,8 +242,8 @@ class Context(object):
         assert S == 5 + nb_class
         if cap is None:
             cap = GH * GW * NB
-        boxes = t.zeros((B, cap, DT_BOX_FLOATS), dtype=t.float32, device=self.device)
-        counts = t.zeros((B,), dtype=t.int32, device=self.device)
+        boxes = t.empty((B, cap, DT_BOX_FLOATS), dtype=t.float32, device=self.device)   # the kernel zero-fills rows >= count
+        counts = t.empty((B,), dtype=t.int32, device=self.device)
         classes = t.zeros((B, cap, nb_class), dtype=t.float32, device=self.device) if want_classes else None
         post = t.empty_like(netout) if want_post else None
         keep, ap = _hptr(anchors)
