@@ -255,17 +255,31 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
         __syncthreads();
         if (c0 == 0) DEC_STAMP(9);
         const int nce = cn * p.NC;                               // class elements of the chunk: (cell lc, class c) <- e2 = lc * NC + c
+        // (p) objectness first: conf * softmax <= conf, so a cell with conf <= threshold keeps no class whatever its
+        // logits are -- its scores are written as 0 without evaluating a single exp (most cells of a frame)
+        if (tid < cn) {
+            float *r = cbuf + tid * S;
+            const float conf = sigmoid_ref(r[4]);               // utils.py:214
+            r[4] = conf;
+            s_sum[tid] = conf > obj_thr ? 0.0f : -1.0f;         // < 0: no class of this cell can pass
+            s_kof[c0 + tid] = 0;
+        }
+        __syncthreads();
         for (int e2 = tid; e2 < nce; e2 += DEC_THREADS) {       // (a)
             const int lc = p.NC == 1 ? e2 : (int)__umulhi((unsigned)e2, c_magic);
             const int e = e2 + 5 * (lc + 1);                    // lc * S + 5 + c
-            float v = cbuf[e] - gmax;
-            if (rescale) v = v / gmin * -100.0f;
-            cbuf[e] = expf(v);
+            float v = 0.0f;
+            if (s_sum[lc] >= 0.0f) {                            // (nearly) wave-uniform: 64 lanes span one or two cells at NC = 80
+                v = cbuf[e] - gmax;
+                if (rescale) v = v / gmin * -100.0f;
+                v = expf(v);
+            }
+            cbuf[e] = v;
         }
         __syncthreads();
         if (c0 == 0) DEC_STAMP(10);
-        if (tid < cn) {                                         // (b)
-            float *r = cbuf + tid * S + 5;
+        if (tid < cn && s_sum[tid] >= 0.0f) {                   // (b)
+            const float *r = cbuf + tid * S + 5;
             float sum = 0.0f;
             int c = 0;
             for (; c + 8 <= p.NC; c += 8) {                     // reads batched, adds in class order
@@ -276,17 +290,17 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
                 for (int u = 0; u < 8; ++u) sum += v[u];
             }
             for (; c < p.NC; ++c) sum += r[c];
-            s_sum[tid] = sum;
-            r[-1] = sigmoid_ref(r[-1]);                         // utils.py:214
-            s_kof[c0 + tid] = 0;
+            s_sum[tid] = sum;                                   // >= 0 (or NaN, which is not < 0: the cell is still scored, like the reference)
         }
         __syncthreads();
         if (c0 == 0) DEC_STAMP(11);
         for (int e2 = tid; e2 < nce; e2 += DEC_THREADS) {       // (c)
             const int lc = p.NC == 1 ? e2 : (int)__umulhi((unsigned)e2, c_magic);
+            const float sum = s_sum[lc];
+            if (sum < 0.0f) continue;                           // its class entries are already 0
             const int c = e2 - lc * p.NC;
             const int e = e2 + 5 * (lc + 1);
-            const float pr = cbuf[lc * S + 4] * (cbuf[e] / s_sum[lc]);   // :215
+            const float pr = cbuf[lc * S + 4] * (cbuf[e] / sum);           // :215
             const float keep = pr > obj_thr ? pr : 0.0f;                   // :216
             cbuf[e] = keep;
             if (keep != 0.0f) {
