@@ -145,8 +145,8 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_in
     const int cq_n = p.C / V;
     const long long items = (long long)p.Mt * cq_n;
     const long long plane = (long long)p.Mt * p.C;
-    for (long long it = (long long)blockIdx.x * WINO_THREADS + threadIdx.x; it < items;
-         it += (long long)gridDim.x * WINO_THREADS) {
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (long long)gridDim.x * blockDim.x) {
         const int tile = (int)(it / cq_n);
         const int c = (int)(it - (long long)tile * cq_n) * V;
         const TileId t = tile_id(p, tile);
@@ -221,8 +221,8 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
     const int nq = p.N / V;
     const long long items = (long long)p.Mt * nq;
     const long long plane = (long long)p.Mt * p.m_ld;
-    for (long long it = (long long)blockIdx.x * WINO_THREADS + threadIdx.x; it < items;
-         it += (long long)gridDim.x * WINO_THREADS) {
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (long long)gridDim.x * blockDim.x) {
         const int tile = (int)(it / nq);
         const int c = (int)(it - (long long)tile * nq) * V;
         const TileId t = tile_id(p, tile);
@@ -280,8 +280,8 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
     const int uq = U / V;
     const long long items = (long long)p.Mt * uq;
     const long long plane = (long long)p.Mt * p.m_ld;
-    for (long long it = (long long)blockIdx.x * WINO_THREADS + threadIdx.x; it < items;
-         it += (long long)gridDim.x * WINO_THREADS) {
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+         it += (long long)gridDim.x * blockDim.x) {
         const int tile = (int)(it / uq);
         const int jc = (int)(it - (long long)tile * uq) * V;          // hidden channel
         const int col = (jc >> 5) * 128 + (jc & 31);                  // column of gate i; f,c,o at +32,+64,+96
@@ -323,9 +323,14 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
     }
 }
 
+// Workgroup size: 256 threads, or one wavefront per workgroup when the whole launch has fewer than 512 x 256 work items
+// (a few frames per call): the transforms are bound by what ONE CU can stream, so the same threads spread over four
+// times as many CUs finish sooner (batch-8 forward: 26 transform launches).
+static unsigned wino_threads(long long items) { return items < 512ll * WINO_THREADS ? 64u : (unsigned)WINO_THREADS; }
 static unsigned wino_blocks(long long items)
 {
-    long long nb = (items + WINO_THREADS - 1) / WINO_THREADS;
+    const long long th = wino_threads(items);
+    long long nb = (items + th - 1) / th;
     const long long cap = 256 * 32;   // 32 workgroups of 256 threads per CU's worth of grid; grid-stride beyond
     if (nb > cap) nb = cap;
     return (unsigned)(nb < 1 ? 1 : nb);
@@ -337,13 +342,13 @@ int launch_wino_input(hipStream_t st, const WinoArgs &a)
 {
     if (a.C % 4 || a.in_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4 && a.ts != 6) || a.g < 1) return 2;
     if (a.ts == 6)
-        hipLaunchKernelGGL((wino_input_kernel<6, 2>), dim3(wino_blocks((long long)a.Mt * (a.C / 2))), dim3(WINO_THREADS), 0,
+        hipLaunchKernelGGL((wino_input_kernel<6, 2>), dim3(wino_blocks((long long)a.Mt * (a.C / 2))), dim3(wino_threads((long long)a.Mt * (a.C / 2))), 0,
                            st, a);
     else if (a.ts == 2)
-        hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.C / 4))), dim3(WINO_THREADS), 0,
+        hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.C / 4))), dim3(wino_threads((long long)a.Mt * (a.C / 4))), 0,
                            st, a);
     else   // 188 VGPRs, two waves per SIMD: still 7 % faster than <4,2> (1 KiB per wave per plane store)
-        hipLaunchKernelGGL((wino_input_kernel<4, 4>), dim3(wino_blocks((long long)a.Mt * (a.C / 4))), dim3(WINO_THREADS), 0,
+        hipLaunchKernelGGL((wino_input_kernel<4, 4>), dim3(wino_blocks((long long)a.Mt * (a.C / 4))), dim3(wino_threads((long long)a.Mt * (a.C / 4))), 0,
                            st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -354,25 +359,22 @@ int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates)
     if (gates) {
         if (a.N % 128 || a.out_ld % 4 || a.c_ld % 4 || a.xp_ld % 4) return 2;
         if (a.ts == 6)
-            hipLaunchKernelGGL((wino_output_gates_kernel<6, 1>), dim3(wino_blocks((long long)a.Mt * (a.N / 4))),
-                               dim3(WINO_THREADS), 0, st, a);
+            hipLaunchKernelGGL((wino_output_gates_kernel<6, 1>), dim3(wino_blocks((long long)a.Mt * (a.N / 4))), dim3(wino_threads((long long)a.Mt * (a.N / 4))), 0, st, a);
         else if (a.ts == 2)
-            hipLaunchKernelGGL((wino_output_gates_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.N / 16))),
-                               dim3(WINO_THREADS), 0, st, a);
+            hipLaunchKernelGGL((wino_output_gates_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.N / 16))), dim3(wino_threads((long long)a.Mt * (a.N / 16))), 0, st, a);
         else
-            hipLaunchKernelGGL((wino_output_gates_kernel<4, 1>), dim3(wino_blocks((long long)a.Mt * (a.N / 4))),
-                               dim3(WINO_THREADS), 0, st, a);
+            hipLaunchKernelGGL((wino_output_gates_kernel<4, 1>), dim3(wino_blocks((long long)a.Mt * (a.N / 4))), dim3(wino_threads((long long)a.Mt * (a.N / 4))), 0, st, a);
     } else {
         // vector stores need aligned rows; ragged N (conv_23-like heads) never takes this path
         if (a.N % 4 || (a.out && a.out_ld % 4) || (a.out2 && a.out2_ld % 4)) return 2;
         if (a.ts == 6)
-            hipLaunchKernelGGL((wino_output_kernel<6, 2>), dim3(wino_blocks((long long)a.Mt * (a.N / 2))), dim3(WINO_THREADS),
+            hipLaunchKernelGGL((wino_output_kernel<6, 2>), dim3(wino_blocks((long long)a.Mt * (a.N / 2))), dim3(wino_threads((long long)a.Mt * (a.N / 2))),
                                0, st, a);
         else if (a.ts == 2)
-            hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.N / 4))), dim3(WINO_THREADS),
+            hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.N / 4))), dim3(wino_threads((long long)a.Mt * (a.N / 4))),
                                0, st, a);
         else   // <4,4> measured equal
-            hipLaunchKernelGGL((wino_output_kernel<4, 2>), dim3(wino_blocks((long long)a.Mt * (a.N / 2))), dim3(WINO_THREADS),
+            hipLaunchKernelGGL((wino_output_kernel<4, 2>), dim3(wino_blocks((long long)a.Mt * (a.N / 2))), dim3(wino_threads((long long)a.Mt * (a.N / 2))),
                                0, st, a);
     }
     return hipGetLastError() == hipSuccess ? 0 : 1;
