@@ -29,6 +29,17 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+/* thread count of the OpenMP loops below (bench.py's cpu_baseline leg picks the count that is fastest on the host;
+ * 0 = OpenMP's default).  Results do not depend on it: every output element is computed by one thread. */
+#ifdef _OPENMP
+#include <omp.h>
+ORC_API void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+ORC_API int orc_max_threads(void) { return omp_get_max_threads(); }
+#else
+ORC_API void orc_set_threads(int n) { (void)n; }
+ORC_API int orc_max_threads(void) { return 1; }
+#endif
+
 /* utility/utils.py:150-153  normalize(): image / 255.  (numpy float64 divide,
  * cast to float32 at the Keras input boundary, KerasYOLO.py:527-531). */
 ORC_API void orc_normalize_u8(const uint8_t *img, int64_t n, float *out)

@@ -49,7 +49,14 @@ def lib():
         _LIB.orc_bbox_iou.restype = ctypes.c_float
         _LIB.orc_decode_netout.restype = ctypes.c_int
         _LIB.orc_associate_clip.restype = ctypes.c_int
+        _LIB.orc_max_threads.restype = ctypes.c_int
     return _LIB
+
+
+def set_threads(n):
+    """OpenMP thread count of the C loops (0 keeps the default); returns the count in effect."""
+    lib().orc_set_threads(int(n))
+    return int(lib().orc_max_threads())
 
 
 def _f(a):
