@@ -26,6 +26,9 @@
 #include "dt_internal.h"
 
 #define WINO_THREADS 256
+#ifndef DT_WINO_NT
+#define DT_WINO_NT 3   // 1: M' loads, 2: activation stores of the output transform as streaming accesses (bench: 13.95 -> 13.25 ms per step)
+#endif
 
 template <int V> struct VecOf;
 template <> struct VecOf<1> { typedef float T; };
@@ -39,6 +42,23 @@ template <int V> __device__ __forceinline__ typename VecOf<V>::T vload(const flo
 template <int V> __device__ __forceinline__ void vstore(float *p, typename VecOf<V>::T v)
 {
     *reinterpret_cast<typename VecOf<V>::T *>(p) = v;
+}
+// streaming variants (DT_WINO_NT build switch, A/B): data that is read exactly once / not re-read by this kernel
+template <int V> __device__ __forceinline__ typename VecOf<V>::T vload_nt(const float *p)
+{
+#if DT_WINO_NT & 1
+    return __builtin_nontemporal_load(reinterpret_cast<const typename VecOf<V>::T *>(p));
+#else
+    return vload<V>(p);
+#endif
+}
+template <int V> __device__ __forceinline__ void vstore_nt(float *p, typename VecOf<V>::T v)
+{
+#if DT_WINO_NT & 2
+    __builtin_nontemporal_store(v, reinterpret_cast<typename VecOf<V>::T *>(p));
+#else
+    vstore<V>(p, v);
+#endif
 }
 template <int V> __device__ __forceinline__ float lane_of(const typename VecOf<V>::T &v, int e) { return v[e]; }
 template <> __device__ __forceinline__ float lane_of<1>(const float &v, int) { return v; }
@@ -197,7 +217,7 @@ __device__ __forceinline__ void wino_at_m_a(const float *src, long long plane, t
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) m[i][j] = vload<V>(src + (long long)(NI * i + j) * plane);
+        for (int j = 0; j < NI; ++j) m[i][j] = vload_nt<V>(src + (long long)(NI * i + j) * plane);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {   // At m : down the columns
         T col[NI];
@@ -245,7 +265,7 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
                 for (int j = 0; j < TS; ++j) {
                     int b, h, w;
                     if (vpixel(p, t.grp, TS * t.ty + i, TS * t.tx + j, b, h, w))
-                        vstore<V>(p.out + (long long)b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c, m[i][j]);
+                        vstore_nt<V>(p.out + (long long)b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c, m[i][j]);
                 }
         }
         if (p.out2) {   // MaxPooling2D(2,2): H and W are even whenever the reference pools; g == 1 (launcher)
