@@ -27,7 +27,8 @@
 
 #define WINO_THREADS 256
 #ifndef DT_WINO_NT
-#define DT_WINO_NT 3   // 1: M' loads, 2: activation stores of the output transform as streaming accesses (bench: 13.95 -> 13.25 ms per step)
+#define DT_WINO_NT 7   // streaming (nontemporal) accesses, A/B per bit: 1 M' loads, 2 activation stores of the output transform (13.95 -> 13.25 ms
+                       // per step), 4 V stores of the input transform (-0.2 ms); 8 = activation loads of the input transform: slower (halo re-reads)
 #endif
 
 template <int V> struct VecOf;
@@ -58,6 +59,22 @@ template <int V> __device__ __forceinline__ void vstore_nt(float *p, typename Ve
     __builtin_nontemporal_store(v, reinterpret_cast<typename VecOf<V>::T *>(p));
 #else
     vstore<V>(p, v);
+#endif
+}
+template <int V> __device__ __forceinline__ void vstore_v(float *p, typename VecOf<V>::T v)   // V planes (A/B bit 4)
+{
+#if DT_WINO_NT & 4
+    __builtin_nontemporal_store(v, reinterpret_cast<typename VecOf<V>::T *>(p));
+#else
+    vstore<V>(p, v);
+#endif
+}
+template <int V> __device__ __forceinline__ typename VecOf<V>::T vload_in(const float *p)     // activations (A/B bit 8)
+{
+#if DT_WINO_NT & 8
+    return __builtin_nontemporal_load(reinterpret_cast<const typename VecOf<V>::T *>(p));
+#else
+    return vload<V>(p);
 #endif
 }
 template <int V> __device__ __forceinline__ float lane_of(const typename VecOf<V>::T &v, int e) { return v[e]; }
@@ -177,7 +194,7 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_in
             for (int j = 0; j < NI; ++j) {
                 int b, h, w;
                 const bool ok = vpixel(p, t.grp, TS * t.ty - 1 + i, TS * t.tx - 1 + j, b, h, w);
-                d[i][j] = ok ? vload<V>(p.in + (long long)b * p.in_bs + (long long)(h * p.W + w) * p.in_ld + c) : vzero<V>();
+                d[i][j] = ok ? vload_in<V>(p.in + (long long)b * p.in_bs + (long long)(h * p.W + w) * p.in_ld + c) : vzero<V>();
             }
         }
         // Bt d : down the columns
@@ -196,7 +213,7 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_in
         for (int i = 0; i < NI; ++i) {
             bt_1d<TS>(d[i]);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) vstore<V>(dst + (long long)(NI * i + j) * plane, d[i][j]);
+            for (int j = 0; j < NI; ++j) vstore_v<V>(dst + (long long)(NI * i + j) * plane, d[i][j]);
         }
     }
 }
