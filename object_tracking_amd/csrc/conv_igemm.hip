@@ -760,6 +760,7 @@ static int launch_cfg(hipStream_t st, const ConvArgs &a, int cfg)
     // extra live state of the tile loop costs them registers).
     constexpr bool P = (KS == 1 && ORDER == ORD_LINEAR && EPI == EPI_PLAIN) && DT_GLDS && DT_BK == 32;
     if (cfg == CFG_128x64) return launch_one<KS, 128, 64, 4, 1, ORDER, EPI, P>(st, a);
+    if (cfg == CFG_64x128) return launch_one<KS, 64, 128, 2, 2, ORDER, EPI, P>(st, a);       // few rows (a handful of Winograd tiles)
     if (cfg == CFG_256x128) return launch_one<KS, 256, 128, 4, 2, ORDER, EPI, P>(st, a);   // 8 waves, 1 workgroup per CU
     if (cfg == CFG_256x256) return launch_one<KS, 256, 256, 4, 4, ORDER, EPI, P>(st, a);   // 16 waves, 1 workgroup per CU
     return launch_one<KS, 128, 128, 2, 2, ORDER, EPI, P>(st, a);
@@ -777,7 +778,7 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
     else a.tile_gn = gn_env >= 0 ? gn_env : ((ks == 3 && epi != EPI_GATES) ? 1 : 2);
     // a caller-forced tile configuration (Policy::conv_cfg: A/B runs and the tests that exercise every
     // configuration at small shapes) applies to the 128-wide-or-wider layers
-    if (a.force_cfg > 0 && cfg != CFG_128x64 && epi != EPI_PARTIAL) cfg = a.force_cfg - 1;
+    if (a.force_cfg > 0 && cfg != CFG_128x64 && cfg != CFG_64x128 && epi != EPI_PARTIAL) cfg = a.force_cfg - 1;
     if (cfg == CFG_256x256) {   // the column tile may only read weight rows that exist
         const int have = a.npad ? a.npad : (a.N + 127) / 128 * 128;
         if (have < (a.N + 255) / 256 * 256) cfg = CFG_256x128;

@@ -58,7 +58,7 @@ struct ConvArgs {
 };
 
 // Tile configurations of the MFMA kernel
-enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_256x128 = 2, CFG_256x256 = 3 };
+enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_256x128 = 2, CFG_256x256 = 3, CFG_64x128 = 4 };
 
 int launch_conv_igemm(hipStream_t st, const ConvArgs &a, int ks, int order, int epi, int cfg);
 int launch_splitk_reduce(hipStream_t st, const float *slab, int S, long long M, int N, const float *bias, float slope,

@@ -458,20 +458,36 @@ static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int 
 // epilogue/prologue) 128.6 vs 256x256 121.4 TFLOP/s at K=1024.  Persistent with the next tile's first DMA
 // issued inside the last chunk: 256x256 132.4 (K=1024), 128.3 (K=512), 122.3 (K=256) -- ahead of 128x128
 // everywhere, so the wide tile is taken whenever wave quantisation does not eat the gain.
+// Small batched GEMMs (a few frames per call): what counts is the busiest CU.  cost = rounds over the 256 CUs x tile
+// area / relative efficiency of the tile shape, in units of one 128x128 tile of this K (measured at batch 8,
+// tools/batch8_layers.py: the 13x13 layers' F(4x4) GEMMs as 36 x 8 tiles of 128x128 leave 224 CUs with one tile and 32
+// with two -- 139 us; as 36 x 16 tiles of 128x64: 112 us; as F(6x6) with 64 x 8 tiles of 64x128 (50 Winograd tiles fit
+// one 64-row tile): 81 us).  Returns the cheapest shape and its cost.
+static double small_gemm_cost(int Mt, int N, int P, int *cfg_out)
+{
+    const long long t128 = (long long)P * ((Mt + 127) / 128) * ((N + 127) / 128);
+    const long long t64n = (long long)P * ((Mt + 127) / 128) * ((N + 63) / 64);
+    const long long t64m = (long long)P * ((Mt + 63) / 64) * ((N + 127) / 128);
+    const long long t256 = (long long)P * ((Mt + 255) / 256) * ((N + 255) / 256);
+    double best = (double)((t128 + 255) / 256);
+    int cfg = CFG_128x128;
+    const double c64n = N % 64 == 0 ? (double)((t64n + 255) / 256) * 0.5 / 0.92 : 1e30;
+    const double c64m = (double)((t64m + 255) / 256) * 0.5 / 0.92;
+    const double c256 = N % 256 == 0 ? (double)((t256 + 255) / 256) * 4.0 / 1.03 : 1e30;
+    if (c64n < best) { best = c64n; cfg = CFG_128x64; }
+    if (c64m < best) { best = c64m; cfg = CFG_64x128; }
+    if (c256 < best) { best = c256; cfg = CFG_256x256; }
+    if (cfg_out) *cfg_out = cfg;
+    return best;
+}
+
 static int pick_cfg_gemm(int Mt, int N, int P)
 {
     const long long t128 = (long long)P * ((Mt + 127) / 128) * ((N + 127) / 128);
     if (t128 <= 4096) {
-        // small problems (a few frames per call): what counts is the busiest CU.  cost = rounds over the 256 CUs x tile
-        // area / relative efficiency of the tile (measured at batch 8, tools/batch8_layers.py: the 13x13 layers' 36 x 8
-        // tiles of 128x128 leave 224 CUs with one tile and 32 with two; 36 x 16 tiles of 128x64 take 112 instead of 139 us)
-        const long long t64 = (long long)P * ((Mt + 127) / 128) * ((N + 63) / 64);
-        const long long t256 = (long long)P * ((Mt + 255) / 256) * ((N + 255) / 256);
-        const double c128 = (double)((t128 + 255) / 256);
-        const double c64 = (double)((t64 + 255) / 256) * 0.5 / 0.92;
-        const double c256 = N % 256 == 0 ? (double)((t256 + 255) / 256) * 4.0 / 1.03 : 1e30;
-        if (N % 64 == 0 && c64 < c128 && c64 < c256) return CFG_128x64;
-        return c256 < c128 ? CFG_256x256 : CFG_128x128;
+        int cfg;
+        (void)small_gemm_cost(Mt, N, P, &cfg);
+        return cfg;
     }
     if (N % 256 == 0) {
         const long long t256 = (long long)P * ((Mt + 255) / 256) * (N / 256);
@@ -665,15 +681,15 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
         io.in = in; io.in_ld = in_ld; io.in_bs = a.in_bs;
         if (epi == EPI_POOL) { io.out2 = out; io.out2_ld = out_ld; }
         else { io.out = out; io.out_ld = out_ld; io.out_bs = a.out_bs; io.out2 = out2; io.out2_ld = out2_ld; }
-        // GEMM cost ~ positions x row tiles of 128: at small batch (one partly filled row tile either way) the 36
-        // positions of F(4x4) beat the 64 of F(6x6); from two F(4x4) row tiles up F(6x6)'s fewer rows win
+        // F(6x6) or F(4x4) for this launch: with many tiles F(6x6)'s fewer multiplies win; with a few frames the choice
+        // is about how the positions x row tiles x column tiles spread over the CUs (small_gemm_cost)
         const float *wt = L.wino;
         int ts = L.wino_ts;
         if (L.wino_alt) {
             const bool pooled = io.out2 != nullptr;
             const WinoGeom q6 = wino_geometry(ctx, 6, B, H, W, pooled), q4 = wino_geometry(ctx, 4, B, H, W, pooled);
-            const long long c6 = 64ll * ((q6.Mt + 127) / 128), c4 = 36ll * ((q4.Mt + 127) / 128);
-            if (c4 < c6 && q4.Mt <= 128) { wt = L.wino_alt; ts = 4; }      // one row tile: the regime the model was measured in
+            const long long t6 = 64ll * ((q6.Mt + 127) / 128) * ((L.cout + 127) / 128);
+            if (t6 <= 4096 && small_gemm_cost(q4.Mt, L.cout, 36, nullptr) < small_gemm_cost(q6.Mt, L.cout, 64, nullptr)) { wt = L.wino_alt; ts = 4; }
         }
         return run_wino(ctx, wt, ts, L.bias, L.cin, L.cout, L.npad, B, H, W, io, slope, tag);
     }
