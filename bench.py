@@ -2,6 +2,8 @@
 """bench.py -- frames/s of the detect-and-track hot path on MI355X.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W        # N > 1 without a launcher: re-executes itself under
+                                                         # torch.distributed.run, one rank per GPU (RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -171,6 +173,56 @@ def detect_batch8_extra(device, H, W, seed0):
     return out
 
 
+def _time_steps(step, warmup, steps):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def track_extra(device, size, clips, T, boxes, steps=3):
+    """BASELINE.json configs[4]'s single-GPU shard under the same clock: MultiObjDetTracker at size x size with
+    ~`boxes` candidate boxes per frame, `clips` clips x T frames per step, its own context."""
+    frames = make_frames(clips, T, size, size, device, seed0=7000)
+    trk, _, _ = build_tracker(size, size, T, boxes, frames)
+    cap = max(128, 2 * boxes)
+    res = {}
+
+    def step():
+        res["r"] = trk.track_clips(frames, cap=cap)
+    sec = _time_steps(step, 2, steps)
+    return {"workload": "BASELINE.json configs[4] on one GPU: MultiObjDetTracker %dx%d, %d clips x %d frames per step, "
+                        "head calibrated to %d candidate boxes per frame" % (size, size, clips, T, boxes),
+            "ms_per_step": 1e3 * sec, "frames_per_s": clips * T / sec,
+            "boxes_per_frame": float(res["r"]["counts"].float().mean().item())}
+
+
+def tiny_extra(device, H, W, seqs, steps=3):
+    """BASELINE.json configs[3] on one GPU under the same clock: TinyTracker over `seqs` sequences x 64 frames
+    (YOLOv2 C=80 + act_13 global max-pool + decode / top box per frame, LSTM(512) + Dense(4) over T)."""
+    from models_tracking.TinyTracker import TinyTracker
+    C, T = 80, 64
+    blob = synth.synth_darknet_blob(C, seed=1234)
+    det = KerasYOLO({'LABELS': KerasYOLO.LABELS_COCO, 'BATCH_SIZE': 4, 'IMAGE_H': H, 'IMAGE_W': W,
+                     'GRID_H': H // 32, 'GRID_W': W // 32}, weights=blob)
+    ctx = det.model.ctx
+    cfg = {"model_tracker": {"name": "TinyTracker", "lstm_units": 512, "sequence_length": T},
+           "train": {"pool": "Global", "batch_size": 4}}
+    tt = TinyTracker(cfg, feature_dims=(H // 16, W // 16, 512), weights=synth.synth_tiny_weights(512), ctx=ctx)
+    frames = make_frames(seqs, T, H, W, device, seed0=9000)
+
+    def step():
+        rows, _ = tt.frame_rows(frames.reshape(seqs * T, H, W, 3), det)
+        return ctx.tiny_sequence(rows.reshape(seqs, T, -1).contiguous())
+    sec = _time_steps(step, 2, steps)
+    return {"workload": "BASELINE.json configs[3] on one GPU: TinyTracker, %d sequences x %d frames, %dx%d" % (seqs, T, H, W),
+            "ms_per_step": 1e3 * sec, "frames_per_s": seqs * T / sec}
+
+
 def load_traffic(clips, T, size):
     """PMC-derived bytes per conv_igemm launch for this exact workload, measured
     with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over
@@ -223,17 +275,39 @@ def _run():
     ap.add_argument("--layer-report", default=None, help="write a per-layer table (HIP-event times) to this file")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed as a plain command: become the launcher -- one rank per GPU of this node under torch.distributed.run
+        # (backend nccl = RCCL unless DT_DIST_BACKEND says otherwise); rank 0 of the child job prints the JSON line to
+        # the stdout this process inherited
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        rc = subprocess.call(cmd, env=env, stdout=sys.__stdout__, stderr=sys.__stderr__)
+        if rc != 0:
+            sys.exit(rc)
+        return None
     rank, world, local = init_from_env()
-    assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: launch with torchrun --nproc-per-node %d, or run " \
+                               "`python bench.py --gpus %d` without a launcher" % (args.gpus, world, args.gpus, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
     device = torch.device("cuda", torch.cuda.current_device())
     H = W = args.size
 
     if args.workload == "track":
         frame_shard = args.shard == "frame" and world > 1
-        # frame-shard: every rank holds the SAME --clips clips (it touches only its own time steps of them)
+        # frame-shard: ONE set of --clips clips for the whole job; a rank keeps only its own time steps of them resident
+        # (sharded ingest: t mod N = rank) once the head is calibrated
         frames = make_frames(args.clips, args.T, H, W, device, seed0=42 + (0 if frame_shard else 100 * rank))
         trk, blob, tw = build_tracker(H, W, args.T, args.boxes, frames)
+        if frame_shard:
+            from parallel import frame_shard_times
+            frames = frames[:, frame_shard_times(args.T, rank, world)].contiguous()
+        xstats = {}
         ctx = trk.model.ctx
         frames_per_step = args.clips * args.T / (world if frame_shard else 1)
         gflop_per_frame = GFLOP_TRACK_416 * (H * W) / (416.0 * 416.0)
@@ -244,11 +318,12 @@ def _run():
             src = frames
             if host_frames is not None:
                 frames.copy_(host_frames, non_blocking=True)     # same stream: serialised in front of the step
+            xstats.clear()
             if frame_shard:
-                return track_clips_frame_sharded(trk, src, cap=max(128, 2 * args.boxes))
+                return track_clips_frame_sharded(trk, src, cap=max(128, 2 * args.boxes), T=args.T, stats=xstats)
             res = trk.track_clips(src, cap=max(128, 2 * args.boxes))
             if world > 1:
-                res = gather_detections(res, n_clips_max=args.clips)
+                res = gather_detections(res, n_clips_max=args.clips, ctx=ctx, stats=xstats)
             return res
     elif args.workload == "tiny":
         # BASELINE.json configs[3]: TinyTracker (ROLO-style) over 64-frame sequences, FRAME-sharded:
@@ -270,6 +345,7 @@ def _run():
         frames_per_step = args.seqs * t_loc
         gflop_per_frame = GFLOP_DETECT_416_C80 * (H * W) / (416.0 * 416.0)
         tw = None
+        xstats = {}
 
         def step():
             rows, _ = tt.frame_rows(frames.reshape(args.seqs * t_loc, H, W, 3), det)
@@ -285,6 +361,7 @@ def _run():
         frames_per_step = args.batch
         gflop_per_frame = GFLOP_DETECT_416_C80 * (H * W) / (416.0 * 416.0)
         tw = None
+        xstats = {}
 
         def step():
             return det.detect(frames)
@@ -334,6 +411,12 @@ def _run():
     wino_in, wino_out = ctx.profile_read("wino_input"), ctx.profile_read("wino_output")
     wino_ms = wino_in["ms"] + wino_out["ms"]
     fused = ctx.profile_read("conv_fused")
+    conv1 = ctx.profile_read("conv1_direct")
+    direct_form_fused = ctx.profile_read("conv_direct_form_fused")["flops"]
+    # whole conv path: every MFMA FLOP the conv kernels execute (batched / direct GEMMs, the fused Winograd kernels,
+    # conv_1) over ALL the time the conv path takes (those kernels + the Winograd transform kernels)
+    conv_path_ms = ig["ms"] + fused["ms"] + conv1["ms"] + wino_ms
+    conv_path_flops = ig["flops"] + fused["flops"] + conv1["flops"]
     # split the family's launches by arithmetic intensity (executed FLOP per algorithmic byte): below the ridge
     # of the chip (157.3 TFLOP/s over ~6.3 TB/s achievable = 25 FLOP/B; 40 used as the class boundary) a launch is
     # HBM-bound whatever the kernel does, and is priced against the HBM roof instead
@@ -383,12 +466,19 @@ def _run():
                        if (args.workload == "track" and args.shard == "frame" and world > 1) else "clip-shard x%d" % world,
                        "gflop_per_frame": gflop_per_frame, "boxes_per_frame": boxes_per_frame},
             "whole_path_tflops": fps * gflop_per_frame / 1e3, "h2d_included": bool(args.h2d),
+            "ranks_seen": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+            "exchange_bytes_received_per_step_rank0": int(xstats.get("bytes_received", 0)),
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32 implicit GEMM)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "frac_executed": achieved / PEAK_F32_MFMA_TFLOPS,
                          # the transform kernels exist only because of the Winograd form: charge them to the conv path
                          "frac_incl_transforms": (ig["flops"] / ((ig["ms"] + wino_ms) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)
                          if ig["ms"] > 0 else None,
+                         "frac_whole_conv_path": (conv_path_flops / (conv_path_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)
+                         if conv_path_ms > 0 else None,
+                         "whole_conv_path": {"executed_tflop_per_step": conv_path_flops / max(1, args.steps) / 1e12,
+                                             "ms_per_step": conv_path_ms / max(1, args.steps),
+                                             "direct_form_tflop_per_step": (direct_form + direct_form_fused + conv1["flops"]) / max(1, args.steps) / 1e12},
                          "transform_ms_per_step": wino_ms / max(1, args.steps),
                          # conv family as a whole (MFMA GEMMs + transforms + fused conv_2): direct-form bytes the
                          # reference's layers need (in + W + out, fp32) vs the bytes this implementation's kernels
@@ -417,8 +507,11 @@ def _run():
                                  "<= 1). The 3x3 layers from conv_3 up and both ConvLSTM convolutions run in Winograd "
                                  "form (F(6x6,3x3): 64 batched GEMMs through the same kernel; F(4x4,3x3) for the recurrent "
                                  "step), which executes up to 5x fewer FLOPs than the direct form SURVEY.md 8d counts; "
-                                 "achieved_algorithmic = direct-form FLOPs of the same launches / the same time, and "
-                                 "exceeds the peak; ..._incl_transforms adds the HBM-bound transform kernels to the time. "
+                                 "achieved_algorithmic = direct-form FLOPs of the layers THESE launches computed (layers run "
+                                 "by the fused Winograd kernels or conv_1 are not counted) / the same time, and exceeds "
+                                 "the peak; ..._incl_transforms adds the HBM-bound transform kernels to the time; "
+                                 "frac_whole_conv_path = every executed MFMA FLOP of the conv path (GEMMs + fused kernels + "
+                                 "conv_1) / (their time + the transforms' time) / peak. "
                                  "mfma_bound_launches / hbm_bound_launches split the family by arithmetic intensity "
                                  "(>= / < 40 executed FLOP per algorithmic byte): the short-K launches (K = 64/128 Winograd "
                                  "GEMMs, early 1x1 layers) sit under the HBM roof, not the MFMA one."},
@@ -431,7 +524,14 @@ def _run():
             out["roofline"]["traffic_unit"] = "bytes/launch (FETCH_SIZE x in-run calibration + WRITE_SIZE; beyond-L2, incl. Infinity Cache hits)"
             out["roofline"]["traffic_source"] = os.path.relpath(tr[0], ROOT)
         if world == 1 and not args.no_extra and args.workload == "track":
-            out["extra"] = {"detect_batch8": detect_batch8_extra(device, H, W, seed0=4242)}
+            import gc
+            out["extra"] = {}
+            for key, fn in (("detect_batch8", lambda: detect_batch8_extra(device, H, W, seed0=4242)),
+                            ("track_608_128boxes", lambda: track_extra(device, 608, 24, args.T, 128)),
+                            ("tiny_T64", lambda: tiny_extra(device, H, W, 32))):
+                out["extra"][key] = fn()
+                gc.collect()                      # each extra owns a context with its own workspaces: release them
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline and args.workload == "track":
             from oracle import oracle as orc
             orc.lib()

@@ -48,7 +48,7 @@ DT_API int dt_create(dt_ctx **out);
 DT_API void dt_destroy(dt_ctx *ctx);
 DT_API const char *dt_last_error(dt_ctx *ctx);
 DT_API int dt_set_stream(dt_ctx *ctx, void *hip_stream);
-/* ABI version of this header: major*100+minor (1.03: 1.02 + dt_policy_reload, dt_detector_extract) */
+/* ABI version of this header: major*100+minor (1.04: 1.03 + dt_pack_detections / dt_unpack_detections) */
 DT_API int dt_abi_version(void);
 
 /* ---- detector: KerasYOLO ---------------------------------------------- */
@@ -161,6 +161,24 @@ DT_API int dt_track_recurrent(dt_ctx *ctx, const float *d_z, int n_clips, int T,
 DT_API int dt_associate(dt_ctx *ctx, const float *d_boxes, const int *d_counts,
                  int n_clips, int T, int cap, float assoc_threshold,
                  int *d_ids, int *d_nids);
+
+/* ---- cross-stream detection exchange (multi-GPU; the reference has no counterpart) ---- *
+ * north_star: "RCCL all-gather of detections over xGMI only for cross-stream association".  Each rank packs its
+ * detection table (the outputs of dt_decode + dt_associate for its clips) into ONE int32 row per clip,
+ *     row = [ boxes T*cap*8 (float bits) | ids T*cap | counts T | nids | valid ],   dt_packed_row_ints(T, cap) ints,
+ * padded with empty rows (valid = 0) to n_rows = the largest clip count of any rank, so that the exchange is ONE
+ * fixed-size all-gather per step (the caller's collective: ncclAllGather / torch.distributed on d_rows, n_rows *
+ * row ints per rank).  dt_unpack_detections compacts the gathered rows of all ranks (rank-major = global clip order)
+ * back into tables and makes the per-clip track ids globally unique: gid = id + sum of nids of all earlier clips.
+ *   dt_pack_detections:   d_boxes [n_clips,T,cap,8], d_counts [n_clips,T], d_ids [n_clips,T,cap], d_nids [n_clips]
+ *                         -> d_rows [n_rows, row] int32          (n_rows >= n_clips; n_clips may be 0)
+ *   dt_unpack_detections: d_rows [n_rows, row] -> d_boxes/d_counts/d_ids/d_nids sized for n_rows clips (the first
+ *                         *d_n_valid are filled), d_gids [n_rows,T,cap] int64 (may be NULL), d_n_valid [1] int32 */
+DT_API size_t dt_packed_row_ints(int T, int cap);
+DT_API int dt_pack_detections(dt_ctx *ctx, const float *d_boxes, const int *d_counts, const int *d_ids,
+                       const int *d_nids, int n_clips, int T, int cap, int n_rows, int32_t *d_rows);
+DT_API int dt_unpack_detections(dt_ctx *ctx, const int32_t *d_rows, int n_rows, int T, int cap, float *d_boxes,
+                         int *d_counts, int *d_ids, int *d_nids, int64_t *d_gids, int *d_n_valid);
 
 /* ---- TinyTracker (models_tracking/TinyTracker.py:25-41) ---------------- */
 /* Also serves TinyHeatmapTracker (models_tracking/TinyHeatmapTracker.py:26-48): same

@@ -24,6 +24,7 @@ SOURCES = {
     "wino4_fused.hip": [],
     "ingest.hip": [],
     "extract.hip": [],
+    "exchange.hip": [],
     "decode.hip": ["-ffp-contract=off"],
     "targets.hip": ["-ffp-contract=off"],
     "recurrent.hip": [],

@@ -727,18 +727,17 @@ static int launch_one(hipStream_t st, const ConvArgs &a, int ksplit = 1)
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     const size_t lds = (size_t)NSTAGE * (BM + BN) * LDK * sizeof(float);
     auto kern = conv_igemm_f32<KS, BM, BN, WGM, WGN, ORDER, EPI, PERSIST>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return 1;
-        attr_done = true;
+        attr.done();
     }
     // one workgroup per tile, or -- with more tiles than resident slots -- a persistent grid of one
     // workgroup per slot (256 CUs x 2 four-wave workgroups, or x 1 of the 8/16-wave ones) that walks the tiles
     int grid = ntm * ntn * (a.zbatch > 1 ? a.zbatch : 1);
 #if DT_GLDS && DT_BK == 32
-    static const int persist_env = [] { const char *e = getenv("DT_PERSIST"); return e ? atoi(e) : 1; }();
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
@@ -746,7 +745,7 @@ static int launch_one(hipStream_t st, const ConvArgs &a, int ksplit = 1)
         return n;
     }();
     const int slots = ((cus * (WGM * WGN > 4 ? 1 : 2)) / 8) * 8;   // multiple of 8: L % 8 stays the XCD
-    if (PERSIST && persist_env && ksplit == 1 && slots > 0 && grid > slots) grid = slots;
+    if (PERSIST && !a.no_persist && ksplit == 1 && slots > 0 && grid > slots) grid = slots;
 #endif
     hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ksplit), dim3(64 * WGM * WGN), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
@@ -769,13 +768,11 @@ static int launch_cfg(hipStream_t st, const ConvArgs &a, int cfg)
 int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, int epi, int cfg)
 {
     ConvArgs a = a_in;
-    static const int remap_env = [] { const char *e = getenv("DT_XCD_REMAP"); return e ? atoi(e) : 1; }();
-    a.xcd_remap = remap_env;
+    // a.xcd_remap / a.no_persist / a.gn_default come from the caller's Policy (network.hip:launch_igemm)
     // column tiles per group of the tile order: measured FETCH_SIZE optimum is 1 for the 3x3
     // layers (all ~64 workgroups resident on an XCD share ONE weight panel) and 2 for 1x1 / gates
-    static const int gn_env = [] { const char *e = getenv("DT_TILE_GN"); return e ? atoi(e) : -1; }();
     if (a_in.tile_gn < 0) a.tile_gn = -a_in.tile_gn - 1;   // caller-chosen width, encoded as -(gn+1)
-    else a.tile_gn = gn_env >= 0 ? gn_env : ((ks == 3 && epi != EPI_GATES) ? 1 : 2);
+    else a.tile_gn = a_in.gn_default > 0 ? a_in.gn_default - 1 : ((ks == 3 && epi != EPI_GATES) ? 1 : 2);
     // a caller-forced tile configuration (Policy::conv_cfg: A/B runs and the tests that exercise every
     // configuration at small shapes) applies to the 128-wide-or-wider layers
     if (a.force_cfg > 0 && cfg != CFG_128x64 && cfg != CFG_64x128 && epi != EPI_PARTIAL) cfg = a.force_cfg - 1;
@@ -783,12 +780,16 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
         const int have = a.npad ? a.npad : (a.N + 127) / 128 * 128;
         if (have < (a.N + 255) / 256 * 256) cfg = CFG_256x128;
     }
-    static float *zeros_dev = nullptr;   // process-wide 256 B of zeros for the padding taps
-    if (!zeros_dev) {
-        if (hipMalloc(reinterpret_cast<void **>(&zeros_dev), 256) != hipSuccess) return 1;
-        if (hipMemset(zeros_dev, 0, 256) != hipSuccess) return 1;
+    static float *zeros_dev[64];   // per device: 256 B of zeros for the padding taps
+    static PerDeviceOnce zeros_once;
+    if (zeros_once.first()) {
+        float *z = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&z), 256) != hipSuccess) return 1;
+        if (hipMemset(z, 0, 256) != hipSuccess) return 1;
+        zeros_dev[zeros_once.dev] = z;
+        zeros_once.done();
     }
-    a.zeros = zeros_dev;
+    a.zeros = zeros_dev[zeros_once.dev];
     if (a.Cin % KCH != 0 || a.K != ks * ks * a.Cin) return 2;
     if (ks == 1 && order == ORD_LINEAR && a.in_bs != (long long)a.H * a.W * a.in_ld) return 2;   // flat row addressing
     if (epi == EPI_GATES) {

@@ -611,12 +611,12 @@ int launch_decode(hipStream_t st, const float *netout, long long frame_stride, i
     if (nms_waves < 1) return 2;
     a.nms_waves = nms_waves > DEC_THREADS / 64 ? DEC_THREADS / 64 : nms_waves;
     const size_t lds = fixed + (size_t)nzcap * 8 + dyn;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(decode_nms_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return 1;
-        attr_done = true;
+        attr.done();
     }
     if (lds > 160 * 1024) return 2;
     hipLaunchKernelGGL(decode_nms_kernel, dim3((unsigned)batch), dim3(DEC_THREADS), lds, st, a);
@@ -726,12 +726,12 @@ int launch_associate(hipStream_t st, const float *boxes, const int *counts, int 
     if (n_clips <= 0) return 0;
     const size_t lds = (size_t)cap * 12 * sizeof(float);   // 2 x 5 box fields + 2 id arrays
     if (lds > 160 * 1024) return 2;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(associate_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return 1;
-        attr_done = true;
+        attr.done();
     }
     hipLaunchKernelGGL(associate_kernel, dim3((unsigned)n_clips), dim3(64), lds, st, boxes, counts, T, cap, thr, ids,
                        nids);

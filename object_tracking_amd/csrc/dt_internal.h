@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -11,6 +12,20 @@
 #include <vector>
 
 #include "../../include/mi355_dt.h"
+
+// One-time, PER-DEVICE set-up of a launch site (hipFuncSetAttribute for large dynamic LDS, small constant buffers):
+// kernel attributes and allocations belong to a device, so a process that drives several GPUs must repeat them on
+// each.  `first()` is true until `done()` was called on the calling thread's current device.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    int dev = 0;
+    bool first()
+    {
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+        return !((mask.load(std::memory_order_acquire) >> dev) & 1ull);
+    }
+    void done() { mask.fetch_or(1ull << dev, std::memory_order_release); }
+};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -55,6 +70,8 @@ struct ConvArgs {
     int zbatch;
     long long z_in, z_wt, z_out;
     int force_cfg; // > 0: tile configuration + 1 forced by the caller's policy (Policy::conv_cfg); 0: none
+    int no_persist; // 1: one tile per workgroup even where the persistent tile loop applies (Policy::persist = 0, A/B runs)
+    int gn_default; // > 0: column-group width + 1 used when tile_gn is 0 (Policy::tile_gn, A/B runs); 0: the per-layer default
 };
 
 // Tile configurations of the MFMA kernel
@@ -227,6 +244,9 @@ struct Policy {
     int wino_cfg = -1, wino_gn = -1;   // DT_WINO_CFG / DT_WINO_GN (A/B runs)
     int ksplit = 0;          // DT_KSPLIT
     int conv_cfg = -1;       // DT_CONV_CFG
+    int persist = 1;         // DT_PERSIST: 0 = one tile per workgroup for the GEMM-shaped launches (A/B runs)
+    int xcd_remap = 1;       // DT_XCD_REMAP: 0 = plain tile numbering (L2 traffic experiments)
+    int tile_gn = -1;        // DT_TILE_GN: column tiles per group of the tile order; -1 = per-layer default
 };
 void policy_from_env(Policy &p);
 

@@ -157,7 +157,7 @@ static int upload(dt_ctx *ctx, float **dst, const std::vector<float> &h)
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int dt_abi_version(void) { return 103; }   // 1.03: + dt_policy_reload, dt_detector_extract
+extern "C" int dt_abi_version(void) { return 104; }   // 1.04: + dt_pack_detections / dt_unpack_detections / dt_packed_row_ints
 
 extern "C" int dt_create(dt_ctx **out)
 {
@@ -377,12 +377,15 @@ extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t 
 
 // "conv_direct_form": direct-form FLOPs (2*M*K*N of the reference's convolution) of every layer a
 // conv_igemm launch computes, whichever form it runs in -- bench.py divides it by the kernel family's
-// time for the algorithmic-equivalent rate next to the executed one.
-static void prof_direct_form(dt_ctx *ctx, double flops, double bytes)
+// time for the algorithmic-equivalent rate next to the executed one.  Layers that run in one of the fused
+// Winograd kernels (conv_2 / conv_3 / conv_5 ...) are NOT conv_igemm launches: they are booked under
+// "conv_direct_form_fused", so that the family's rate is never credited with work another kernel did.
+static void prof_direct_form(dt_ctx *ctx, double flops, double bytes, bool fused_kernel = false)
 {
     if (!ctx->prof) return;
-    ctx->prof_tab["conv_direct_form"].flops += flops;
-    ctx->prof_tab["conv_direct_form"].bytes += bytes;   // in + weights + out of the reference's layer, float32
+    ProfEntry &e = ctx->prof_tab[fused_kernel ? "conv_direct_form_fused" : "conv_direct_form"];
+    e.flops += flops;
+    e.bytes += bytes;   // in + weights + out of the reference's layer, float32
 }
 
 // ---------------------------------------------------------------------------
@@ -410,6 +413,9 @@ void policy_from_env(Policy &p)
     p.wino_gn = geti("DT_WINO_GN", d.wino_gn);
     p.ksplit = geti("DT_KSPLIT", d.ksplit);
     p.conv_cfg = geti("DT_CONV_CFG", d.conv_cfg);
+    p.persist = geti("DT_PERSIST", d.persist);
+    p.xcd_remap = geti("DT_XCD_REMAP", d.xcd_remap);
+    p.tile_gn = geti("DT_TILE_GN", d.tile_gn);
 }
 
 static bool wino_wanted(const dt_ctx *ctx, int ks, int cin, int cout)
@@ -502,6 +508,9 @@ static int pick_cfg_gemm(int Mt, int N, int P)
 static int launch_igemm(dt_ctx *ctx, ConvArgs &a, int ks, int order, int epi, int cfg)
 {
     a.force_cfg = ctx->pol.conv_cfg >= 0 ? ctx->pol.conv_cfg + 1 : 0;
+    a.no_persist = ctx->pol.persist ? 0 : 1;
+    a.xcd_remap = ctx->pol.xcd_remap;
+    a.gn_default = ctx->pol.tile_gn >= 0 ? ctx->pol.tile_gn + 1 : 0;
     return launch_conv_igemm(ctx->stream, a, ks, order, epi, cfg);
 }
 
@@ -648,7 +657,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
             // executed MFMA FLOPs: 16 positions x (tiles x 32 x 64) x 2; bytes: input once (+halo) and the pooled output
             ProfScope ps(ctx, "conv_fused", 2.0 * 16.0 * B * (H / 2.0) * (W / 2.0) * 32.0 * 64.0,
                          4.0 * ((double)B * H * W * 32.0 * 1.27 + (double)B * (H / 2) * (W / 2) * 64.0), tag);
-            prof_direct_form(ctx, flops, bytes);
+            prof_direct_form(ctx, flops, bytes, true);
             const int rc = launch_wino2_fused_pool(ctx->stream, f);
             if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused Winograd launch failed", tag);
             return DT_OK;
@@ -658,7 +667,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
     // blocks to fill the chip several times over; below that the unfused forms win (few, half-empty workgroups)
     if (L.fused4 && in_ld % 4 == 0 && ((epi == EPI_PLAIN && order == ORD_LINEAR) || (epi == EPI_POOL && !((H | W) & 1)))) {
         const long long blocks = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * (L.cout / 128);
-        if (ctx->pol.fused4 == 2 || ((ctx->pol.fused4 == 1 && L.cin == 64 || ctx->pol.fused4 == 3) && blocks >= 1024)) {
+        if (ctx->pol.fused4 == 2 || (((ctx->pol.fused4 == 1 && L.cin == 64) || ctx->pol.fused4 == 3) && blocks >= 1024)) {
             Wino4FusedArgs f;
             memset(&f, 0, sizeof(f));
             f.in = in; f.in_bs = a.in_bs; f.in_ld = in_ld; f.B = B; f.H = H; f.W = W; f.Cin = L.cin; f.N = L.cout;
@@ -669,7 +678,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
             const double tiles = (double)B * ((H + 3) / 4) * ((W + 3) / 4);
             ProfScope ps(ctx, "conv_fused", 2.0 * 36.0 * tiles * L.cin * L.cout,
                          4.0 * ((double)B * H * W * L.cin * 1.27 * (L.cout / 128) + (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0)), tag);
-            prof_direct_form(ctx, flops, bytes);
+            prof_direct_form(ctx, flops, bytes, true);
             const int rc = launch_wino4_fused(ctx->stream, f);
             if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused F(4x4) launch failed", tag);
             return DT_OK;
@@ -1147,8 +1156,17 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
     float *xproj = ws_get(ctx, "trk_xproj", (size_t)F * GG * N4 * sizeof(float));
     float *cst = ws_get(ctx, "trk_c", (size_t)n_clips * GG * U * sizeof(float));
     if (!xproj || !cst) return DT_ERR_DEVICE;
-    // z, hseq, xproj and the cell state are library-owned: the whole recurrence (3 launches per step) replays as a graph
-    return graphed(ctx, "clstm:" + std::to_string(n_clips) + "x" + std::to_string(T), [&]() -> int {
+    // hseq, xproj and the cell state are library-owned, z only when it is the 'trk_z' workspace (dt_track_forward).  A
+    // captured graph keeps the pointers it was captured with, so the input projection -- the one part that reads z --
+    // is inside the replayed graph only for the library-owned z; for a caller's rows (dt_track_recurrent) it runs
+    // plainly and the recurrence alone (3 launches per step, library-owned buffers only) replays, under its own key.
+    bool z_owned = false;
+    {
+        auto it = ctx->ws.find("trk_z");
+        z_owned = it != ctx->ws.end() && it->second.p == static_cast<const void *>(z);
+    }
+    const std::string shape = std::to_string(n_clips) + "x" + std::to_string(T);
+    auto input_projection = [&]() -> int {
     if (wino_runs(ctx, wx_wino, ctx->trk_wino_ts, F, gh, gw, Cx, N4)) {
         WinoIO io;
         memset(&io, 0, sizeof(io));
@@ -1171,6 +1189,9 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
         if (launch_igemm(ctx, a, 3, ORD_LINEAR, EPI_PLAIN, pick_cfg(a.M, N4, 3)))
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM input projection launch failed");
     }
+    return DT_OK;
+    };
+    auto recurrence = [&]() -> int {
     const long long xp_bs = (long long)T * GG * N4, h_bs = (long long)T * GG * U, c_bs = (long long)GG * U;
     {   // t = 0: h_{-1} = c_{-1} = 0
         ProfScope ps(ctx, "convlstm_gates", 0.0, 4.0 * n_clips * GG * (3.0 * U + 2.0 * U));
@@ -1206,7 +1227,14 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
             return dt_fail(ctx, DT_ERR_DEVICE, "ConvLSTM step launch failed");
     }
     return DT_OK;
-    });
+    };
+    if (z_owned)
+        return graphed(ctx, "clstm:" + shape, [&]() -> int {
+            const int rc = input_projection();
+            return rc ? rc : recurrence();
+        });
+    const int rc = input_projection();
+    return rc ? rc : graphed(ctx, "clstm_steps:" + shape, recurrence);
 }
 
 // the recurrent head on z [n_clips][T][G*G][Cx] (library- or caller-owned): ConvLSTM2D over T, then tconv_2

@@ -363,12 +363,12 @@ int launch_wino4_fused(hipStream_t st, const Wino4FusedArgs &a_in)
     const long long blocks = (long long)a.B * a.nby * a.nbx;
     if (blocks >= (1ll << 31)) return 2;
     const size_t lds = (size_t)2 * (W4_PBUF + W4_VBUF) * sizeof(float);      // 123,008 B
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return 1;
-        attr_done = true;
+        attr.done();
     }
     const dim3 grid((unsigned)((blocks + 1) / 2), (unsigned)(a.N / 64));
     if (pool) hipLaunchKernelGGL(wino4_fused_kernel<true>, grid, dim3(W4_THREADS), lds, st, a);

@@ -27,6 +27,7 @@ SYMBOLS = [
     "dt_tiny_load", "dt_tiny_forward", "dt_tiny_features", "dt_tiny_sequence", "dt_top_box", "dt_heatmap_from_boxes", "dt_heatmap_from_xywh64", "dt_rect_from_heatmap", "dt_encode_targets", "dt_graph_enable", "dt_conv2d", "dt_convlstm_step",
     "dt_profile_enable", "dt_profile_reset", "dt_profile_read", "dt_profile_names", "dt_policy_reload", "dt_detector_extract", "dt_decode_per_frame",
     "dt_track_row_width", "dt_track_detect", "dt_track_recurrent",
+    "dt_packed_row_ints", "dt_pack_detections", "dt_unpack_detections",
 ]
 
 _lib = None
@@ -69,6 +70,9 @@ def load_library():
     L.dt_track_row_width.argtypes = [vp]
     L.dt_track_detect.argtypes = [vp, vp, ci, ci, vp]
     L.dt_track_recurrent.argtypes = [vp, vp, ci, ci, vp, vp]
+    L.dt_packed_row_ints.argtypes = [ci, ci]
+    L.dt_pack_detections.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    L.dt_unpack_detections.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp]
     L.dt_tiny_load.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, vp]
     L.dt_heatmap_from_boxes.argtypes = [vp, vp, ci, ci, vp]
     L.dt_heatmap_from_xywh64.argtypes = [vp, vp, ci, ci, vp]
@@ -89,8 +93,9 @@ def load_library():
                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                   ctypes.POINTER(ctypes.c_double)]
     for s in SYMBOLS:
-        if s not in ("dt_destroy", "dt_last_error"):
+        if s not in ("dt_destroy", "dt_last_error", "dt_packed_row_ints"):
             getattr(L, s).restype = ctypes.c_int
+    L.dt_packed_row_ints.restype = ctypes.c_size_t
     _lib = L
     return L
 
@@ -282,6 +287,39 @@ class Context(object):
         self._check(self.lib.dt_associate(self.h, _dptr(boxes), _dptr(counts), n_clips, T, cap,
                                           float(assoc_threshold), _dptr(ids), _dptr(nids)), "dt_associate")
         return ids, nids
+
+    # ---- cross-stream exchange ------------------------------------------
+    def pack_detections(self, boxes, counts, ids, nids, n_rows):
+        """this rank's detection table -> int32 rows [n_rows, dt_packed_row_ints(T, cap)] (rows past the local clips
+        are empty): the buffer of the ONE all-gather of a step."""
+        t = self.torch
+        n, T, cap = ids.shape
+        assert boxes.is_cuda and boxes.is_contiguous() and counts.is_contiguous() and ids.is_contiguous() and nids.is_contiguous()
+        assert counts.dtype == t.int32 and ids.dtype == t.int32 and nids.dtype == t.int32 and boxes.dtype == t.float32
+        assert n <= n_rows, "this rank holds %d clips but the exchange was sized for at most %d per rank (n_clips_max)" % (n, n_rows)
+        rows = t.empty((n_rows, int(self.lib.dt_packed_row_ints(T, cap))), dtype=t.int32, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.dt_pack_detections(self.h, _dptr(boxes), _dptr(counts), _dptr(ids), _dptr(nids), n, T, cap,
+                                                n_rows, _dptr(rows)), "dt_pack_detections")
+        return rows
+
+    def unpack_detections(self, rows, T, cap):
+        """gathered rows of all ranks [R, row] -> (boxes, counts, ids, nids, gids) of the valid clips in global order"""
+        t = self.torch
+        assert rows.is_cuda and rows.is_contiguous() and rows.dtype == t.int32
+        R = rows.shape[0]
+        assert rows.shape[1] == int(self.lib.dt_packed_row_ints(T, cap))
+        boxes = t.empty((R, T, cap, DT_BOX_FLOATS), dtype=t.float32, device=self.device)
+        counts = t.empty((R, T), dtype=t.int32, device=self.device)
+        ids = t.empty((R, T, cap), dtype=t.int32, device=self.device)
+        nids = t.empty((R,), dtype=t.int32, device=self.device)
+        gids = t.empty((R, T, cap), dtype=t.int64, device=self.device)
+        nv = t.zeros((1,), dtype=t.int32, device=self.device)
+        self._sync_stream()
+        self._check(self.lib.dt_unpack_detections(self.h, _dptr(rows), R, T, cap, _dptr(boxes), _dptr(counts), _dptr(ids),
+                                                  _dptr(nids), _dptr(gids), _dptr(nv)), "dt_unpack_detections")
+        n = int(nv.item())
+        return boxes[:n], counts[:n], ids[:n], nids[:n], gids[:n]
 
     # ---- tracker ------------------------------------------------------
     def tracker_load(self, units, kernel, recurrent, bias, out_kernel, out_bias):

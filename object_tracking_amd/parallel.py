@@ -58,6 +58,8 @@ def _pack_rows(boxes, counts, ids, nids, n_pad):
     """One int32 row per clip: [boxes T*cap*8 (float bits) | ids T*cap | counts T | nids | valid]; rows beyond the
     local clips are empty (valid = 0).  One buffer -> ONE collective per step (the exchange is latency-bound)."""
     n, T, cap = ids.shape
+    assert n <= n_pad, ("this rank holds %d clips but the exchange was sized for at most %d per rank: pass "
+                        "n_clips_max >= the largest clip count of any rank (or None to let one all-reduce find it)" % (n, n_pad))
     row = T * cap * 8 + T * cap + T + 2
     buf = torch.zeros((n_pad, row), dtype=torch.int32, device=boxes.device)
     o = 0
@@ -81,23 +83,42 @@ def _unpack_rows(buf, T, cap):
     return boxes, counts, ids, nids
 
 
-def gather_detections(res, n_clips_max=None, group=None):
+def gather_detections(res, n_clips_max=None, group=None, ctx=None, clip_ids=None, stats=None):
     """Cross-stream exchange.  `res` is MultiObjDetTracker.track_clips output for
     this rank's clips (device tensors).  Returns the dict for ALL clips of all ranks in global clip
     order with an extra `gids` tensor of globally unique track ids.  Shards may be uneven: rows are padded to
     `n_clips_max` clips per rank (pass it when known, e.g. ceil(total / world) -- otherwise one extra scalar
     all-reduce finds it).  ONE all-gather of one packed buffer per step.  Without an initialised process group
-    (single process) only the id globalisation is applied."""
+    (single process) only the id globalisation is applied.
+      ctx       a mi355_dt.Context: pack / unpack / id globalisation run as the library's kernels
+                (dt_pack_detections / dt_unpack_detections) instead of torch indexing -- the path a C-ABI caller has;
+      clip_ids  global clip index of every gathered row in rank-major order (block partition: omit; round-robin
+                owners of the frame-shard: see track_clips_frame_sharded) -- rows are put in global clip order
+                BEFORE the ids are globalised, so every partition gives the single-process ids;
+      stats     dict that receives `bytes_received` (bytes of other ranks' rows this rank took in)."""
     boxes, counts, ids, nids = res["boxes"], res["counts"], res["ids"], res["nids"]
     n_local = boxes.shape[0]
+    native = ctx is not None and boxes.is_cuda
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
         if n_clips_max is None:
             m = torch.tensor([n_local], dtype=torch.int64, device=boxes.device if dist.get_backend(group) == "nccl" else "cpu")
             dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
             n_clips_max = int(m.item())
         T, cap = ids.shape[1], ids.shape[2]
-        allrows = _all_gather_cat(_pack_rows(boxes, counts, ids, nids, n_clips_max), group)
+        mine = ctx.pack_detections(boxes.contiguous(), counts.contiguous(), ids.contiguous(), nids.contiguous(), n_clips_max) \
+            if native else _pack_rows(boxes, counts, ids, nids, n_clips_max)
+        allrows = _all_gather_cat(mine, group)
+        if stats is not None:
+            stats["bytes_received"] = stats.get("bytes_received", 0) + (world - 1) * mine.numel() * 4
+        if native and clip_ids is None:
+            boxes, counts, ids, nids, gids = ctx.unpack_detections(allrows.contiguous(), T, cap)
+            return dict(boxes=boxes, counts=counts, ids=ids, nids=nids, gids=gids)
         boxes, counts, ids, nids = _unpack_rows(allrows, T, cap)
+        if clip_ids is not None:
+            order = torch.argsort(torch.as_tensor(list(clip_ids), dtype=torch.int64)).to(boxes.device)
+            assert order.numel() == boxes.shape[0], "clip_ids names %d rows, the exchange delivered %d" % (order.numel(), boxes.shape[0])
+            boxes, counts, ids, nids = boxes[order], counts[order], ids[order], nids[order]
     return dict(boxes=boxes, counts=counts, ids=ids, nids=nids, gids=global_track_ids(ids, nids))
 
 
@@ -118,37 +139,101 @@ def stitch_frame_rows(gathered, T, world):
     return out[:, :T].contiguous()
 
 
-def track_clips_frame_sharded(trk, frames, cap=None, group=None):
+def owned_clips(n_clips, rank, world):
+    """clips whose RECURRENCE runs on `rank`: round-robin (clip c -> rank c mod world), so that any number of clips
+    spreads over as many ranks as it can and every rank's count is within one of the others."""
+    return list(range(rank, n_clips, world))
+
+
+def _all_to_all_rows(send, group, async_op):
+    """send [world, ...] (slice d goes to rank d) -> (recv [world, ...] (slice s came from rank s), work handle).
+    nccl: device buffers straight over xGMI; gloo: staged through the host."""
+    backend = dist.get_backend(group)
+    src = send.contiguous()
+    if backend == "gloo" and src.is_cuda:
+        src = src.cpu()
+    out = torch.empty_like(src)
+    work = dist.all_to_all_single(out, src, group=group, async_op=async_op)
+    return out, work
+
+
+def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=2, stats=None):
     """MultiObjDetTracker on clips whose frames are spread over the ranks of `group`: ONE stream can use all GPUs.
-      1. detector (the 74 % of a frame's FLOPs) on this rank's time steps of EVERY clip (dt_track_detect),
-      2. all-gather of the per-frame rows z = [conv_feat | x_bbox] (757 KB/frame at 416x416; over xGMI this is
-         ~0.3 GB/s per GPU at 375 frames/s -- far below one link) and stitching into time order,
-      3. ConvLSTM recurrence + 1x1 + decode + association on the OWNER of each clip (contiguous block partition of
-         the clips, shard_range): the recurrence is sequential in T, so it cannot be split further,
-      4. the cross-stream detection all-gather of gather_detections.
-    `frames` [n_clips,T,H,W,3] must be the same on every rank (a rank only touches its own time steps).  Returns
-    the global table like gather_detections.  Single process: identical to track_clips + gather_detections."""
+      1. detector (the 74 % of a frame's FLOPs) on this rank's time steps {t : t mod N = rank} of EVERY clip
+         (dt_track_detect).  `frames` is either the whole [n_clips,T,H,W,3] batch (a rank then touches only its own
+         time steps of it) or -- sharded ingest, pass T -- only this rank's frames [n_clips, len(frame_shard_times),
+         H,W,3]: nothing but a rank's own frames has to reach its HBM;
+      2. the per-frame rows z = [conv_feat | x_bbox] (757 KB/frame at 416x416) go to the OWNER of their clip only
+         (round-robin owners, `owned_clips`): one all_to_all_single per chunk of the local time axis, issued
+         asynchronously so that the exchange of chunk k runs under the detector pass of chunk k+1.  A rank receives
+         (its clips) x T rows -- 1/N of what an all-gather would deliver;
+      3. ConvLSTM recurrence + 1x1 + decode + association on the owner (the recurrence is sequential in T, so it
+         cannot be split further; with fewer clips than ranks the surplus ranks idle in this phase);
+      4. the cross-stream detection all-gather of gather_detections, rows put back in global clip order.
+    Returns the global table like gather_detections.  Single process: identical to track_clips + gather_detections.
+    `stats` (dict) receives bytes_received (rows + detection records from other ranks) for this call."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return gather_detections(trk.track_clips(frames, cap=cap))
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     ctx = trk.model.ctx
     frames = trk.detector.model.to_device(frames)
-    n_clips, T = frames.shape[:2]
-    mine = frame_shard_times(T, rank, world)
-    Tl = (T + world - 1) // world
+    n_clips = frames.shape[0]
+    local_only = T is not None
+    if T is None:
+        T = frames.shape[1]
+    mine_t = frame_shard_times(T, rank, world)
+    if local_only:
+        assert frames.shape[1] == len(mine_t), "rank %d owns %d time steps of T=%d, got %d frames per clip" % (rank, len(mine_t), T, frames.shape[1])
+    Tl = (T + world - 1) // world                      # local slots per clip, padded
+    n_own = (n_clips + world - 1) // world             # clips per owner, padded
     gh, gw = ctx.grid
-    z_local = torch.zeros((n_clips, Tl, gh, gw, ctx.track_row_width()), dtype=torch.float32, device=ctx.device)
-    if mine:
-        sub = frames[:, mine].contiguous()
-        z = ctx.track_detect(sub.reshape((n_clips * len(mine),) + tuple(frames.shape[2:])))
-        z_local[:, :len(mine)] = z.reshape((n_clips, len(mine)) + tuple(z.shape[1:]))
-    z_all = stitch_frame_rows(_all_gather_cat(z_local.unsqueeze(0), group), T, world)
-    lo, hi = shard_range(n_clips, rank, world)
-    if hi > lo:
-        res = trk.decode_and_associate(ctx.track_recurrent(z_all[lo:hi].contiguous()), cap=cap)
+    rw = ctx.track_row_width()
+    # clip order of the send buffer: owner-major, each owner's clips in increasing index
+    perm = [c for r in range(world) for c in owned_clips(n_clips, r, world)]
+    slot_of = {}
+    for r in range(world):
+        for k, c in enumerate(owned_clips(n_clips, r, world)):
+            slot_of[c] = (r, k)
+    # the schedule is the same on every rank (a collective needs equal shapes everywhere): the PADDED local time axis
+    # [0, Tl) is cut into `chunks` pieces; a rank whose last slot does not exist (T not a multiple of N) sends zeros
+    chunks = max(1, min(int(chunks), Tl))
+    bounds = [(Tl * i) // chunks for i in range(chunks + 1)]
+    pending = []
+    for ci in range(chunks):
+        j0, j1 = bounds[ci], bounds[ci + 1]
+        send = torch.zeros((world, n_own, j1 - j0, gh, gw, rw), dtype=torch.float32, device=ctx.device)
+        jr = min(j1, len(mine_t))                      # slots of this chunk that exist on this rank
+        if jr > j0:
+            sub = (frames[:, j0:jr] if local_only else frames[:, mine_t[j0:jr]]).contiguous()
+            z = ctx.track_detect(sub.reshape((n_clips * (jr - j0),) + tuple(frames.shape[2:])))
+            z = z.reshape((n_clips, jr - j0) + tuple(z.shape[1:]))
+            for c in range(n_clips):
+                r, k = slot_of[c]
+                send[r, k, :jr - j0] = z[c]
+        # issued asynchronously: the exchange of this chunk overlaps the detector pass of the next one (nccl orders the
+        # collective after the kernels already queued on the current stream)
+        recv, work = _all_to_all_rows(send, group, async_op=True)
+        pending.append((j0, j1, recv, work))
+    my_owned = owned_clips(n_clips, rank, world)
+    z_mine = torch.zeros((len(my_owned), T, gh, gw, rw), dtype=torch.float32, device=ctx.device)
+    recv_bytes = 0
+    for j0, j1, recv, work in pending:
+        work.wait()
+        recv = recv.to(ctx.device)
+        for src in range(world):
+            ts = frame_shard_times(T, src, world)[j0:j1]
+            if ts and my_owned:
+                z_mine[:, ts] = recv[src, :len(my_owned), :len(ts)]
+                if src != rank:
+                    recv_bytes += len(my_owned) * len(ts) * gh * gw * rw * 4
+    if my_owned:
+        res = trk.decode_and_associate(ctx.track_recurrent(z_mine), cap=cap)
     else:
         res = trk.empty_result(T, cap)
-    return gather_detections(res, n_clips_max=(n_clips + world - 1) // world, group=group)
+    if stats is not None:
+        stats["bytes_received"] = stats.get("bytes_received", 0) + recv_bytes
+    return gather_detections(res, n_clips_max=n_own, group=group, clip_ids=perm, stats=stats,
+                             ctx=ctx if getattr(ctx, "pack_detections", None) else None)
 
 
 def gather_frame_rows(rows_local, group=None):

@@ -92,20 +92,34 @@ def _report(name, payload):
     print(name, json.dumps(payload))
 
 
+_SETUP = {}
+
+
+def _setup_config(size, n_clips, T, target_boxes):
+    """frames, tracker (calibrated exactly as bench.py does) and the ORACLE's tracking grids of one configuration.  The
+    oracle forward is the expensive part (n_clips*T frames of the whole graph on the host), so the per-frame-threshold
+    test and the default-threshold test of a configuration share it."""
+    key = (size, n_clips, T, target_boxes)
+    if key not in _SETUP:
+        import bench
+        dev = torch.device("cuda", torch.cuda.current_device())
+        C = 12
+        frames = bench.make_frames(n_clips, T, size, size, dev, seed0=42)
+        trk, blob, tw = bench.build_tracker(size, size, T, target_boxes, frames)
+        layers, used = orc.parse_darknet_blob(blob, C)
+        assert used == blob.size
+        host = frames.cpu().numpy()
+        ref_trk = np.stack([orc.tracker_forward(orc.normalize_u8(host[i]), layers, tw)[0] for i in range(n_clips)])
+        _SETUP.clear()          # one configuration at a time (the frames and workspaces of a 608x608 step are large)
+        _SETUP[key] = (frames, trk, ref_trk)
+    return _SETUP[key]
+
+
 def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_policy, min_boxes_per_frame):
-    import bench
-    dev = torch.device("cuda", torch.cuda.current_device())
     C = 12
-    frames = bench.make_frames(n_clips, T, size, size, dev, seed0=42)
-    trk, blob, tw = bench.build_tracker(size, size, T, target_boxes, frames)
+    frames, trk, ref_trk = _setup_config(size, n_clips, T, target_boxes)
     ctx = trk.model.ctx
     G = size // 32
-
-    # ---- oracle forward (the expensive part: n_clips*T frames of the whole graph on the host)
-    layers, used = orc.parse_darknet_blob(blob, C)
-    assert used == blob.size
-    host = frames.cpu().numpy()
-    ref_trk = np.stack([orc.tracker_forward(orc.normalize_u8(host[i]), layers, tw)[0] for i in range(n_clips)])
 
     # ---- thresholds from the oracle's decision values (module docstring)
     scores = np.stack([[oracle_scores(ref_trk[i, t], C) for t in range(T)] for i in range(n_clips)])
@@ -196,6 +210,38 @@ def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_pol
         assoc_threshold=assoc_thr, assoc_margin=m_assoc, ids_bit_exact=True, kernels=sorted(n for n in names if ":" in n)))
 
 
+def _track_config_at_reference_defaults(size, n_clips, T, target_boxes, cap, tag, max_flip_frames):
+    """The same configuration at the thresholds a user of the reference gets -- OBJ_THRESHOLD 0.5 / NMS_THRESHOLD 0.45
+    (KerasYOLO.py:43-44), ASSOC_THRESHOLD 0.3 -- with every discrete disagreement between the
+    HIP path and the oracle accounted for (tests/flip_accounting.py): frames without an oracle decision inside the
+    MEASURED error band of its threshold must be identical; a differing box must trace to an in-band decision; track
+    ids must be bit-identical up to a clip's first in-band decision.  Writes the flip statistics to
+    profiles/parity_<tag>.json (via gpurun_out/)."""
+    import flip_accounting as fa
+    C = 12
+    frames, trk, ref_trk = _setup_config(size, n_clips, T, target_boxes)
+    ctx = trk.model.ctx
+    trk.OBJ_THRESHOLD, trk.NMS_THRESHOLD, trk.ASSOC_THRESHOLD = 0.5, 0.45, 0.3
+    res = trk.track_clips(frames, cap=cap)
+    got = res["netout"]
+    flat = got.reshape((n_clips * T,) + tuple(got.shape[2:])).contiguous()
+    ncell = flat.shape[1] * flat.shape[2] * flat.shape[3]
+    # the HIP kernel's OWN class scores: its decode with nothing thresholded and nothing suppressed
+    post = ctx.decode(flat, 0.0, 2.0, ANCHORS, C, cap=ncell, want_post=True)["post"]
+    got_scores = post[..., 5:].reshape(n_clips, T, ncell, C).cpu().numpy()
+    rep = fa.account(ref_trk, got.cpu().numpy(), got_scores, res["boxes"].cpu().numpy(), res["counts"].cpu().numpy(),
+                     res["ids"].cpu().numpy(), res["nids"].cpu().numpy(), ANCHORS, C, 0.5, 0.45, 0.3)
+    rep["config"] = "%d clips x T=%d x %dx%d, C=12, default policy, reference-default thresholds" % (n_clips, T, size, size)
+    _report("parity_%s.json" % tag, rep)
+    assert rep["box_coord_err"] < 1e-3 and rep["box_iou_min"] >= 0.999
+    assert rep["frames_with_a_flip"] <= max_flip_frames, "%d of %d frames flipped" % (rep["frames_with_a_flip"], rep["frames"])
+    assert rep["boxes_in_identical_frames"] > 0
+
+
+def test_configs2_track_416_reference_default_thresholds():
+    _track_config_at_reference_defaults(416, 9, 30, 32, 128, "r03_defaults_track416", max_flip_frames=27)
+
+
 def test_configs2_benched_track_416_vs_oracle():
     """BASELINE configs[2] as bench.py runs it: this is the path the headline number is measured on."""
     _track_config_vs_oracle(416, 9, 30, 32, 128, "r02_track416",
@@ -210,6 +256,10 @@ def test_configs4_track_608_128_boxes_vs_oracle():
     _track_config_vs_oracle(608, 4, 30, 400, 640, "r02_track608",
                             ["wino_input:convlstm_xproj", "wino_input:convlstm_step", "wino_input:conv_22",
                              "conv_fused:conv_2", "conv_fused:conv_3"], min_boxes_per_frame=100)    # 400 candidates/frame -> >= 100 tracks after NMS
+
+
+def test_configs4_track_608_reference_default_thresholds():
+    _track_config_at_reference_defaults(608, 4, 30, 400, 640, "r03_defaults_track608", max_flip_frames=12)
 
 
 def test_configs3_tinytracker_T64_vs_oracle():

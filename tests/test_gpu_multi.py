@@ -149,3 +149,152 @@ def test_bench_two_ranks_on_one_gpu(shard):
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == ("strong" if shard == "frame" else "weak")
     frames_total = 2 * 4 * (1 if shard == "frame" else 2)
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 - frames_total) < 1e-6 * frames_total
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2 ...` typed as a plain command (no torchrun on the command line, no WORLD_SIZE in the
+    environment): bench.py re-executes itself under torch.distributed.run with one rank per GPU and rank 0 prints the
+    one JSON line.  Here both ranks share the box's single GPU over gloo (DT_ONE_DEVICE / DT_DIST_BACKEND); on an
+    8-GPU node the same command uses RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DT_ONE_DEVICE="1", DT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "2",
+           "--T", "4", "--size", "96", "--boxes", "4", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["exchange_bytes_received_per_step_rank0"] > 0
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 2 * 2 * 4) < 1e-5
+
+
+def test_native_pack_unpack_matches_host_logic(ctx):
+    """dt_pack_detections / dt_unpack_detections (the exchange a C-ABI caller has) against parallel.py's torch
+    statements of the same layout: bit-identical rows, tables, global ids; padding rows and empty ranks handled."""
+    import torch
+    from parallel import _pack_rows, _unpack_rows, global_track_ids
+    dev = ctx.device
+    torch.manual_seed(5)
+    T, cap = 7, 9
+    shards = [3, 0, 2, 4]                     # clips per "rank"; rows padded to 4
+    n_pad = max(shards)
+    parts, tables = [], []
+    for n in shards:
+        boxes = torch.rand(n, T, cap, 8, device=dev)
+        counts = torch.randint(0, cap + 1, (n, T), dtype=torch.int32, device=dev)
+        ids = torch.randint(-1, 6, (n, T, cap), dtype=torch.int32, device=dev)
+        nids = torch.randint(0, 7, (n,), dtype=torch.int32, device=dev)
+        rows = ctx.pack_detections(boxes, counts, ids, nids, n_pad)
+        assert rows.shape == (n_pad, T * cap * 8 + T * cap + T + 2)
+        assert torch.equal(rows, _pack_rows(boxes, counts, ids, nids, n_pad))
+        parts.append(rows)
+        tables.append((boxes, counts, ids, nids))
+    allrows = torch.cat(parts).contiguous()
+    b, c, i, n, g = ctx.unpack_detections(allrows, T, cap)
+    wb, wc, wi, wn = _unpack_rows(allrows, T, cap)
+    assert torch.equal(b, wb) and torch.equal(c, wc) and torch.equal(i, wi) and torch.equal(n, wn)
+    assert torch.equal(b, torch.cat([t[0] for t in tables])) and b.shape[0] == sum(shards)
+    assert torch.equal(g, global_track_ids(wi, wn))
+    with pytest.raises(AssertionError):
+        ctx.pack_detections(*tables[3], 2)           # 4 clips into 2 rows: refused with a clear message
+
+
+_FRAMESHARD4 = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import object_tracking_amd
+from parallel import global_track_ids, track_clips_frame_sharded, init_from_env, frame_shard_times, gather_frame_rows
+from models_tracking.MultiObjDetTracker import MultiObjDetTracker
+from utility import synth
+rank, world, _ = init_from_env()
+H = W = 96; T = 6; N = 3; C = 12
+class Trk(MultiObjDetTracker):
+    IMAGE_H, IMAGE_W = H, W
+    GRID_H, GRID_W = 3, 3
+    SEQUENCE_LENGTH = T
+    LOAD_MODEL = False
+    OBJ_THRESHOLD = 0.3
+tw = synth.synth_tracker_weights(C); tw["out_kernel"] = tw["out_kernel"] * 40.0; tw["out_bias"][4::17] = 1.5
+trk = Trk(detector_weights=synth.synth_darknet_blob(C), tracker_weights=tw)
+frames = np.stack([synth.synth_clip(T, H, W, 2, seed=500 + i) for i in range(N)])
+ref = trk.track_clips(frames)
+mine = frame_shard_times(T, rank, world)
+st = {}
+out = track_clips_frame_sharded(trk, np.ascontiguousarray(frames[:, mine]), T=T, chunks=2, stats=st)      # sharded ingest
+ok = (torch.equal(out["counts"], ref["counts"]) and torch.equal(out["boxes"][..., 5], ref["boxes"][..., 5])
+      and torch.equal(out["boxes"][..., 7], ref["boxes"][..., 7])
+      and torch.allclose(out["boxes"], ref["boxes"], rtol=1e-4, atol=1e-5)
+      and torch.equal(out["ids"], ref["ids"]) and torch.equal(out["gids"], global_track_ids(ref["ids"], ref["nids"]))
+      and int(ref["counts"].sum()) > 0 and st["bytes_received"] > 0)
+# TinyTracker frame-shard (BASELINE configs[3]): rows of this rank's slice of the time axis, all-gathered, LSTM replicated
+from models_detection.KerasYOLO import KerasYOLO
+from models_tracking.TinyTracker import TinyTracker
+Tt, S = 64, 2
+det = KerasYOLO({'LABELS': [str(i) for i in range(C)], 'BATCH_SIZE': 4, 'IMAGE_H': H, 'IMAGE_W': W, 'GRID_H': 3, 'GRID_W': 3},
+                weights=synth.synth_darknet_blob(C, head_std=0.01))
+ctx = det.model.ctx
+cfg = {"model_tracker": {"name": "TinyTracker", "lstm_units": 512, "sequence_length": Tt}, "train": {"pool": "Global", "batch_size": 4}}
+tt = TinyTracker(cfg, feature_dims=(H // 16, W // 16, 512), weights=synth.synth_tiny_weights(512), ctx=ctx)
+fr = torch.from_numpy(np.stack([synth.synth_clip(Tt, H, W, 2, seed=900 + i) for i in range(S)])).to(ctx.device)
+rows_all, _ = tt.frame_rows(fr.reshape(S * Tt, H, W, 3), det)
+want = ctx.tiny_sequence(rows_all.reshape(S, Tt, -1).contiguous())
+tl = Tt // world
+loc = fr[:, rank * tl:(rank + 1) * tl].contiguous()
+rows, _ = tt.frame_rows(loc.reshape(S * tl, H, W, 3), det)
+got = ctx.tiny_sequence(gather_frame_rows(rows.reshape(S, tl, -1).contiguous()))
+ok &= bool(torch.allclose(got, want, rtol=0, atol=2e-5)) and got.shape == (S, Tt, 4)
+print("RANK", rank, "OK" if ok else "MISMATCH", int(ref["counts"].sum()), flush=True)
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+def test_frame_shard_four_ranks_one_gpu(tmp_path):
+    """4 ranks (gloo, one device): MultiObjDetTracker frame-shard with sharded ingest, rows to round-robin owners in two
+    chunks -- ids identical to one process (3 clips on 4 ranks: one rank owns no clip); and the TinyTracker T=64
+    frame-shard (gather_frame_rows) equal to the one-process sequence."""
+    script = tmp_path / "fs4.py"
+    script.write_text(_FRAMESHARD4)
+    procs, outs = _run_ranks(script, 4, {"DT_ONE_DEVICE": "1", "DT_DIST_BACKEND": "gloo"}, 29771, timeout=900)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("RANK %d OK" % r) in o, o[-3000:]
+
+
+def test_graph_replay_with_caller_owned_rows():
+    """dt_graph_enable + dt_track_recurrent with a DIFFERENT caller-owned z buffer on every call (what the
+    frame-shard does): a captured graph must never replay a stale row pointer -- every call equals the ungraphed
+    result for ITS rows, and dt_track_forward (library-owned z) still replays beside it."""
+    import numpy as np
+    import torch
+    from models_tracking.MultiObjDetTracker import MultiObjDetTracker
+    from utility import synth
+    H = W = 96; T = 5; N = 2; C = 12
+
+    class Trk(MultiObjDetTracker):
+        IMAGE_H, IMAGE_W = H, W
+        GRID_H, GRID_W = 3, 3
+        SEQUENCE_LENGTH = T
+        LOAD_MODEL = False
+    trk = Trk(detector_weights=synth.synth_darknet_blob(C), tracker_weights=synth.synth_tracker_weights(C))
+    ctx = trk.model.ctx
+    dev = ctx.device
+    clips = [torch.from_numpy(np.stack([synth.synth_clip(T, H, W, 2, seed=300 + 10 * k + i) for i in range(N)])).to(dev) for k in range(4)]
+    zs = [ctx.track_detect(c.reshape(N * T, H, W, 3)).reshape(N, T, 3, 3, -1).clone() for c in clips]
+    want = [ctx.track_recurrent(z) for z in zs]
+    want_fwd = [ctx.track_forward(c, want_det=False) for c in clips]
+    assert not torch.equal(want[0], want[1])
+    ctx.graph_enable(True)
+    try:
+        for rep in range(2):
+            for k, z in enumerate(zs):
+                zz = z.clone()                      # a fresh buffer each call: a stale captured pointer would show
+                got = ctx.track_recurrent(zz)
+                assert torch.equal(got, want[k]), "graph replay used another call's rows (call %d, pass %d)" % (k, rep)
+                del zz
+            for k, c in enumerate(clips):
+                assert torch.equal(ctx.track_forward(c, want_det=False), want_fwd[k])
+        assert ctx.profile_read("graph_replay")["launches"] > 0
+    finally:
+        ctx.graph_enable(False)

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(mi355_dt.LIB_PATH)
     for s in declared:
         assert hasattr(lib, s), "missing export " + s
-    assert lib.dt_abi_version() == 103
+    assert lib.dt_abi_version() == 104
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -323,31 +323,47 @@ class Trk(object):
 
 torch.manual_seed(1)
 ok = True
-for (n_clips, T) in [(3, 5), (1, 4), (4, 2)]:      # uneven time shards, fewer clips than ranks, T == world
+for (n_clips, T) in [(3, 5), (1, 4), (4, 2), (5, 9), (2, 1)]:   # uneven time shards, fewer clips than ranks, T == world, T < world
     frames = torch.randint(0, 255, (n_clips, T, 4, 4, 3), dtype=torch.uint8)
     trk = Trk()
     want = trk.track_clips(frames, cap=4)          # the single-process table, no collective
     want["gids"] = global_track_ids(want["ids"], want["nids"])
-    Ctx.calls = []
-    got = track_clips_frame_sharded(trk, frames, cap=4)
-    ok &= all(torch.equal(got[k], want[k]) for k in ("boxes", "counts", "ids", "nids", "gids"))
-    ok &= Ctx.calls == ([n_clips * len(frame_shard_times(T, rank, world))] if frame_shard_times(T, rank, world) else [])
+    mine = frame_shard_times(T, rank, world)
+    for chunks in (1, 2, 3):
+        for local in (False, True):                # whole batch on every rank / sharded ingest: only this rank's frames
+            Ctx.calls = []
+            st = {}
+            if local:
+                got = track_clips_frame_sharded(trk, frames[:, mine].contiguous(), cap=4, T=T, chunks=chunks, stats=st)
+            else:
+                got = track_clips_frame_sharded(trk, frames, cap=4, chunks=chunks, stats=st)
+            ok &= all(torch.equal(got[k], want[k]) for k in ("boxes", "counts", "ids", "nids", "gids"))
+            ok &= sum(Ctx.calls) == n_clips * len(mine)          # the detector ran on this rank's frames only
+            # rows arrive at the clip's owner only: (own clips) x (other ranks' time steps) rows of 2*3*8 floats
+            own = len(range(rank, n_clips, world))
+            want_rows = own * (T - len(mine)) * 2 * 3 * 8 * 4
+            row_ints = T * 4 * 8 + T * 4 + T + 2
+            want_det = (world - 1) * ((n_clips + world - 1) // world) * row_ints * 4
+            ok &= st["bytes_received"] == want_rows + want_det
 print("RANK", rank, "OK" if ok else "MISMATCH", flush=True)
 dist.barrier(); dist.destroy_process_group()
 sys.exit(0 if ok else 1)
 '''
 
 
-def test_frame_sharded_tracker_gloo_world2(tmp_path):
-    """configs[4] split (SURVEY.md 8e row 3): detector frame-shard {t : t mod N = r}, all-gather of the per-frame rows,
-    recurrence on the clip's owner, detection gather -- with a torch-CPU stand-in for the two library halves, two gloo
-    ranks give exactly the single-process table (also: each rank ran the detector on its own frames only)."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_frame_sharded_tracker_gloo(tmp_path, world):
+    """configs[4] split (SURVEY.md 8e row 3): detector frame-shard {t : t mod N = r} (whole batch on every rank, or
+    sharded ingest: only the rank's own frames), rows sent to the clip's round-robin owner with chunked all_to_all,
+    recurrence on the owner, detection gather in global clip order -- with a torch-CPU stand-in for the two library
+    halves, 2 / 4 gloo ranks give exactly the single-process table incl. the global ids; the detector ran on each rank's
+    own frames only; the bytes a rank received are the owner-only volume."""
     script = tmp_path / "worker_fs.py"
     script.write_text(_WORKER_FRAMESHARD)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29735", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29735 + 10 * world), WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=180)[0] for p in procs]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "RANK %d OK" % r in o, o
