@@ -22,6 +22,7 @@ SOURCES = {
     "winograd.hip": [],
     "wino_fused.hip": [],
     "wino4_fused.hip": [],
+    "wino4s_fused.hip": [],
     "ingest.hip": [],
     "extract.hip": [],
     "exchange.hip": [],

@@ -143,9 +143,13 @@ struct Wino4FusedArgs {
     float *out2;         // 2x2 max-pooled output [B][H/2][W/2][out2_ld] or null (exactly one of out / out2)
     int out2_ld;
     int nby, nbx;        // set by the launcher
+    const float *zeros;  // >= 16 B of device zeros: DMA source of out-of-image patch pixels (wino4s_fused.hip)
 };
 int launch_wino4_fused(hipStream_t st, const Wino4FusedArgs &a);
 void wino4_fused_pack(const float *u36, int npad, int cin, int cout, float *dst);
+// second-generation fused F(4x4,3x3) kernel: U staged through LDS by DMA, in-register output transform, persistent (wino4s_fused.hip)
+int launch_wino4s_fused(hipStream_t st, const Wino4FusedArgs &a, const float *zeros);
+void wino4s_fused_pack(const float *u36, int npad, int cin, int cout, float *dst);
 int launch_wino2_fused_pool(hipStream_t st, const WinoFusedArgs &a);
 void wino2_fused_pack(const float *hwio, const float *scale, float *dst);
 int launch_wino_input(hipStream_t st, const WinoArgs &a);
@@ -225,6 +229,7 @@ struct ConvLayer {
     float *wino_alt = nullptr;           // device, F(4x4) weights kept next to F(6x6) ones for small-batch launches, or null
     float *fused = nullptr;              // device, fused-Winograd weights (32 -> 64 pooled layer: conv_2) or null
     float *fused4 = nullptr;             // device, fused F(4x4,3x3) weights (Cin 64/128 -> Cout 128/256: conv_3/5/6/8) or null
+    float *fused4s = nullptr;            // device, the same for the LDS-staged kernel (wino4s_fused.hip; also conv_2's shape) or null
     float *bias = nullptr;               // device, [npad]
     float *scale = nullptr;              // device, [cout]: folded BatchNorm scale (dt_detector_extract un-folds with it) or null
     bool scale_has_zero = false;
@@ -244,6 +249,8 @@ struct Policy {
     int wino_cfg = -1, wino_gn = -1;   // DT_WINO_CFG / DT_WINO_GN (A/B runs)
     int ksplit = 0;          // DT_KSPLIT
     int conv_cfg = -1;       // DT_CONV_CFG
+    int w4s = 1;             // DT_W4S: 1 = the LDS-staged fused F(4x4) kernel (wino4s_fused.hip) where fused4 applies, 0 = wino4_fused.hip;
+                             //         2 = also conv_2 (instead of its fused F(2x2) kernel)
     int persist = 1;         // DT_PERSIST: 0 = one tile per workgroup for the GEMM-shaped launches (A/B runs)
     int xcd_remap = 1;       // DT_XCD_REMAP: 0 = plain tile numbering (L2 traffic experiments)
     int tile_gn = -1;        // DT_TILE_GN: column tiles per group of the tile order; -1 = per-layer default

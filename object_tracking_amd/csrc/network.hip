@@ -202,6 +202,7 @@ extern "C" void dt_destroy(dt_ctx *ctx)
         if (ctx->layers[i].wino_alt) (void)hipFree(ctx->layers[i].wino_alt);
         if (ctx->layers[i].fused) (void)hipFree(ctx->layers[i].fused);
         if (ctx->layers[i].fused4) (void)hipFree(ctx->layers[i].fused4);
+        if (ctx->layers[i].fused4s) (void)hipFree(ctx->layers[i].fused4s);
         if (ctx->layers[i].scale) (void)hipFree(ctx->layers[i].scale);
     }
     float *singles[] = {ctx->conv1_w, ctx->conv1_b, ctx->lut255, ctx->anchors_dev, ctx->trk_wx, ctx->trk_bx,
@@ -287,12 +288,21 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
     if (L.wino_alt) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino_alt); L.wino_alt = nullptr; }
     if (L.fused) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused); L.fused = nullptr; }
     if (L.fused4) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused4); L.fused4 = nullptr; }
-    if (ks == 3 && (cin == 64 || cin == 128) && cout % 128 == 0 && cout <= 256 && ctx->pol.wino != 0 && ctx->pol.fused4 != 0) {
-        // conv_3 / conv_5 / conv_6 / conv_8's shapes: fused F(4x4,3x3) kernel (wino4_fused.hip)
+    if (L.fused4s) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused4s); L.fused4s = nullptr; }
+    const bool f4_shape = (cin == 64 || cin == 128) && cout % 128 == 0 && cout <= 256;
+    const bool f4s_conv2 = cin == 32 && cout == 64 && ctx->pol.w4s == 2;
+    if (ks == 3 && (f4_shape || f4s_conv2) && ctx->pol.wino != 0 && ctx->pol.fused4 != 0) {
+        // conv_3 / conv_5 / conv_6 / conv_8's shapes (and conv_2's with DT_W4S=2): fused F(4x4,3x3) kernels
         std::vector<float> u36((size_t)36 * L.npad * cin), uf((size_t)36 * cin * cout);
         wino_pack_weights(4, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale, u36.data());
-        wino4_fused_pack(u36.data(), L.npad, cin, cout, uf.data());
-        if ((rc = upload(ctx, &L.fused4, uf))) return rc;
+        if (f4_shape) {
+            wino4_fused_pack(u36.data(), L.npad, cin, cout, uf.data());
+            if ((rc = upload(ctx, &L.fused4, uf))) return rc;
+        }
+        if (ctx->pol.w4s != 0) {
+            wino4s_fused_pack(u36.data(), L.npad, cin, cout, uf.data());
+            if ((rc = upload(ctx, &L.fused4s, uf))) return rc;
+        }
     }
     if (ks == 3 && cin == 32 && cout == 64 && ctx->pol.wino != 0) {   // conv_2's shape: fused F(2x2,3x3) + pool kernel
         std::vector<float> uf((size_t)16 * 2 * 32 * 2 * 16);
@@ -413,6 +423,7 @@ void policy_from_env(Policy &p)
     p.wino_gn = geti("DT_WINO_GN", d.wino_gn);
     p.ksplit = geti("DT_KSPLIT", d.ksplit);
     p.conv_cfg = geti("DT_CONV_CFG", d.conv_cfg);
+    p.w4s = geti("DT_W4S", d.w4s);
     p.persist = geti("DT_PERSIST", d.persist);
     p.xcd_remap = geti("DT_XCD_REMAP", d.xcd_remap);
     p.tile_gn = geti("DT_TILE_GN", d.tile_gn);
@@ -649,7 +660,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
     snprintf(tag, sizeof(tag), L.idx == 102 ? "tconv_2" : "conv_%d", L.idx);
     // conv_2's shape with its pooling epilogue: the fused Winograd kernel (wino_fused.hip) once there are enough
     // workgroups to fill the chip (one per 8x8 pooled pixels); DT_WINO_FUSED=0 keeps the direct form
-    if (L.fused && epi == EPI_POOL && in_ld == 32 && out_ld == 64 && !((H | W) & 1)) {
+    if (L.fused && !(L.fused4s && ctx->pol.w4s == 2) && epi == EPI_POOL && in_ld == 32 && out_ld == 64 && !((H | W) & 1)) {
         const int fmode = ctx->pol.fused;      // 0: never, 2: at any size (parity tests)
         if (fmode == 2 || (fmode == 1 && (long long)B * ((H / 2 + 7) / 8) * ((W / 2 + 7) / 8) >= 512)) {
             WinoFusedArgs f;
@@ -665,9 +676,9 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
     }
     // conv_3/5/6/8's shapes: the fused F(4x4,3x3) kernel (V and M' stay on the CU) once there are enough 16x16-pixel
     // blocks to fill the chip several times over; below that the unfused forms win (few, half-empty workgroups)
-    if (L.fused4 && in_ld % 4 == 0 && ((epi == EPI_PLAIN && order == ORD_LINEAR) || (epi == EPI_POOL && !((H | W) & 1)))) {
-        const long long blocks = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * (L.cout / 128);
-        if (ctx->pol.fused4 == 2 || (((ctx->pol.fused4 == 1 && L.cin == 64) || ctx->pol.fused4 == 3) && blocks >= 1024)) {
+    if ((L.fused4 || L.fused4s) && in_ld % 4 == 0 && ((epi == EPI_PLAIN && order == ORD_LINEAR) || (epi == EPI_POOL && !((H | W) & 1)))) {
+        const long long blocks = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((L.cout + 127) / 128);
+        if (ctx->pol.fused4 == 2 || (((ctx->pol.fused4 == 1 && L.cin <= 64) || ctx->pol.fused4 == 3) && blocks >= 1024)) {
             Wino4FusedArgs f;
             memset(&f, 0, sizeof(f));
             f.in = in; f.in_bs = a.in_bs; f.in_ld = in_ld; f.B = B; f.H = H; f.W = W; f.Cin = L.cin; f.N = L.cout;
@@ -677,9 +688,19 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
             // executed MFMA FLOPs: 36 positions x (whole 4x4 tiles) x Cin x N x 2; bytes: input once (+ halo 27 %) and the output
             const double tiles = (double)B * ((H + 3) / 4) * ((W + 3) / 4);
             ProfScope ps(ctx, "conv_fused", 2.0 * 36.0 * tiles * L.cin * L.cout,
-                         4.0 * ((double)B * H * W * L.cin * 1.27 * (L.cout / 128) + (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0)), tag);
+                         4.0 * ((double)B * H * W * L.cin * 1.27 * ((L.cout + 127) / 128) + (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0)), tag);
             prof_direct_form(ctx, flops, bytes, true);
-            const int rc = launch_wino4_fused(ctx->stream, f);
+            int rc;
+            if (L.fused4s && ctx->pol.w4s != 0 && (long long)B * a.in_bs < (1ll << 31)) {
+                float *zeros = ws_get(ctx, "zeros256", 256, /*zero_on_grow=*/true);
+                if (!zeros) return DT_ERR_DEVICE;
+                f.u = L.fused4s;
+                rc = launch_wino4s_fused(ctx->stream, f, zeros);
+            } else if (L.fused4) {
+                rc = launch_wino4_fused(ctx->stream, f);
+            } else {
+                rc = 2;
+            }
             if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused F(4x4) launch failed", tag);
             return DT_OK;
         }

@@ -7,8 +7,9 @@ lies closer to its threshold than the value error can legitimately come out diff
 renumbers every later track of its clip.  This module turns "ids are bit-exact" into a checkable statement at the
 operating point a user of the reference gets (OBJ 0.5 / NMS 0.45, KerasYOLO.py:43-44; ASSOC 0.3):
 
-  * eps_s / eps_iou = the MEASURED error of the decision values (class scores near the threshold; IoUs of candidate
-    pairs), over the whole configuration;
+  * eps_s / eps_iou = the MEASURED error of the decision values that can flip (class scores within 0.01 of the score
+    threshold; IoUs of candidate pairs within 0.01 of a threshold), over the whole configuration -- and the error of
+    ALL scores / IoUs is asserted to be below 0.01 (and below the 1e-3 parity bar), so nothing outside that window can;
   * a decision of the ORACLE is "in band" when its margin to the threshold (or to the competing value, for an order
     or arg-max decision) is <= eps;
   * every frame without an in-band decode decision must come out IDENTICAL (box set, order, labels);
@@ -64,16 +65,30 @@ def oracle_scores(grid, anchors, C):
     return post[..., 5:].reshape(-1, C)
 
 
-def measure_eps(sc_ref, sc_got, box_ref, box_got, obj_thr, window=0.25):
-    """measured error of the decision values of one frame: (score error over scores within `window` of the
-    threshold, IoU error over the pairs of cells whose best score is within `window` of / above the threshold)"""
-    near = np.abs(sc_ref - obj_thr) < window
-    e_s = float(np.abs(sc_got - sc_ref)[near].max()) if near.any() else 0.0
-    cells = np.nonzero(sc_ref.max(1) > obj_thr - window)[0]
-    e_iou = 0.0
+def measure_eps(sc_ref, sc_got, box_ref, box_got, obj_thr, iou_thrs, wide=0.25, narrow=0.01):
+    """measured error of the decision values of one frame -> (e_s, e_iou, e_s_wide, e_iou_wide):
+      e_s / e_iou            over the values a flip can come from: scores within `narrow` of the score threshold, IoUs of
+                             candidate pairs within `narrow` of one of `iou_thrs`;
+      e_s_wide / e_iou_wide  over everything within `wide` of / above the score threshold -- account() asserts these stay
+                             below `narrow`, which is what makes the narrow window sufficient (a value further than
+                             `narrow` from its threshold cannot cross it).
+    The error of a class score scales with how undecided its softmax is (p (1 - p) times the logit error), so it is
+    measured where decisions are made, not as one number for the whole grid."""
+    d = np.abs(sc_got.astype(np.float64) - sc_ref.astype(np.float64))
+    dist = np.abs(sc_ref.astype(np.float64) - obj_thr)
+    e_s_wide = float(d[dist < wide].max()) if (dist < wide).any() else 0.0
+    e_s = float(d[dist < narrow].max()) if (dist < narrow).any() else 0.0
+    cells = np.nonzero(sc_ref.max(1) > obj_thr - wide)[0]
+    e_iou = e_iou_wide = 0.0
     if len(cells) >= 2:
-        e_iou = float(np.abs(iou_matrix(box_ref[cells], box_ref[cells]) - iou_matrix(box_got[cells], box_got[cells])).max())
-    return e_s, e_iou
+        ir = iou_matrix(box_ref[cells], box_ref[cells])
+        di = np.abs(ir - iou_matrix(box_got[cells], box_got[cells]))
+        e_iou_wide = float(di.max())
+        for thr in iou_thrs:
+            near = np.abs(ir - thr) < narrow
+            if near.any():
+                e_iou = max(e_iou, float(di[near].max()))
+    return e_s, e_iou, e_s_wide, e_iou_wide
 
 
 def decode_decisions(sc_ref, box_ref, eps_s, eps_iou, obj_thr, nms_thr):
@@ -146,7 +161,7 @@ def assoc_decisions(rows_t, rows_p, eps_iou, assoc_thr):
 
 
 def account(ref_grids, got_grids, got_scores, got_rows, got_counts, got_ids, got_nids, anchors, C,
-            obj_thr=0.5, nms_thr=0.45, assoc_thr=0.3, eps_floor=(1e-7, 1e-6), max_eps=(1e-4, 1e-3)):
+            obj_thr=0.5, nms_thr=0.45, assoc_thr=0.3, eps_floor=(1e-7, 1e-6), max_eps=(1e-3, 1e-3), narrow=0.01):
     """ref_grids / got_grids [n_clips,T,GH,GW,NB,5+C] raw tracking grids (oracle / implementation under test);
     got_scores [n_clips,T,ncell,C] the implementation's own conf*softmax scores (its decode at threshold 0);
     got_rows [n_clips,T,cap,8], got_counts [n_clips,T], got_ids [n_clips,T,cap], got_nids [n_clips]: its outputs at
@@ -159,14 +174,18 @@ def account(ref_grids, got_grids, got_scores, got_rows, got_counts, got_ids, got
     sc_ref = np.empty((n_clips, T, ncell, C), dtype=np.float32)
     bx_ref = np.empty((n_clips, T, ncell, 4), dtype=np.float32)
     eps_s, eps_iou = eps_floor
+    eps_s_wide = eps_iou_wide = 0.0
     for i in range(n_clips):
         for t in range(T):
             sc_ref[i, t] = oracle_scores(ref_grids[i, t], anchors, C)
             bx_ref[i, t] = boxes_of_grid(ref_grids[i, t], anchors)
-            e_s, e_iou = measure_eps(sc_ref[i, t], got_scores[i, t], bx_ref[i, t], boxes_of_grid(got_grids[i, t], anchors), obj_thr)
-            eps_s, eps_iou = max(eps_s, e_s), max(eps_iou, e_iou + eps_floor[1])
-    assert eps_s <= max_eps[0], "score error %g near the threshold exceeds %g" % (eps_s, max_eps[0])
-    assert eps_iou <= max_eps[1], "IoU error %g of candidate pairs exceeds %g" % (eps_iou, max_eps[1])
+            e_s, e_iou, e_sw, e_iw = measure_eps(sc_ref[i, t], got_scores[i, t], bx_ref[i, t], boxes_of_grid(got_grids[i, t], anchors),
+                                                 obj_thr, (nms_thr, assoc_thr), narrow=narrow)
+            eps_s, eps_iou = max(eps_s, e_s + eps_floor[0]), max(eps_iou, e_iou + eps_floor[1])
+            eps_s_wide, eps_iou_wide = max(eps_s_wide, e_sw), max(eps_iou_wide, e_iw)
+    # nothing further than `narrow` from its threshold can cross it; and the parity bars themselves
+    assert eps_s_wide < min(narrow, max_eps[0]), "class-score error %g (scores within 0.25 of the threshold) exceeds %g" % (eps_s_wide, min(narrow, max_eps[0]))
+    assert eps_iou_wide < min(narrow, max_eps[1]), "IoU error %g of candidate pairs exceeds %g" % (eps_iou_wide, min(narrow, max_eps[1]))
 
     # ---- pass 2: the oracle's outputs at the fixed thresholds, in-band decisions, frame-by-frame comparison
     ref_rows = np.zeros((n_clips, T, cap, 8), dtype=np.float32)
@@ -233,7 +252,8 @@ def account(ref_grids, got_grids, got_scores, got_rows, got_counts, got_ids, got
                 id_mismatch += int((got_ids[i, t, :n] != rid[t, :n]).sum())
     n_dec = n_clips * T * ncell * C
     return dict(obj_threshold=obj_thr, nms_threshold=nms_thr, assoc_threshold=assoc_thr,
-                eps_score=eps_s, eps_iou=eps_iou, frames=int(n_clips * T), score_decisions=int(n_dec),
+                eps_score=eps_s, eps_iou=eps_iou, eps_score_whole_window=eps_s_wide, eps_iou_all_pairs=eps_iou_wide,
+                eps_window=narrow, frames=int(n_clips * T), score_decisions=int(n_dec),
                 in_band_decode_decisions=int(n_band), in_band_assoc_decisions_before_break=int(assoc_band),
                 frames_with_in_band_decision=int(dirty_frames), frames_clean_and_identical=int(clean_frames),
                 frames_with_a_flip=int(frame_flip.sum()), flips_per_1e5_score_decisions=1e5 * float(frame_flip.sum()) / n_dec,

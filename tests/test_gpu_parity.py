@@ -1142,8 +1142,10 @@ def test_winograd_randomized_shapes_vs_oracle(ctx, monkeypatch):
     (1, 13, 13, 128, 256, 0),     # odd size, smaller than a block
     (5, 104, 104, 64, 128, 0),    # conv_3's real geometry (6.5 blocks per side)
 ])
-def test_conv_fused_f4x4_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool):
+@pytest.mark.parametrize("w4s", [1, 0])      # 1: the LDS-staged persistent kernel (wino4s_fused.hip), 0: wino4_fused.hip
+def test_conv_fused_f4x4_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool, w4s):
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
+    monkeypatch.setenv("DT_W4S", str(w4s))
     rs = np.random.RandomState(B * 100 + H + W + Cin)
     x = rs.randn(B, H, W, Cin).astype(np.float32)
     w = (rs.randn(3, 3, Cin, Cout) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
@@ -1162,9 +1164,31 @@ def test_conv_fused_f4x4_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool):
     assert relerr(got.cpu().numpy(), other.cpu().numpy()) < 2e-4
 
 
-def test_conv_fused_f4x4_one_hot(ctx, monkeypatch):
+@pytest.mark.parametrize("B,H,W,pool", [(3, 32, 48, 1), (2, 208, 208, 1), (1, 26, 22, 0)])
+def test_conv2_shape_through_staged_f4x4_kernel(ctx, monkeypatch, B, H, W, pool):
+    """DT_W4S=2: conv_2's shape (32 -> 64 channels, pooled) through the LDS-staged F(4x4) kernel instead of its F(2x2) one"""
+    monkeypatch.setenv("DT_WINO_FUSED4", "2")
+    monkeypatch.setenv("DT_W4S", "2")
+    rs = np.random.RandomState(B + H + W)
+    x = rs.randn(B, H, W, 32).astype(np.float32)
+    w = (rs.randn(3, 3, 32, 64) * np.sqrt(2.0 / (9 * 32))).astype(np.float32)
+    b = rs.randn(64).astype(np.float32)
+    ref = orc.conv2d(x, w, b)
+    ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
+    if pool:
+        ref = orc.maxpool2(ref)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=pool)
+    ctx.profile_enable(False)
+    assert ctx.profile_read("conv_fused:conv_0")["launches"] == 1
+    assert relerr(got.cpu().numpy(), ref) < 1e-4
+
+
+@pytest.mark.parametrize("w4s", [1, 0])
+def test_conv_fused_f4x4_one_hot(ctx, monkeypatch, w4s):
     """one-hot taps on small integers: every position / tile offset / channel slot of the fused kernel must line up"""
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
+    monkeypatch.setenv("DT_W4S", str(w4s))
     B, H, W, Cin, Cout = 2, 20, 36, 64, 128
     x = (np.arange(B * H * W * Cin, dtype=np.float32).reshape(B, H, W, Cin) % 251)
     w = np.zeros((3, 3, Cin, Cout), dtype=np.float32)

@@ -9,7 +9,9 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  timeout 1500 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -25 | tee $O/pytest_gpu.txt
+  timeout 1500 python -m pytest tests -m gpu -q --durations=8 > $O/pytest_gpu_full.txt 2>&1
+  tail -25 $O/pytest_gpu_full.txt | tee $O/pytest_gpu.txt
+  grep -E "^E  |^FAILED|Error" $O/pytest_gpu_full.txt | cut -c1-400 | head -60
 fi
 timeout 600 python bench.py --layer-report $O/bench_layers.txt 2>$O/bench.err | tail -1 | tee $O/bench.json
 cd /tmp && export TMPDIR=/tmp
