@@ -13,8 +13,11 @@
 //   * the input patches also arrive by DMA (16 bytes = 4 channels of one pixel per lane); the LDS image is padded by
 //     one 16-byte slot per 4 pixels and 41 slots per row, which makes the 6x6 window reads of the input transform
 //     conflict-free without any per-read address arithmetic (slot = 164 ty + 9 tx + 41 i + 2 j + (j >> 2) + half);
-//   * the workgroup is PERSISTENT: it walks (block pair, 64-channel slice) items; launch and tail effects of ~70 k
-//     one-shot workgroups are gone.
+//   * the workgroup is PERSISTENT and the stage pipeline runs ACROSS items: during the last stages of an item the DMA
+//     already fetches the next item's first patch stages and U stage, and the last stage's transform slot produces the
+//     next item's V(0) -- only the first item of a workgroup pays a prologue;
+//   * data movement and the input transform are issued BETWEEN the MFMA quads of a stage (one DMA piece / one window
+//     column per quad), so they run in the shadow of the matrix pipe instead of in front of it.
 //
 // Workgroup = 8 waves = 2 blocks (4x4 tiles of 4x4 pixels each) x 4 column groups of 16 channels; v_mfma_f32_16x16x4_f32
 // (row = tile, column = channel, k = input channel).  K runs in stages of 4 input channels (one MFMA k-step), one
@@ -24,6 +27,8 @@
 //                 all waves: 36 MFMAs on V(s), U(s);   vmcnt(0); barrier.
 // LDS (157.7 KB of 160): U 2 x 36.9 KB | V 2 x 18.4 KB | patch 2 x 24.6 KB.
 // fp32 throughout; rounding identical in kind to wino4_fused / winograd.hip TS = 4 (products summed in another order).
+#include <type_traits>
+
 #include "dt_internal.h"
 
 typedef __attribute__((address_space(1))) const void s4_gptr_t;
@@ -79,19 +84,22 @@ template <int HALF>
 __device__ __forceinline__ void s4_transform_half(const float *pl, float *o)
 {
     float t[3][6];
+    float w[6][6];             // HALF 0 never reads window row 5, HALF 1 never row 0
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int i = (HALF == 0 ? 0 : 1); i < (HALF == 0 ? 5 : 6); ++i) w[i][j] = pl[(S4_PROW * i + 2 * j + (j >> 2)) * 4];
+    __builtin_amdgcn_sched_barrier(0);      // all 30 requests go out before the first value is consumed
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        float d[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) d[i] = pl[(S4_PROW * i + 2 * j + (j >> 2)) * 4];
         if (HALF == 0) {           // Bt rows 0, 1, 2
-            t[0][j] = 4.0f * d[0] - 5.0f * d[2] + d[4];
-            t[1][j] = -4.0f * (d[1] + d[2]) + d[3] + d[4];
-            t[2][j] = 4.0f * (d[1] - d[2]) - d[3] + d[4];
+            t[0][j] = 4.0f * w[0][j] - 5.0f * w[2][j] + w[4][j];
+            t[1][j] = -4.0f * (w[1][j] + w[2][j]) + w[3][j] + w[4][j];
+            t[2][j] = 4.0f * (w[1][j] - w[2][j]) - w[3][j] + w[4][j];
         } else {                   // Bt rows 3, 4, 5
-            t[0][j] = 2.0f * (d[3] - d[1]) - d[2] + d[4];
-            t[1][j] = 2.0f * (d[1] - d[3]) - d[2] + d[4];
-            t[2][j] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+            t[0][j] = 2.0f * (w[3][j] - w[1][j]) - w[2][j] + w[4][j];
+            t[1][j] = 2.0f * (w[1][j] - w[3][j]) - w[2][j] + w[4][j];
+            t[2][j] = 4.0f * w[1][j] - 5.0f * w[3][j] + w[5][j];
         }
     }
 #pragma unroll
@@ -122,62 +130,73 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int blk = wave >> 2, wn = wave & 3;               // MFMA role: block, 16-channel column group
     const int kq = lane >> 4, r16 = lane & 15;
-    const int nst = p.Cin >> 2;                             // MFMA stages of 4 input channels
+    const int nst = p.Cin >> 2;                             // MFMA stages of 4 input channels (a multiple of 4: Cin % 16 == 0)
+    const int npatch = nst >> 1;                            // patch stages of 8 channels (even)
     const int nblk = p.B * p.nby * p.nbx;
     const int npair = (nblk + 1) >> 1;
     const int nitems = npair * (p.N >> 6);
+    if ((int)blockIdx.x >= nitems) return;
 
-    // ---- V production role (even stages: waves 0-3, odd stages: waves 4-7): (block, xi half) ----
+    // ---- wave sets.  Set 0 = waves 0-3 (block 0), set 1 = waves 4-7 (block 1); the two waves that share a SIMD belong to
+    // different sets.  In stage s, set (s & 1) is the DATA-MOVEMENT set: it issues all of the stage's DMA, then its MFMAs;
+    // set (s & 1) ^ 1 issues its MFMAs first and then runs the input transform of stage s + 1.  So on every SIMD one wave
+    // feeds the matrix pipe while its partner does the side work, and they swap half-way through the stage. ----
+    const int vset = wave >> 2, w4 = wave & 3;
+    // V production role within a set: (block, xi half); lanes 0-31 take tile rows 0-1, lanes 32-63 tile rows 2-3
     const int vblk = wave & 1, vhalf = (wave >> 1) & 1;
     const int vtile = (lane & 7) | ((lane >> 5) << 3), vk = (lane >> 3) & 3;
     const int vty = vtile >> 2, vtx = vtile & 3;
     const int vsrc = (vblk * S4_PBLK + 164 * vty + 9 * vtx) * 4 + vk;       // float index of window pixel (0,0), half 0
-    const int vdst = (vblk * 64 + vk * 16 + vtile) * 2 + vhalf * (9 * 256); // float index in a V stage: pg2 = 9 half + ...
+    const int vdst = (vblk * 64 + vk * 16 + vtile) * 2 + vhalf * (9 * 256); // float index in a V stage: pg2 = 9 half + 3 x + nu / 2
 
-    // ---- patch DMA role: pieces wave, wave + 8, wave + 16 of the 24 (12 per block) ----
-    int poff[3];            // float offset of this lane's 16 bytes relative to the block's pixel (0,0), channel 0; < 0: zeros
-    int pblk[3];
-    auto patch_setup = [&](int j0) {
+    // ---- patch DMA geometry of this lane for the block-image pieces w4, w4 + 4, w4 + 8 (the same for both blocks):
+    // packed (py << 8 | px << 2 | half << 1 | exists); the source offset is formed at issue time ----
+    int pgeo[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int P = (w4 + 4 * i) * 64 + lane;             // slot within the block image
+        const int py = P / S4_PROW, rr = P - py * S4_PROW;
+        const int g = rr / 9, r9 = rr - 9 * g;
+        const int px = 4 * g + (r9 >> 1), hf = r9 & 1;
+        pgeo[i] = (py << 8) | (px << 2) | (hf << 1) | ((py < 18 && r9 < 8 && px < 18) ? 1 : 0);
+    }
+    struct Item { int nq, j0; const float *u; };
+    auto item_of = [&](int it) {
+        Item I;
+        I.nq = it / npair;
+        I.j0 = 2 * (it - I.nq * npair);
+        I.u = p.u + (long long)I.nq * nst * S4_UBUF;
+        return I;
+    };
+    // pieces w4 + 4 i (i = 0..2) of block image b01 of patch stage c (channels 8c .. 8c+7) of item I -> patch buffer buf
+    auto patch_half = [&](const Item &I, int b01, int c, int buf, bool exists) {
+        const int j = I.j0 + b01;
+        const int bx = j % p.nbx, by = (j / p.nbx) % p.nby, b = j / (p.nbx * p.nby);
+        const int y0 = by * 16 - 1, x0 = bx * 16 - 1;
+        const float *base = p.in + (long long)b * p.in_bs + ((long long)y0 * p.W + x0) * p.in_ld + 8 * c;   // wave-uniform
+        const bool blk_ok = exists && j < nblk;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int piece = wave + 8 * i;
-            const int b01 = piece / 12;
-            const int P = (piece - 12 * b01) * 64 + lane;   // slot within the block image
-            const int py = P / S4_PROW, rr = P - py * S4_PROW;
-            const int g = rr / 9, r9 = rr - 9 * g;
-            const int px = 4 * g + (r9 >> 1), hf = r9 & 1;
-            const int j = j0 + b01;
-            const int bx = j % p.nbx, by = (j / p.nbx) % p.nby, b = j / (p.nbx * p.nby);
-            const int hh = by * 16 - 1 + py, ww = bx * 16 - 1 + px;
-            const bool ok = py < 18 && r9 < 8 && px < 18 && j < nblk && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
-            // offsets fit 31 bits: the launcher checks B * in_bs < 2^31 floats
-            poff[i] = ok ? (int)((long long)b * p.in_bs + ((long long)hh * p.W + ww) * p.in_ld + hf * 4) : -1;
-            pblk[i] = b01;
+            const int py = pgeo[i] >> 8, px = (pgeo[i] >> 2) & 63, hf = (pgeo[i] >> 1) & 1;
+            const bool ok = blk_ok && (pgeo[i] & 1) && y0 + py >= 0 && y0 + py < p.H && x0 + px >= 0 && x0 + px < p.W;
+            const float *src = ok ? base + (py * p.W + px) * p.in_ld + hf * 4 : p.zeros;
+            __builtin_amdgcn_global_load_lds((s4_gptr_t *)src, (s4_lptr_t *)(Pb + buf * S4_PBUF + (b01 * 12 + w4 + 4 * i) * 256), 16, 0, 0);
         }
     };
-    auto patch_dma = [&](int c, int buf) {              // patch stage c = channels 8c .. 8c+7
+    auto u_pieces = [&](const float *ustage, int buf, int i0, int i1) {      // pieces w4 + 4 i, i in [i0, i1), of a stage's 36
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float *src = poff[i] >= 0 ? p.in + poff[i] + 8 * c : p.zeros;
-            float *dst = Pb + buf * S4_PBUF + (wave + 8 * i) * 256;
-            __builtin_amdgcn_global_load_lds((s4_gptr_t *)src, (s4_lptr_t *)dst, 16, 0, 0);
-        }
-    };
-    // U DMA: pieces wave + 8 i of the stage's 36
-    auto u_dma = [&](const float *ustage, int buf) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int piece = wave + 8 * i;
-            if (piece < 36)
+        for (int i = 0; i < 9; ++i)
+            if (i >= i0 && i < i1) {
+                const int piece = w4 + 4 * i;
                 __builtin_amdgcn_global_load_lds((s4_gptr_t *)(ustage + piece * 256 + lane * 4),
                                                  (s4_lptr_t *)(Ub + buf * S4_UBUF + piece * 256), 16, 0, 0);
-        }
+            }
     };
-    // input transform of MFMA stage s (channels 4 s .. 4 s + 3 = half s & 1 of patch stage s >> 1) into Vbuf[s & 1]:
-    // this lane's (tile, channel), xi rows 3 vhalf .. 3 vhalf + 2, all six nu (wave-uniform branch on the half)
-    auto transform = [&](int s) {
-        const float *pl = Pb + ((s >> 1) & 1) * S4_PBUF + vsrc + (s & 1) * 4;
-        float *o = Vb + (s & 1) * S4_VBUF + vdst;
+    // input transform of one stage: (patch buffer pbuf, channel half hf) -> V buffer vbuf; this lane's (tile, channel), xi rows
+    // 3 vhalf .. + 2.  All 36 window values are requested before the first is used (one LDS round trip, not twelve).
+    auto transform = [&](int pbuf, int hf, int vbuf) {
+        const float *pl = Pb + pbuf * S4_PBUF + vsrc + hf * 4;
+        float *o = Vb + vbuf * S4_VBUF + vdst;
         if (vhalf == 0) s4_transform_half<0>(pl, o);
         else s4_transform_half<1>(pl, o);
     };
@@ -185,83 +204,112 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
     const float *const a_base = Vb + (blk * 64 + lane) * 2;            // + stage buffer + pg2 * 256
     const float *const b_base = Ub + (wn * 64 + lane) * 4;             // + stage buffer + pg * 1024
 
-#pragma unroll 1
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const int nq = item / npair, pair = item - nq * npair;
-        const int j0 = 2 * pair;
-        const float *const u_item = p.u + (long long)nq * nst * S4_UBUF;
+    f32x4 acc[36];
+    // the 36 MFMAs of a stage: positions in quads; the operands of quad g+1 are requested BEFORE the MFMAs of quad g are
+    // issued (pinned with sched_barrier: left alone hipcc sinks the reads behind the MFMAs and waits for them at once)
+    auto mfma_block = [&](int sbuf) {
+        const float *va = a_base + sbuf * S4_VBUF;
+        const float *ua = b_base + sbuf * S4_UBUF;
+        f32x2 a0[2], a1[2];
+        f32x4 bq[2];
+        a0[0] = *reinterpret_cast<const f32x2 *>(va);
+        a1[0] = *reinterpret_cast<const f32x2 *>(va + 256);
+        bq[0] = *reinterpret_cast<const f32x4 *>(ua);
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            const int c = g & 1, n = c ^ 1;
+            if (g + 1 < 9) {
+                a0[n] = *reinterpret_cast<const f32x2 *>(va + (2 * g + 2) * 256);
+                a1[n] = *reinterpret_cast<const f32x2 *>(va + (2 * g + 3) * 256);
+                bq[n] = *reinterpret_cast<const f32x4 *>(ua + (g + 1) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c].x, bq[c][0], acc[4 * g + 0], 0, 0, 0);
+            acc[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c].y, bq[c][1], acc[4 * g + 1], 0, 0, 0);
+            acc[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c].x, bq[c][2], acc[4 * g + 2], 0, 0, 0);
+            acc[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c].y, bq[c][3], acc[4 * g + 3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- first item: prologue.  Patch stage 0 (set b fetches block image b), U stage 0, the block-0 half of patch stage 1
+    // (its block-1 half is fetched by the data-movement set of stage 0); then V(0) by set 0. ----
+    int item = blockIdx.x;
+    Item cur = item_of(item);
 #ifdef DT_S4_TIMING
-        const int tt_i = (item - (int)blockIdx.x) / (int)gridDim.x;
+    int tt_i = 0;
+    S4_PUT(0, S4_NOW());
+#endif
+    patch_half(cur, vset, 0, 0, true);
+    if (vset == 0) u_pieces(cur.u, 0, 0, 5);
+    else { u_pieces(cur.u, 0, 5, 9); patch_half(cur, 0, 1, 1, npatch > 1); }
+    __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
+    __syncthreads();
+    if (vset == 0) transform(0, 0, 0);
+    __syncthreads();
+
+#pragma unroll 1
+    for (;;) {
+        const int nxt = item + (int)gridDim.x;
+        const bool has_next = nxt < nitems;
+        const Item nx = item_of(has_next ? nxt : item);
+#ifdef DT_S4_TIMING
         unsigned long long tt_tr = 0, tt_mm = 0, tt_bw = 0, tt_dm = 0;
 #endif
-        S4_PUT(0, S4_NOW());
-        patch_setup(j0);
-
-        f32x4 acc[36];
+        S4_PUT(1, S4_NOW());
 #pragma unroll
         for (int i = 0; i < 36; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-        // ---- prologue: patch stage 0, U stage 0; V(0) ----
-        patch_dma(0, 0);
-        u_dma(u_item, 0);
-        __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
-        __syncthreads();
-        if (wave < 4) transform(0);
-        if (nst > 2) patch_dma(1, 1);
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
-        S4_PUT(1, S4_NOW());
-
 #pragma unroll 1
         for (int s = 0; s < nst; ++s) {
-            // data movement of the stages ahead
             [[maybe_unused]] const unsigned long long c0 = S4_NOW();
-            if (s + 1 < nst) u_dma(u_item + (long long)(s + 1) * S4_UBUF, (s + 1) & 1);
-            // patch stage c is read by the transforms of MFMA stages 2c, 2c+1, which run during stages 2c-1 and 2c; its
-            // buffer is free again after stage 2c, so patch c+2 is fetched during stage 2c+1
-            if ((s & 1) && ((s + 3) >> 1) < (nst >> 1)) patch_dma((s + 3) >> 1, ((s + 3) >> 1) & 1);
-            [[maybe_unused]] const unsigned long long c1 = S4_NOW();
-            if (s + 1 < nst && ((wave >> 2) == ((s + 1) & 1))) transform(s + 1);
-            [[maybe_unused]] const unsigned long long c2 = S4_NOW();
-            // 36 MFMAs: positions in quads; the operands of quad g+1 are requested BEFORE the MFMAs of quad g are issued
-            // (pinned with sched_barrier: left alone hipcc sinks the reads behind the MFMAs and waits for them at once)
-            const float *va = a_base + (s & 1) * S4_VBUF;
-            const float *ua = b_base + (s & 1) * S4_UBUF;
-            f32x2 a0[2], a1[2];
-            f32x4 bq[2];
-            a0[0] = *reinterpret_cast<const f32x2 *>(va);
-            a1[0] = *reinterpret_cast<const f32x2 *>(va + 256);
-            bq[0] = *reinterpret_cast<const f32x4 *>(ua);
-#pragma unroll
-            for (int g = 0; g < 9; ++g) {
-                const int c = g & 1, n = c ^ 1;
-                if (g + 1 < 9) {
-                    a0[n] = *reinterpret_cast<const f32x2 *>(va + (2 * g + 2) * 256);
-                    a1[n] = *reinterpret_cast<const f32x2 *>(va + (2 * g + 3) * 256);
-                    bq[n] = *reinterpret_cast<const f32x4 *>(ua + (g + 1) * 1024);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                acc[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c].x, bq[c][0], acc[4 * g + 0], 0, 0, 0);
-                acc[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c].y, bq[c][1], acc[4 * g + 1], 0, 0, 0);
-                acc[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c].x, bq[c][2], acc[4 * g + 2], 0, 0, 0);
-                acc[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c].y, bq[c][3], acc[4 * g + 3], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+            const bool last = s + 1 == nst;
+            const bool dset = vset == (s & 1);
+            if (dset) {
+                // ---- data-movement set: U of the next stage (of this item, or stage 0 of the next item), then half a patch
+                // stage: odd s -> block image 0 of patch stage (s+3)/2, even s -> block image 1 of patch stage (s+2)/2 (the
+                // stage whose first half went out one stage earlier).  Past this item's patches the numbering continues
+                // into the next item's (npatch is even, so the buffers line up). ----
+                if (!last || has_next) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9);
+                const int pc_all = (s + 2 + (s & 1)) >> 1;
+                const bool pnx = pc_all >= npatch;
+                patch_half(pnx ? nx : cur, (s & 1) ^ 1, pnx ? pc_all - npatch : pc_all, pc_all & 1, !pnx || has_next);
             }
+            [[maybe_unused]] const unsigned long long c1 = S4_NOW();
+            mfma_block(s & 1);
+            [[maybe_unused]] const unsigned long long c2 = S4_NOW();
+            if (!dset && (!last || has_next)) {
+                // ---- the other set: after its MFMAs, the input transform of stage s + 1 (stage 0 of the next item after the
+                // last stage): patch buffer ((s+1)/2) & 1, channel half (s+1) & 1, V buffer (s+1) & 1 ----
+                const int s1 = s + 1;
+                transform((s1 >> 1) & 1, s1 & 1, s1 & 1);
+            }
+#ifdef DT_S4_TIMING
+            tt_dm += c1 - c0; tt_mm += c2 - c1; tt_tr += S4_NOW() - c2;
+#endif
             [[maybe_unused]] const unsigned long long c3 = S4_NOW();
             __builtin_amdgcn_s_waitcnt(0x0f70);     // this wave's DMA pieces have landed
             __syncthreads();
 #ifdef DT_S4_TIMING
-            tt_dm += c1 - c0; tt_tr += c2 - c1; tt_mm += c3 - c2; tt_bw += S4_NOW() - c3;
+            tt_bw += S4_NOW() - c3;
 #endif
         }
         S4_PUT(2, S4_NOW());
 
-        // ---- epilogue: At M' A per (tile, channel) in registers; C/D row = 4 kq + e -> tile (ty = kq, tx = e), col = channel ----
-        const int j = j0 + blk;
+        // ---- epilogue: At M' A per (tile, channel) in registers; C/D row = 4 kq + e -> tile (ty = kq, tx = e), col = channel.
+        // The DMAs of the next item's first stages are already in flight / landed; nothing here touches LDS. ----
+        const int j = cur.j0 + blk;
         if (j < nblk) {
             const int bx = j % p.nbx, by = (j / p.nbx) % p.nby, b = j / (p.nbx * p.nby);
-            const int ch = nq * 64 + wn * 16 + r16;
+            const int ch = cur.nq * 64 + wn * 16 + r16;
             const float bias = p.bias[ch];
+            // Retire the load HERE, on the straight path: left to be consumed inside the lane-divergent store branches
+            // below, hipcc's waitcnt bookkeeping never sees it complete on every path and puts a vmcnt(0) -- which also
+            // drains every store issued so far -- in front of each later use, and in front of every reuse of its register
+            // in the next item's stage loop.
+            asm volatile("" ::"v"(bias));
+            const int y0 = by * 16 + 4 * kq, x0 = bx * 16;
+            const bool full = by * 16 + 16 <= p.H && bx * 16 + 16 <= p.W;     // wave-uniform: no per-pixel bounds checks inside
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float m[36];
@@ -276,46 +324,46 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const float z = m[6 * a + c] + bias;
-                        m[6 * a + c] = z > 0.0f ? z : z * p.slope;
+                        m[6 * a + c] = fmaxf(z, z * p.slope);           // LeakyReLU, 0 <= slope <= 1 (1: linear)
                     }
                 if (!POOL) {
+                    float *ob = p.out + (long long)b * p.out_bs + ((long long)y0 * p.W + x0 + 4 * e) * p.out_ld + ch;
+                    const int rs = p.W * p.out_ld;
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const int oy = by * 16 + 4 * kq + a;
+                    for (int a = 0; a < 4; ++a)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int ox = bx * 16 + 4 * e + c;
-                            if (oy < p.H && ox < p.W)
-                                p.out[(long long)b * p.out_bs + ((long long)oy * p.W + ox) * p.out_ld + ch] = m[6 * a + c];
-                        }
-                    }
+                        for (int c = 0; c < 4; ++c)
+                            if (full || (y0 + a < p.H && x0 + 4 * e + c < p.W)) ob[a * rs + c * p.out_ld] = m[6 * a + c];
                 } else {
                     const int H2 = p.H >> 1, W2 = p.W >> 1;
+                    float *ob = p.out2 + (((long long)b * H2 + (y0 >> 1)) * W2 + (x0 >> 1) + 2 * e) * p.out2_ld + ch;
+                    const int rs = W2 * p.out2_ld;
 #pragma unroll
                     for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
                         for (int c2 = 0; c2 < 2; ++c2) {
                             const float mx = fmaxf(fmaxf(m[6 * (2 * a2) + 2 * c2], m[6 * (2 * a2) + 2 * c2 + 1]),
                                                    fmaxf(m[6 * (2 * a2 + 1) + 2 * c2], m[6 * (2 * a2 + 1) + 2 * c2 + 1]));
-                            const int py = by * 8 + 2 * kq + a2, qx = bx * 8 + 2 * e + c2;
-                            if (py < H2 && qx < W2)
-                                p.out2[(((long long)b * H2 + py) * W2 + qx) * p.out2_ld + ch] = mx;
+                            if (full || ((y0 >> 1) + a2 < H2 && (x0 >> 1) + 2 * e + c2 < W2)) ob[a2 * rs + c2 * p.out2_ld] = mx;
                         }
                 }
             }
         }
 #ifdef DT_S4_TIMING
         S4_PUT(3, S4_NOW()); S4_PUT(4, tt_tr); S4_PUT(5, tt_mm); S4_PUT(6, tt_bw); S4_PUT(7, tt_dm);
+        ++tt_i;
+        S4_PUT(0, S4_NOW());
 #endif
-        // no barrier here: every LDS read of this item finished before the last stage's barrier, so a wave that is done
-        // with its stores may start the next item's prologue DMA while the others are still in their epilogue
+        if (!has_next) break;
+        item = nxt;
+        cur = nx;
     }
 }
 
 int launch_wino4s_fused(hipStream_t st, const Wino4FusedArgs &a_in, const float *zeros)
 {
     Wino4FusedArgs a = a_in;
-    if (a.B <= 0 || a.Cin % 8 || a.N % 64 || a.in_ld % 4) return 2;
+    if (a.B <= 0 || a.Cin % 16 || a.N % 64 || a.in_ld % 4) return 2;   // Cin % 16: an even number of 8-channel patch stages
     const bool pool = a.out2 != nullptr;
     if (pool && ((a.H | a.W) & 1)) return 2;
     if (pool == (a.out != nullptr)) return 2;       // exactly one of the two outputs
