@@ -249,8 +249,8 @@ struct Policy {
     int wino_cfg = -1, wino_gn = -1;   // DT_WINO_CFG / DT_WINO_GN (A/B runs)
     int ksplit = 0;          // DT_KSPLIT
     int conv_cfg = -1;       // DT_CONV_CFG
-    int w4s = 1;             // DT_W4S: 1 = the LDS-staged fused F(4x4) kernel (wino4s_fused.hip) where fused4 applies, 0 = wino4_fused.hip;
-                             //         2 = also conv_2 (instead of its fused F(2x2) kernel)
+    int w4s = 2;             // DT_W4S: 2 (default) = the LDS-staged fused F(4x4) kernel (wino4s_fused.hip) where fused4 applies AND for
+                             //         conv_2 (instead of its fused F(2x2) kernel); 1 = not for conv_2; 0 = wino4_fused.hip
     int persist = 1;         // DT_PERSIST: 0 = one tile per workgroup for the GEMM-shaped launches (A/B runs)
     int xcd_remap = 1;       // DT_XCD_REMAP: 0 = plain tile numbering (L2 traffic experiments)
     int tile_gn = -1;        // DT_TILE_GN: column tiles per group of the tile order; -1 = per-layer default

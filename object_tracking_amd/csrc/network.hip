@@ -658,22 +658,6 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
                                 (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0));
     char tag[32];
     snprintf(tag, sizeof(tag), L.idx == 102 ? "tconv_2" : "conv_%d", L.idx);
-    // conv_2's shape with its pooling epilogue: the fused Winograd kernel (wino_fused.hip) once there are enough
-    // workgroups to fill the chip (one per 8x8 pooled pixels); DT_WINO_FUSED=0 keeps the direct form
-    if (L.fused && !(L.fused4s && ctx->pol.w4s == 2) && epi == EPI_POOL && in_ld == 32 && out_ld == 64 && !((H | W) & 1)) {
-        const int fmode = ctx->pol.fused;      // 0: never, 2: at any size (parity tests)
-        if (fmode == 2 || (fmode == 1 && (long long)B * ((H / 2 + 7) / 8) * ((W / 2 + 7) / 8) >= 512)) {
-            WinoFusedArgs f;
-            f.in = in; f.B = B; f.H = H; f.W = W; f.u = L.fused; f.bias = L.bias; f.slope = slope; f.out = out;
-            // executed MFMA FLOPs: 16 positions x (tiles x 32 x 64) x 2; bytes: input once (+halo) and the pooled output
-            ProfScope ps(ctx, "conv_fused", 2.0 * 16.0 * B * (H / 2.0) * (W / 2.0) * 32.0 * 64.0,
-                         4.0 * ((double)B * H * W * 32.0 * 1.27 + (double)B * (H / 2) * (W / 2) * 64.0), tag);
-            prof_direct_form(ctx, flops, bytes, true);
-            const int rc = launch_wino2_fused_pool(ctx->stream, f);
-            if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused Winograd launch failed", tag);
-            return DT_OK;
-        }
-    }
     // conv_3/5/6/8's shapes: the fused F(4x4,3x3) kernel (V and M' stay on the CU) once there are enough 16x16-pixel
     // blocks to fill the chip several times over; below that the unfused forms win (few, half-empty workgroups)
     if ((L.fused4 || L.fused4s) && in_ld % 4 == 0 && ((epi == EPI_PLAIN && order == ORD_LINEAR) || (epi == EPI_POOL && !((H | W) & 1)))) {
@@ -702,6 +686,23 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
                 rc = 2;
             }
             if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused F(4x4) launch failed", tag);
+            return DT_OK;
+        }
+    }
+    // conv_2's shape with its pooling epilogue, when the F(4x4) kernel above did not take it (DT_W4S < 2, or too few blocks):
+    // the fused F(2x2) Winograd kernel (wino_fused.hip) once there are enough
+    // workgroups to fill the chip (one per 8x8 pooled pixels); DT_WINO_FUSED=0 keeps the direct form
+    if (L.fused && epi == EPI_POOL && in_ld == 32 && out_ld == 64 && !((H | W) & 1)) {
+        const int fmode = ctx->pol.fused;      // 0: never, 2: at any size (parity tests)
+        if (fmode == 2 || (fmode == 1 && (long long)B * ((H / 2 + 7) / 8) * ((W / 2 + 7) / 8) >= 512)) {
+            WinoFusedArgs f;
+            f.in = in; f.B = B; f.H = H; f.W = W; f.u = L.fused; f.bias = L.bias; f.slope = slope; f.out = out;
+            // executed MFMA FLOPs: 16 positions x (tiles x 32 x 64) x 2; bytes: input once (+halo) and the pooled output
+            ProfScope ps(ctx, "conv_fused", 2.0 * 16.0 * B * (H / 2.0) * (W / 2.0) * 32.0 * 64.0,
+                         4.0 * ((double)B * H * W * 32.0 * 1.27 + (double)B * (H / 2) * (W / 2) * 64.0), tag);
+            prof_direct_form(ctx, flops, bytes, true);
+            const int rc = launch_wino2_fused_pool(ctx->stream, f);
+            if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused Winograd launch failed", tag);
             return DT_OK;
         }
     }

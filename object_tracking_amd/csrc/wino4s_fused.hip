@@ -68,15 +68,16 @@ extern "C" __attribute__((visibility("default"))) int dt_debug_s4_times(unsigned
 #define S4_PBUF (2 * S4_PBLK * 4)      // floats per patch buffer (two blocks, 8 channels)
 #define S4_LDS_FLOATS (2 * S4_UBUF + 2 * S4_VBUF + 2 * S4_PBUF)
 
-__device__ __forceinline__ void s4_at(float *m, int st)      // At (4x6): 6 inputs -> 4 outputs in the first 4 slots
-{
-    const float a = m[st] + m[2 * st], b = m[st] - m[2 * st], c = m[3 * st] + m[4 * st], e = m[3 * st] - m[4 * st];
-    const float y0 = m[0] + a + c, y1 = b + 2.0f * e, y2 = a + 4.0f * c, y3 = b + 8.0f * e + m[5 * st];
-    m[0] = y0; m[st] = y1; m[2 * st] = y2; m[3 * st] = y3;
-}
-
 typedef float f32x2 __attribute__((ext_vector_type(2)));   // NOT HIP's float2: LDS accesses through the struct type carry TBAA
                                                            // info that makes hipcc wait vmcnt(0) for every LDS-DMA in flight
+
+template <typename T>
+__device__ __forceinline__ void s4_at(T *m, int st)      // At (4x6): 6 inputs -> 4 outputs in the first 4 slots (T: float or f32x2)
+{
+    const T a = m[st] + m[2 * st], b = m[st] - m[2 * st], c = m[3 * st] + m[4 * st], e = m[3 * st] - m[4 * st];
+    const T y0 = m[0] + a + c, y1 = b + 2.0f * e, y2 = a + 4.0f * c, y3 = b + 8.0f * e + m[5 * st];
+    m[0] = y0; m[st] = y1; m[2 * st] = y2; m[3 * st] = y3;
+}
 
 // Bt d B restricted to three xi rows (HALF 0: rows 0-2, HALF 1: rows 3-5) of one 6x6 window; pl = window pixel (0,0) of
 // this lane's channel in the padded patch image, o = this lane's slot of pair 0 of the half in the V stage
@@ -118,6 +119,13 @@ __device__ __forceinline__ void s4_transform_half(const float *pl, float *o)
         *reinterpret_cast<f32x2 *>(o + (3 * x + 2) * 256) = v45;
     }
 }
+
+#ifndef S4_PRIO
+#define S4_PRIO 1           // raise the wave's issue priority while it does side work (DMA issue, input transform) beside its
+#endif                      // partner's MFMA block
+#ifndef S4_PF
+#define S4_PF 2             // MFMA operand prefetch distance in quads (1 or 2)
+#endif
 
 template <bool POOL>
 __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs p)
@@ -210,19 +218,20 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
     auto mfma_block = [&](int sbuf) {
         const float *va = a_base + sbuf * S4_VBUF;
         const float *ua = b_base + sbuf * S4_UBUF;
-        f32x2 a0[2], a1[2];
-        f32x4 bq[2];
-        a0[0] = *reinterpret_cast<const f32x2 *>(va);
-        a1[0] = *reinterpret_cast<const f32x2 *>(va + 256);
-        bq[0] = *reinterpret_cast<const f32x4 *>(ua);
+        constexpr int NB = S4_PF + 1;                      // operand register sets in rotation
+        f32x2 a0[NB], a1[NB];
+        f32x4 bq[NB];
+        auto request = [&](int g, int slot) {
+            a0[slot] = *reinterpret_cast<const f32x2 *>(va + (2 * g) * 256);
+            a1[slot] = *reinterpret_cast<const f32x2 *>(va + (2 * g + 1) * 256);
+            bq[slot] = *reinterpret_cast<const f32x4 *>(ua + g * 1024);
+        };
+#pragma unroll
+        for (int g = 0; g < S4_PF; ++g) request(g, g);
 #pragma unroll
         for (int g = 0; g < 9; ++g) {
-            const int c = g & 1, n = c ^ 1;
-            if (g + 1 < 9) {
-                a0[n] = *reinterpret_cast<const f32x2 *>(va + (2 * g + 2) * 256);
-                a1[n] = *reinterpret_cast<const f32x2 *>(va + (2 * g + 3) * 256);
-                bq[n] = *reinterpret_cast<const f32x4 *>(ua + (g + 1) * 1024);
-            }
+            const int c = g % NB;
+            if (g + S4_PF < 9) request(g + S4_PF, (g + S4_PF) % NB);
             __builtin_amdgcn_sched_barrier(0);
             acc[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c].x, bq[c][0], acc[4 * g + 0], 0, 0, 0);
             acc[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c].y, bq[c][1], acc[4 * g + 1], 0, 0, 0);
@@ -266,6 +275,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
             const bool last = s + 1 == nst;
             const bool dset = vset == (s & 1);
             if (dset) {
+                if (S4_PRIO) __builtin_amdgcn_s_setprio(2);
                 // ---- data-movement set: U of the next stage (of this item, or stage 0 of the next item), then half a patch
                 // stage: odd s -> block image 0 of patch stage (s+3)/2, even s -> block image 1 of patch stage (s+2)/2 (the
                 // stage whose first half went out one stage earlier).  Past this item's patches the numbering continues
@@ -274,6 +284,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
                 const int pc_all = (s + 2 + (s & 1)) >> 1;
                 const bool pnx = pc_all >= npatch;
                 patch_half(pnx ? nx : cur, (s & 1) ^ 1, pnx ? pc_all - npatch : pc_all, pc_all & 1, !pnx || has_next);
+                if (S4_PRIO) __builtin_amdgcn_s_setprio(0);
             }
             [[maybe_unused]] const unsigned long long c1 = S4_NOW();
             mfma_block(s & 1);
@@ -282,7 +293,9 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
                 // ---- the other set: after its MFMAs, the input transform of stage s + 1 (stage 0 of the next item after the
                 // last stage): patch buffer ((s+1)/2) & 1, channel half (s+1) & 1, V buffer (s+1) & 1 ----
                 const int s1 = s + 1;
+                if (S4_PRIO) __builtin_amdgcn_s_setprio(2);
                 transform((s1 >> 1) & 1, s1 & 1, s1 & 1);
+                if (S4_PRIO) __builtin_amdgcn_s_setprio(0);
             }
 #ifdef DT_S4_TIMING
             tt_dm += c1 - c0; tt_mm += c2 - c1; tt_tr += S4_NOW() - c2;
@@ -310,42 +323,70 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
             asm volatile("" ::"v"(bias));
             const int y0 = by * 16 + 4 * kq, x0 = bx * 16;
             const bool full = by * 16 + 16 <= p.H && bx * 16 + 16 <= p.W;     // wave-uniform: no per-pixel bounds checks inside
+            // two tiles (e, e + 1) at a time as float2 lanes: their accumulators are adjacent registers of acc[i], so every
+            // operation of the output transform is one packed instruction (no MFMA runs beside the epilogue -- the one
+            // place where v_pk_* f32 pays)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float m[36];
+            for (int e2 = 0; e2 < 4; e2 += 2) {
+                f32x2 m[36];
 #pragma unroll
-                for (int i = 0; i < 36; ++i) m[i] = acc[i][e];
+                for (int i = 0; i < 36; ++i) { m[i].x = acc[i][e2]; m[i].y = acc[i][e2 + 1]; }
 #pragma unroll
                 for (int nu = 0; nu < 6; ++nu) s4_at(m + nu, 6);        // over xi -> rows a = 0..3 (slots 6 a + nu)
 #pragma unroll
                 for (int a = 0; a < 4; ++a) s4_at(m + 6 * a, 1);        // over nu -> cols c = 0..3
+                const f32x2 bias2 = {bias, bias}, slope2 = {p.slope, p.slope};
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float z = m[6 * a + c] + bias;
-                        m[6 * a + c] = fmaxf(z, z * p.slope);           // LeakyReLU, 0 <= slope <= 1 (1: linear)
+                        const f32x2 z = m[6 * a + c] + bias2;
+                        m[6 * a + c] = __builtin_elementwise_max(z, z * slope2);    // LeakyReLU, 0 <= slope <= 1 (1: linear)
                     }
-                if (!POOL) {
-                    float *ob = p.out + (long long)b * p.out_bs + ((long long)y0 * p.W + x0 + 4 * e) * p.out_ld + ch;
-                    const int rs = p.W * p.out_ld;
+                // two code paths, chosen wave-uniformly: interior blocks store unconditionally (no exec masking, no per-store
+                // scalar work); border blocks check every pixel
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                for (int h = 0; h < 2; ++h) {
+                    const int e = e2 + h;
+                    if (!POOL) {
+                        float *ob = p.out + (long long)b * p.out_bs + ((long long)y0 * p.W + x0 + 4 * e) * p.out_ld + ch;
+                        const int rs = p.W * p.out_ld;
+                        if (full) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (full || (y0 + a < p.H && x0 + 4 * e + c < p.W)) ob[a * rs + c * p.out_ld] = m[6 * a + c];
-                } else {
-                    const int H2 = p.H >> 1, W2 = p.W >> 1;
-                    float *ob = p.out2 + (((long long)b * H2 + (y0 >> 1)) * W2 + (x0 >> 1) + 2 * e) * p.out2_ld + ch;
-                    const int rs = W2 * p.out2_ld;
+                            for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int a2 = 0; a2 < 2; ++a2)
+                                for (int c = 0; c < 4; ++c) ob[a * rs + c * p.out_ld] = m[6 * a + c][h];
+                        } else {
 #pragma unroll
-                        for (int c2 = 0; c2 < 2; ++c2) {
-                            const float mx = fmaxf(fmaxf(m[6 * (2 * a2) + 2 * c2], m[6 * (2 * a2) + 2 * c2 + 1]),
-                                                   fmaxf(m[6 * (2 * a2 + 1) + 2 * c2], m[6 * (2 * a2 + 1) + 2 * c2 + 1]));
-                            if (full || ((y0 >> 1) + a2 < H2 && (x0 >> 1) + 2 * e + c2 < W2)) ob[a2 * rs + c2 * p.out2_ld] = mx;
+                            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    if (y0 + a < p.H && x0 + 4 * e + c < p.W) ob[a * rs + c * p.out_ld] = m[6 * a + c][h];
                         }
+                    } else {
+                        const int H2 = p.H >> 1, W2 = p.W >> 1;
+                        float *ob = p.out2 + (((long long)b * H2 + (y0 >> 1)) * W2 + (x0 >> 1) + 2 * e) * p.out2_ld + ch;
+                        const int rs = W2 * p.out2_ld;
+                        float mx[2][2];
+#pragma unroll
+                        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                            for (int c2 = 0; c2 < 2; ++c2)
+                                mx[a2][c2] = fmaxf(fmaxf(m[6 * (2 * a2) + 2 * c2][h], m[6 * (2 * a2) + 2 * c2 + 1][h]),
+                                                   fmaxf(m[6 * (2 * a2 + 1) + 2 * c2][h], m[6 * (2 * a2 + 1) + 2 * c2 + 1][h]));
+                        if (full) {
+#pragma unroll
+                            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                                for (int c2 = 0; c2 < 2; ++c2) ob[a2 * rs + c2 * p.out2_ld] = mx[a2][c2];
+                        } else {
+#pragma unroll
+                            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                                for (int c2 = 0; c2 < 2; ++c2)
+                                    if ((y0 >> 1) + a2 < H2 && (x0 >> 1) + 2 * e + c2 < W2) ob[a2 * rs + c2 * p.out2_ld] = mx[a2][c2];
+                        }
+                    }
                 }
             }
         }

@@ -158,7 +158,7 @@ def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_pol
     for want in expect_policy:
         assert want in names, "%s did not run; ran: %s" % (want, sorted(n for n in names if ":" in n or "wino" in n))
     assert ctx.profile_read("wino_input:convlstm_step")["launches"] == T - 1
-    assert ctx.profile_read("conv_fused")["launches"] == 3          # conv_2 (F(2x2)), conv_3 and conv_5 (F(4x4)) fused kernels
+    assert ctx.profile_read("conv_fused")["launches"] == 3          # conv_2, conv_3 and conv_5: the fused F(4x4) kernel (wino4s_fused.hip)
 
     # ---- tracking grid: per-channel error overall and as a function of t (rounding growth of the recurrence)
     got = res["netout"].cpu().numpy()

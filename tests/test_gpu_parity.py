@@ -1054,6 +1054,7 @@ def test_conv2_fused_winograd_vs_oracle(ctx, monkeypatch, B, H, W):
     """32 -> 64 channels with the 2x2 pooling epilogue through the fused kernel (forced at any size): whole and
     partial 8x8-tile workgroups, image borders, several frames; F(2x2,3x3) rounds like the direct form."""
     monkeypatch.setenv("DT_WINO_FUSED", "2")
+    monkeypatch.setenv("DT_W4S", "1")          # the default (2) hands conv_2's shape to the F(4x4) kernel when there are enough blocks
     rs = np.random.RandomState(B * 100 + H + W)
     x = rs.randn(B, H, W, 32).astype(np.float32)
     w = (rs.randn(3, 3, 32, 64) * np.sqrt(2.0 / (9 * 32))).astype(np.float32)
@@ -1073,6 +1074,7 @@ def test_conv2_fused_winograd_vs_oracle(ctx, monkeypatch, B, H, W):
 def test_conv2_fused_winograd_one_hot(ctx, monkeypatch):
     """one-hot taps on integer data: exact, and any misplaced tile / channel / position is off by >= 1"""
     monkeypatch.setenv("DT_WINO_FUSED", "2")
+    monkeypatch.setenv("DT_W4S", "1")
     B, H, W = 2, 20, 12
     x = (np.arange(B * H * W * 32, dtype=np.float32).reshape(B, H, W, 32) % 251)
     w = np.zeros((3, 3, 32, 64), dtype=np.float32)
