@@ -435,7 +435,7 @@ def _run():
 
     if rank == 0 and args.layer_report:
         with open(args.layer_report, "w") as f:
-            f.write("# per-layer HIP-event times inside the timed region (%d steps); algorithmic FLOP / bytes\n" % args.steps)
+            f.write("# per-layer HIP-event times inside the timed region (%d steps); EXECUTED MFMA FLOP / algorithmic bytes\n" % args.steps)
             f.write("%-32s %8s %12s %10s %10s\n" % ("name", "launches", "ms/step", "TFLOP/s", "GB/s(alg)"))
             for name in sorted(ctx.profile_names()):
                 p = ctx.profile_read(name)

@@ -675,7 +675,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
                          4.0 * ((double)B * H * W * L.cin * 1.27 * ((L.cout + 127) / 128) + (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0)), tag);
             prof_direct_form(ctx, flops, bytes, true);
             int rc;
-            if (L.fused4s && ctx->pol.w4s != 0 && (long long)B * a.in_bs < (1ll << 31)) {
+            if (L.fused4s && ctx->pol.w4s != 0) {
                 float *zeros = ws_get(ctx, "zeros256", 256, /*zero_on_grow=*/true);
                 if (!zeros) return DT_ERR_DEVICE;
                 f.u = L.fused4s;

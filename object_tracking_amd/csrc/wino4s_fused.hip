@@ -408,7 +408,6 @@ int launch_wino4s_fused(hipStream_t st, const Wino4FusedArgs &a_in, const float 
     const bool pool = a.out2 != nullptr;
     if (pool && ((a.H | a.W) & 1)) return 2;
     if (pool == (a.out != nullptr)) return 2;       // exactly one of the two outputs
-    if ((long long)a.B * a.in_bs >= (1ll << 31)) return 2;   // 32-bit patch offsets
     a.nby = (a.H + 15) / 16;
     a.nbx = (a.W + 15) / 16;
     const long long blocks = (long long)a.B * a.nby * a.nbx;

@@ -91,7 +91,6 @@ class H5File(object):
             raise H5Error("superblock version %d is not supported" % ver)
         if self.O not in (4, 8) or self.L not in (4, 8):
             raise H5Error("unsupported offset/length sizes %d/%d" % (self.O, self.L))
-        self.base += 0 if self.base else 0
         self.root = root_hdr
         self._gcol = {}
 

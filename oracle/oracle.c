@@ -8,17 +8,26 @@
  * Each function cites the reference file:line it follows (paths relative to
  * the upstream ktzsh/object-tracking tree).
  *
- * Parity status
- *   - decode_netout / NMS / bbox_iou: PINNED.  Checked against golden vectors
- *     produced by executing the reference's own numpy code
- *     (utility/utils.py:113-188,208-270) -- see tools/make_goldens.py and
- *     tests/golden/decode_*.npz.
- *   - conv / BN / LeakyReLU / maxpool / space_to_depth / ConvLSTM2D / LSTM /
- *     Dense: PARITY UNPINNED versus Keras/TensorFlow (un-vendored, unpinned
- *     third-party dependency that cannot run in this image; the reference holds
- *     no tests or fixtures for them).  They restate the public Keras 2.x / TF1
- *     layer semantics named at the reference call sites and are cross-checked
- *     against torch-CPU (an independent implementation) in tests/.
+ * Parity status (DESIGN.md section 7)
+ *   - PINNED by golden vectors produced by EXECUTING the reference's own numpy
+ *     code (tools/make_goldens.py -> tests/golden/): decode_netout / NMS /
+ *     bbox_iou (utility/utils.py:113-188,208-270), WeightReader (:138-148),
+ *     normalize (:150-153), heat maps (:53-79), target encoding and sequence
+ *     windows (utility/preprocessing.py:12-89,171-188,195-371).
+ *   - GRAPH TOPOLOGY PINNED by executing the reference's own load_model bodies
+ *     (KerasYOLO.py:239-407 incl. init_weights on a darknet file,
+ *     MultiObjDetTracker.py:160-189, TinyTracker.py:25-41) against a float64
+ *     stand-in for the Keras names they use (tools/make_graph_goldens.py +
+ *     tools/kshim.py -> tests/golden/graph_*.npz): layer order, the skip tap,
+ *     space_to_depth channel order, both concat orders, darknet read order and
+ *     OIHW->HWIO.  This file agrees with those fixtures to 8e-5.
+ *   - STILL UNPINNED: the per-layer ARITHMETIC of Keras/TensorFlow itself
+ *     (inference BatchNorm with eps 1e-3, LeakyReLU, 'same' padding,
+ *     hard_sigmoid, gate order i,f,c,o, NHWC space_to_depth) and cv2.resize:
+ *     un-vendored, unversioned dependencies that cannot run in this image; the
+ *     reference holds no tests or fixtures for them.  Both this file and kshim
+ *     restate the public Keras 2.x / TF1 / OpenCV definitions, independently,
+ *     and are cross-checked against torch-CPU in tests/.
  *
  * All tensors are float32, NHWC, dense.
  */

@@ -103,3 +103,66 @@ print("H5PY_OK")
     env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
     r = subprocess.run([H5PY_PYTHON, "-c", code, path, str(tmp_path / "want.npz")], capture_output=True, text=True, env=env)
     assert "H5PY_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_h5py_branch_of_the_reader_with_a_stand_in_module(golden_dir, monkeypatch):
+    """read_keras_weights prefers h5py when it is importable.  h5py is not in this image, so the branch is driven with a
+    minimal stand-in module (File / Group / Dataset with `in`, iteration, item access and visititems -- the calls
+    the branch makes) backed by this repository's own reader: both branches must give the same layer dict."""
+    import sys
+    import types
+    from utility import keras_h5
+
+    class Dataset(object):
+        def __init__(self, arr):
+            self.arr = arr
+
+        def __array__(self, dtype=None, copy=None):
+            return np.asarray(self.arr, dtype=dtype)
+
+    class Group(object):
+        def __init__(self, tree):
+            self.tree = tree
+
+        def __contains__(self, k):
+            return k in self.tree
+
+        def __iter__(self):
+            return iter(self.tree)
+
+        def __getitem__(self, k):
+            v = self.tree[k]
+            return Group(v) if isinstance(v, dict) else Dataset(v)
+
+        def visititems(self, fn, prefix=""):
+            for k, v in self.tree.items():
+                name = prefix + k
+                if isinstance(v, dict):
+                    fn(name, Group(v))
+                    Group(v).visititems(fn, name + "/")
+                else:
+                    fn(name, Dataset(v))
+
+    class File(Group):
+        def __init__(self, path, mode="r"):
+            assert mode == "r"
+            Group.__init__(self, keras_h5.H5File(path).tree())
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    path = os.path.join(golden_dir, "h5", "keras_tracker_ckpt.hdf5")
+    monkeypatch.setitem(sys.modules, "h5py", None)               # import h5py -> ImportError: the pure-Python branch
+    want = keras_h5.read_keras_weights(path)
+    fake = types.ModuleType("h5py")
+    fake.File, fake.Dataset, fake.Group = File, Dataset, Group
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    got = keras_h5.read_keras_weights(path)
+    assert sorted(got) == sorted(want) and len(got) >= 2
+    for lname in want:
+        assert sorted(got[lname]) == sorted(want[lname])
+        for k in want[lname]:
+            assert np.array_equal(got[lname][k], want[lname][k])
