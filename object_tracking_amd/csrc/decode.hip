@@ -17,7 +17,10 @@
 #include "dt_internal.h"
 
 #define DEC_THREADS 1024           // 16 waves: the frame is read with few bytes in flight per thread, so more threads = shorter passes
-#define DEC_MAX_CELLS 1920        // 19*19*5 = 1805 fits; (5+16)*mc*4 B of LDS must stay under 160 KiB
+#define DEC_MAX_CELLS 1920        // 19*19*5 = 1805 fits; (5+16)*mc*4 B of LDS must stay under 160 KiB.  Larger grids (up to
+#define DEC_BIG_MAX_CELLS 8192    // 8192 cells: the 13-bit cell field of the kept-score keys) run the BIG instance of the kernel, whose
+                                  // per-candidate arrays and overflow sort lists live in a global scratch instead of LDS
+#define DEC_CELL_BITS 13
 #define DEC_CHUNK_BYTES (96 * 1024)
 #define DEC_NZ_CAP 4096           // kept (cell, class) scores held in LDS for the NMS (8 B each + 16 B of sort lists)
 
@@ -129,8 +132,14 @@ struct DecodeArgs {
     int mc;             // ncell rounded up to 64: stride of the LDS candidate / sort arrays
     int ncp;            // NC rounded up to 4: per-class candidate counters in LDS
     int nzcap;          // capacity of the LDS list of non-zero (cell, class) scores; more than that: NMS gathers from global memory
+    float *scratch;     // BIG instance: per frame [7][mc] candidate arrays | [2 mc] keys (u64) | [nms_waves][4][mc] overflow lists
+    long long scratch_stride;   // floats per frame
 };
 
+// BIG = false: every per-candidate array in LDS (grids up to DEC_MAX_CELLS cells; the production sizes).  BIG = true: the
+// same algorithm with the [mc]-sized arrays in a global scratch region of the frame (read and written by this workgroup
+// only, ordered by its barriers) -- slower, but any grid up to DEC_BIG_MAX_CELLS cells decodes (utils.py:208-257 has no size limit).
+template <bool BIG>
 __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -146,23 +155,24 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
     // LDS carve: candidate arrays first (persistent), then a region that is the staging chunk in phase 2 and the
     // per-class sort lists in phase 3.
     const int MC = p.mc;
-    int *s_cell = reinterpret_cast<int *>(smem);              // [MC] cell of candidate k
-    float *s_bx = smem + MC;                                  // [4][MC] box of candidate k
-    int *s_kof = reinterpret_cast<int *>(smem + 5 * MC);      // [MC] per cell: 'any class kept' flag, then its candidate index
-    float *s_conf = smem + 6 * MC;                            // [MC] objectness of candidate k
-    float *s_red = smem + 7 * MC;                             // [32]: per-wave max, per-wave min
+    float *const cand = BIG ? p.scratch + (long long)frame * p.scratch_stride : smem;   // [7][MC] candidate arrays
+    int *s_cell = reinterpret_cast<int *>(cand);              // [MC] cell of candidate k
+    float *s_bx = cand + MC;                                  // [4][MC] box of candidate k
+    int *s_kof = reinterpret_cast<int *>(cand + 5 * MC);      // [MC] per cell: 'any class kept' flag, then its candidate index
+    float *s_conf = cand + 6 * MC;                            // [MC] objectness of candidate k
+    float *s_red = BIG ? smem : smem + 7 * MC;                // [32]: per-wave max, per-wave min
     int *s_tot = reinterpret_cast<int *>(s_red + 32);         // [16]
     int *s_nzn = reinterpret_cast<int *>(s_red + 48);         // [0]: number of non-zero (cell, class) scores
     int *s_ccnt = reinterpret_cast<int *>(s_red + 64);        // [ncp] candidates with a non-zero score per class
     int *s_coff = s_ccnt + p.ncp;                             // [ncp] start of the class's segment in the sort lists
     int *s_cfill = s_coff + p.ncp;                            // [ncp]
     float *s_sum = s_red + 64 + 3 * p.ncp;                    // [DEC_THREADS] softmax denominators of the chunk's cells
-    unsigned *s_nzk = reinterpret_cast<unsigned *>(s_sum + DEC_THREADS);   // [nzcap] cell | class << 11
+    unsigned *s_nzk = reinterpret_cast<unsigned *>(s_sum + DEC_THREADS);   // [nzcap] cell | class << DEC_CELL_BITS
     float *s_nzs = reinterpret_cast<float *>(s_nzk + p.nzcap);             // [nzcap] score
     float *s_dyn = s_nzs + p.nzcap;                           // chunk / sort lists
     // [MC] per candidate: max over its classes of (score bits << 32 | ~class) after the NMS; takes the place of the
     // (cell, class, score) list once that has been bucketed (8 nzcap >= 8 MC bytes: launch_decode)
-    unsigned long long *s_key = reinterpret_cast<unsigned long long *>(s_nzk);
+    unsigned long long *s_key = BIG ? reinterpret_cast<unsigned long long *>(cand + 7 * MC) : reinterpret_cast<unsigned long long *>(s_nzk);
 
     DEC_STAMP(0);
     // ---- phase 1: global max / min of the class logits (utils.py:263-264) ----
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
                 s_kof[c0 + lc] = 1;
                 atomicAdd(&s_ccnt[c], 1);
                 const int at = atomicAdd(&s_nzn[0], 1);
-                if (at < p.nzcap) { s_nzk[at] = (unsigned)(c0 + lc) | ((unsigned)c << 11); s_nzs[at] = keep; }
+                if (at < p.nzcap) { s_nzk[at] = (unsigned)(c0 + lc) | ((unsigned)c << DEC_CELL_BITS); s_nzs[at] = keep; }
             }
         }
         __syncthreads();
@@ -376,10 +386,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
         __syncthreads();
         for (int i = tid; i < nzn; i += DEC_THREADS) {
             const unsigned key = s_nzk[i];
-            const int c = (int)(key >> 11);
+            const int c = (int)(key >> DEC_CELL_BITS);
             const int at = s_coff[c] + atomicAdd(&s_cfill[c], 1);
             u_sc0[at] = s_nzs[i];
-            u_id0[at] = s_kof[key & 2047u];
+            u_id0[at] = s_kof[key & ((1u << DEC_CELL_BITS) - 1u)];
         }
         __syncthreads();
         for (int k = tid; k < ncand; k += DEC_THREADS) s_key[k] = 0ull;
@@ -464,10 +474,11 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
     } else {
         // more kept scores than the LDS list holds: gather each class's scores from post[] (global memory)
         // per wavefront: sorted (score,id) list + unsorted staging list, MC entries each
-        volatile float *l_sc = s_dyn + wave * (4 * MC);
-        volatile int *l_id = reinterpret_cast<volatile int *>(s_dyn + wave * (4 * MC) + MC);
-        volatile float *u_sc = s_dyn + wave * (4 * MC) + 2 * MC;
-        volatile int *u_id = reinterpret_cast<volatile int *>(s_dyn + wave * (4 * MC) + 3 * MC);
+        float *const ovf = BIG ? cand + 9 * MC : s_dyn;     // BIG: the lists follow the candidate arrays and keys in the scratch
+        volatile float *l_sc = ovf + wave * (4 * MC);
+        volatile int *l_id = reinterpret_cast<volatile int *>(ovf + wave * (4 * MC) + MC);
+        volatile float *u_sc = ovf + wave * (4 * MC) + 2 * MC;
+        volatile int *u_id = reinterpret_cast<volatile int *>(ovf + wave * (4 * MC) + 3 * MC);
         for (int c = wave; c < p.NC && wave < p.nms_waves; c += p.nms_waves) {
             if (s_ccnt[c] < 2) continue;   // fewer than two boxes carry this class: nothing to suppress (wave-uniform)
             // gather candidates with a non-zero score for class c
@@ -576,23 +587,35 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_nms_kernel(DecodeArgs p)
 #endif
 }
 
+// floats of global scratch per frame the BIG instance needs (0: the grid fits the LDS-resident instance)
+size_t decode_scratch_floats(int GH, int GW, int NB)
+{
+    const int ncell = GH * GW * NB;
+    if (ncell <= DEC_MAX_CELLS) return 0;
+    const size_t mc = (size_t)((ncell + 63) / 64) * 64;
+    return (9 + 4 * (DEC_THREADS / 64)) * mc;      // [7][mc] candidates | [mc] u64 keys | [16 waves][4][mc] overflow lists
+}
+
 int launch_decode(hipStream_t st, const float *netout, long long frame_stride, int batch, int GH, int GW, int NB,
                   int NC, float obj_thr, float nms_thr, const float *anchors_dev, int cap, float *boxes,
-                  int *counts, float *classes, float *post, const float *frame_thr)
+                  int *counts, float *classes, float *post, const float *frame_thr, float *scratch)
 {
     const int S = 5 + NC;
     const int ncell = GH * GW * NB;
-    if (ncell > DEC_MAX_CELLS || batch <= 0) return 2;
+    if (ncell > DEC_BIG_MAX_CELLS || batch <= 0) return 2;
+    const bool big = ncell > DEC_MAX_CELLS;
+    if (big && !scratch) return 2;
     const int mc = ((ncell + 63) / 64) * 64;
     const int ncp = (NC + 3) / 4 * 4;
-    // LDS budget: candidate arrays [7][mc], counters, softmax denominators, the list of kept (cell, class, score)
-    // triples, and one region that is the staging chunk in phase 2 and the sort lists in phase 3
-    const size_t fixed = (size_t)(7 * mc + 64 + 3 * ncp + DEC_THREADS) * sizeof(float);
+    // LDS budget: candidate arrays [7][mc] (LDS-resident instance only), counters, softmax denominators, the list of kept
+    // (cell, class, score) triples, and one region that is the staging chunk in phase 2 and the sort lists in phase 3
+    const size_t fixed = (size_t)((big ? 0 : 7 * mc) + 64 + 3 * ncp + DEC_THREADS) * sizeof(float);
     int nzcap = DEC_NZ_CAP;
     while (nzcap > 256 && fixed + (size_t)nzcap * 8 + (size_t)nzcap * 16 > 160 * 1024) nzcap /= 2;
     size_t dyn = 160 * 1024 - fixed - (size_t)nzcap * 8;
     if (dyn > DEC_CHUNK_BYTES) dyn = DEC_CHUNK_BYTES;
-    if (dyn < (size_t)nzcap * 16 || nzcap < mc) return 2;
+    // LDS-resident instance: the per-candidate keys take the place of the kept-score list (8 nzcap >= 8 mc bytes)
+    if (dyn < (size_t)nzcap * 16 || (!big && nzcap < mc)) return 2;
     int chunk = (int)((dyn - 16) / (S * sizeof(float)));   // up to three floats of alignment padding in front of the chunk
     chunk = (chunk / 64) * 64;
     if (chunk > DEC_THREADS) chunk = DEC_THREADS;
@@ -606,20 +629,26 @@ int launch_decode(hipStream_t st, const float *netout, long long frame_stride, i
     a.mc = mc;
     a.ncp = ncp;
     a.nzcap = nzcap;
-    // overflow path of the NMS (more kept scores than nzcap): per-wave lists of 4 x mc floats in the same region
-    int nms_waves = (int)(dyn / ((size_t)4 * mc * sizeof(float)));
+    a.scratch = scratch;
+    a.scratch_stride = (long long)decode_scratch_floats(GH, GW, NB);
+    // overflow path of the NMS (more kept scores than nzcap): per-wave lists of 4 x mc floats -- in the dyn region of the
+    // LDS-resident instance (as many waves as fit), in the scratch of the BIG one (all 16)
+    int nms_waves = big ? DEC_THREADS / 64 : (int)(dyn / ((size_t)4 * mc * sizeof(float)));
     if (nms_waves < 1) return 2;
     a.nms_waves = nms_waves > DEC_THREADS / 64 ? DEC_THREADS / 64 : nms_waves;
     const size_t lds = fixed + (size_t)nzcap * 8 + dyn;
     static PerDeviceOnce attr;
     if (attr.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(decode_nms_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(decode_nms_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(decode_nms_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return 1;
         attr.done();
     }
     if (lds > 160 * 1024) return 2;
-    hipLaunchKernelGGL(decode_nms_kernel, dim3((unsigned)batch), dim3(DEC_THREADS), lds, st, a);
+    if (big) hipLaunchKernelGGL(decode_nms_kernel<true>, dim3((unsigned)batch), dim3(DEC_THREADS), lds, st, a);
+    else hipLaunchKernelGGL(decode_nms_kernel<false>, dim3((unsigned)batch), dim3(DEC_THREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

@@ -166,7 +166,9 @@ int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, in
 
 int launch_decode(hipStream_t st, const float *netout, long long frame_stride, int batch, int GH, int GW, int NB,
                   int NC, float obj_thr, float nms_thr, const float *anchors_dev, int cap, float *boxes,
-                  int *counts, float *classes, float *post, const float *frame_thr /*[batch][2] (obj, nms) or null*/);
+                  int *counts, float *classes, float *post, const float *frame_thr /*[batch][2] (obj, nms) or null*/,
+                  float *scratch /*batch x decode_scratch_floats() floats for grids above 1920 cells, else null*/);
+size_t decode_scratch_floats(int GH, int GW, int NB);
 
 int launch_bbox_iou(hipStream_t st, const float *pairs, int n, float *iou);
 

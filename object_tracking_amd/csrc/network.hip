@@ -1067,11 +1067,16 @@ static int decode_common(dt_ctx *ctx, const float *d_netout, int batch, int GH, 
         post = ws_get(ctx, "dec_post", (size_t)batch * fsz * sizeof(float));
         if (!post) return DT_ERR_DEVICE;
     }
+    float *scratch = nullptr;      // grids above 1920 cells: the kernel's per-candidate arrays live in global memory
+    if (const size_t sf = decode_scratch_floats(GH, GW, NB)) {
+        scratch = ws_get(ctx, "dec_scratch", (size_t)batch * sf * sizeof(float));
+        if (!scratch) return DT_ERR_DEVICE;
+    }
     ProfScope ps(ctx, "decode_nms", 0.0, 4.0 * 3.0 * batch * (double)fsz);
     const int rc = launch_decode(ctx->stream, d_netout, (long long)fsz, batch, GH, GW, NB, NC, obj_threshold,
-                                 nms_threshold, anch, cap, d_boxes, d_counts, d_classes, post, d_frame_thr);
+                                 nms_threshold, anch, cap, d_boxes, d_counts, d_classes, post, d_frame_thr, scratch);
     if (rc == 2)
-        return dt_fail(ctx, DT_ERR_ARG, "decode: grid %dx%dx%d / %d classes exceeds the LDS-resident limits", GH, GW,
+        return dt_fail(ctx, DT_ERR_ARG, "decode: grid %dx%dx%d (limit 8192 cells) / %d classes exceeds the kernel's limits", GH, GW,
                        NB, NC);
     if (rc) return dt_fail(ctx, DT_ERR_DEVICE, "decode launch failed");
     return DT_OK;

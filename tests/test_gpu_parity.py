@@ -177,6 +177,67 @@ def test_decode_dense_low_threshold(ctx, C, thr):
     print("decode dense: C=%d, %d scores survive NMS in %d frames" % (C, kept, B))
 
 
+@pytest.mark.parametrize("G,C,thr,dense", [(26, 12, 0.5, False), (26, 80, 0.3, False), (32, 3, 1e-3, True), (40, 12, 0.02, True),
+                                           (20, 12, 0.5, False)])
+def test_decode_grids_above_1920_cells(ctx, G, C, thr, dense):
+    """utils.py:208-257 has no size limit.  Grids above 19x19x5 cells (832x832 -> 26x26, 1024 -> 32x32, 1280 -> 40x40:
+    3380 / 5120 / 8000 cells) run the kernel instance whose per-candidate arrays live in a global scratch; 20x20
+    (2000 cells) is the first size past the LDS-resident limit.  Planted objects over a quiet background (a few boxes per
+    frame, overlapping pairs for the NMS) and dense low-threshold frames (thousands of kept scores: the overflow path
+    of the NMS): same boxes, order, labels, scores and post-NMS grid as the oracle."""
+    rs = np.random.RandomState(G * 7 + C)
+    B = 3
+    if dense:
+        grids = rs.randn(B, G, G, 5, 5 + C).astype(np.float32)
+        grids[..., 4] -= 2.0
+        grids[..., 2:4] *= 0.5
+    else:
+        grids = (rs.randn(B, G, G, 5, 5 + C) * 0.3).astype(np.float32)
+        grids[..., 4] -= 6.0                                       # quiet background
+        for b in range(B):
+            for k in range(40):                                    # planted objects, in overlapping pairs
+                r, c, a, cl = rs.randint(G), rs.randint(G - 1), rs.randint(5), rs.randint(C)
+                for dc in (0, 1):
+                    grids[b, r, c + dc, a, 4] = 4.0 + rs.rand()
+                    grids[b, r, c + dc, a, 5 + cl] = 9.0 + rs.rand()
+                    grids[b, r, c + dc, a, 2:4] = 1.2
+    r = ctx.decode(dev(grids, ctx), thr, 0.45, ANCHORS, C, want_post=True, want_classes=True)
+    counts = r["counts"].cpu().numpy()
+    boxes = r["boxes"].cpu().numpy()
+    post = r["post"].cpu().numpy()
+    nbox = 0
+    for i in range(B):
+        rows, opost = orc.decode_netout(grids[i], thr, 0.45, ANCHORS, C)
+        assert counts[i] == len(rows), (counts[i], len(rows))
+        got = boxes[i, :counts[i]]
+        assert np.array_equal(got[:, 5], rows[:, 5]) and np.array_equal(got[:, 7], rows[:, 7])
+        np.testing.assert_allclose(got[:, :7], rows[:, :7], rtol=2e-6, atol=1e-6)
+        assert np.array_equal(post[i][..., 5:] > 0, opost[..., 5:] > 0), "suppressed set differs"
+        np.testing.assert_allclose(post[i], opost, rtol=2e-6, atol=1e-7)
+        nbox += len(rows)
+    assert nbox >= (300 if dense else 60), nbox
+    # the same call twice: bitwise identical (the scratch is reused)
+    r2 = ctx.decode(dev(grids, ctx), thr, 0.45, ANCHORS, C, want_post=True)
+    assert torch.equal(r2["boxes"], r["boxes"]) and torch.equal(r2["counts"], r["counts"]) and torch.equal(r2["post"], r["post"])
+
+
+def test_detector_832_decodes_end_to_end(ctx):
+    """an 832x832 frame (26x26 grid, 3380 cells: above the LDS-resident decode limit) through KerasYOLO.detect"""
+    det, layers, _ = _detector(ctx, 832, 832, 12)
+    frames = synth.synth_clip(1, 832, 832, 3, seed=33)
+    c = det.model.ctx
+    net = c.detect_forward(dev(frames, c))
+    assert net.shape == (1, 26, 26, 5, 17)
+    netc = net.cpu().numpy()
+    thr = float(np.sort((1 / (1 + np.exp(-netc[0, ..., 4]))).ravel())[-40])       # ~40 cells above the objectness threshold
+    r = c.decode(net, thr * 0.5, 0.45, ANCHORS, 12)
+    rows, _ = orc.decode_netout(netc[0], thr * 0.5, 0.45, ANCHORS, 12)
+    assert int(r["counts"][0]) == len(rows)
+    got = r["boxes"][0, :len(rows)].cpu().numpy()
+    assert np.array_equal(got[:, 7], rows[:, 7]) and np.array_equal(got[:, 5], rows[:, 5])
+    np.testing.assert_allclose(got[:, :7], rows[:, :7], rtol=2e-6, atol=1e-6)
+
+
 def test_decode_is_deterministic_across_runs(ctx):
     """The kernel's LDS lists are filled through atomics (order differs from run to run); boxes, counts, order and the
     post-NMS grid must not: 64 dense frames, three thresholds, decoded five times each -- bitwise equal."""
@@ -714,7 +775,7 @@ def test_error_paths_fail_loudly(ctx):
     x = torch.zeros((1, 7, 8, 32), dtype=torch.float32, device=ctx.device)          # odd H with pooling
     with pytest.raises(mi355_dt.NativeError):
         ctx.conv2d(x, np.zeros((3, 3, 32, 32), dtype=np.float32), pool=1)
-    big = torch.zeros((1, 26, 26, 5, 17), dtype=torch.float32, device=ctx.device)   # 3380 cells > LDS-resident limit
+    big = torch.zeros((1, 48, 48, 5, 17), dtype=torch.float32, device=ctx.device)   # 11520 cells > the 13-bit cell field (8192)
     with pytest.raises(mi355_dt.NativeError):
         ctx.decode(big, 0.5, 0.45, ANCHORS, 12)
     c2 = mi355_dt.Context()
