@@ -120,6 +120,10 @@ __device__ __forceinline__ void s4_transform_half(const float *pl, float *o)
     }
 }
 
+#ifndef S4_ABLATE
+#define S4_ABLATE 0         // timing-only ablation builds (results WRONG): 1 no U DMA, 2 no patch DMA, 4 no input transform, 8 no operand reads,
+                            // 16 patch addresses as for a channel-blocked input, 32 patch pieces from a contiguous source
+#endif
 #ifndef S4_PRIO
 #define S4_PRIO 1           // raise the wave's issue priority while it does side work (DMA issue, input transform) beside its
 #endif                      // partner's MFMA block
@@ -168,26 +172,42 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
         const int px = 4 * g + (r9 >> 1), hf = r9 & 1;
         pgeo[i] = (py << 8) | (px << 2) | (hf << 1) | ((py < 18 && r9 < 8 && px < 18) ? 1 : 0);
     }
-    struct Item { int nq, j0; const float *u; };
-    auto item_of = [&](int it) {
+    // an item = (64-channel slice nq, block pair j0, j0 + 1).  The geometry of its two block images is decoded ONCE here (the
+    // integer divisions cost hundreds of cycles): origin pixel of the patch, its address for channel 0, existence.
+    struct Blk { const float *base; int y0, x0; bool ok; };       // named members only: arrays indexed at run time land in scratch
+    struct Item { int nq, j0; const float *u; Blk b0, b1; };
+    auto blk_of = [&](int j, bool exists) {
+        Blk B;
+        const int bxy = p.nbx * p.nby;
+        const int b = j / bxy, r = j - b * bxy;
+        const int by = r / p.nbx, bx = r - by * p.nbx;
+        B.y0 = by * 16 - 1; B.x0 = bx * 16 - 1;
+        B.base = p.in + (long long)b * p.in_bs + ((long long)B.y0 * p.W + B.x0) * p.in_ld;   // wave-uniform
+        B.ok = exists && j < nblk;
+        return B;
+    };
+    auto item_of = [&](int it, bool exists) {
         Item I;
         I.nq = it / npair;
         I.j0 = 2 * (it - I.nq * npair);
         I.u = p.u + (long long)I.nq * nst * S4_UBUF;
+        I.b0 = blk_of(I.j0, exists);
+        I.b1 = blk_of(I.j0 + 1, exists);
         return I;
     };
     // pieces w4 + 4 i (i = 0..2) of block image b01 of patch stage c (channels 8c .. 8c+7) of item I -> patch buffer buf
-    auto patch_half = [&](const Item &I, int b01, int c, int buf, bool exists) {
-        const int j = I.j0 + b01;
-        const int bx = j % p.nbx, by = (j / p.nbx) % p.nby, b = j / (p.nbx * p.nby);
-        const int y0 = by * 16 - 1, x0 = bx * 16 - 1;
-        const float *base = p.in + (long long)b * p.in_bs + ((long long)y0 * p.W + x0) * p.in_ld + 8 * c;   // wave-uniform
-        const bool blk_ok = exists && j < nblk;
+    auto patch_half = [&](const Blk &B, int b01, int c, int buf, bool exists) {
+        const int y0 = B.y0, x0 = B.x0;
+        const float *base = B.base + 8 * c;
+        const bool blk_ok = exists && B.ok;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int py = pgeo[i] >> 8, px = (pgeo[i] >> 2) & 63, hf = (pgeo[i] >> 1) & 1;
             const bool ok = blk_ok && (pgeo[i] & 1) && y0 + py >= 0 && y0 + py < p.H && x0 + px >= 0 && x0 + px < p.W;
             const float *src = ok ? base + (py * p.W + px) * p.in_ld + hf * 4 : p.zeros;
+            if (S4_ABLATE & 16)     // timing probe: the access pattern of a channel-blocked [C/8][H][W][8] input (values wrong)
+                src = ok ? base + (long long)c * (p.H * p.W * 8 - 8) - (long long)(y0 * p.W + x0) * (p.in_ld - 8) + (py * p.W + px) * 8 + hf * 4 : p.zeros;
+            if (S4_ABLATE & 32) src = p.u + (w4 + 4 * i) * 256 + lane * 4;                          // timing probe: a contiguous, always-valid source
             __builtin_amdgcn_global_load_lds((s4_gptr_t *)src, (s4_lptr_t *)(Pb + buf * S4_PBUF + (b01 * 12 + w4 + 4 * i) * 256), 16, 0, 0);
         }
     };
@@ -222,6 +242,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
         f32x2 a0[NB], a1[NB];
         f32x4 bq[NB];
         auto request = [&](int g, int slot) {
+            if (S4_ABLATE & 8) { a0[slot] = f32x2{1.0f, 2.0f}; a1[slot] = f32x2{3.0f, 4.0f}; bq[slot] = f32x4{1.0f, 1.0f, 1.0f, 1.0f}; return; }
             a0[slot] = *reinterpret_cast<const f32x2 *>(va + (2 * g) * 256);
             a1[slot] = *reinterpret_cast<const f32x2 *>(va + (2 * g + 1) * 256);
             bq[slot] = *reinterpret_cast<const f32x4 *>(ua + g * 1024);
@@ -244,14 +265,13 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
     // ---- first item: prologue.  Patch stage 0 (set b fetches block image b), U stage 0, the block-0 half of patch stage 1
     // (its block-1 half is fetched by the data-movement set of stage 0); then V(0) by set 0. ----
     int item = blockIdx.x;
-    Item cur = item_of(item);
+    Item cur = item_of(item, true);
 #ifdef DT_S4_TIMING
     int tt_i = 0;
     S4_PUT(0, S4_NOW());
 #endif
-    patch_half(cur, vset, 0, 0, true);
-    if (vset == 0) u_pieces(cur.u, 0, 0, 5);
-    else { u_pieces(cur.u, 0, 5, 9); patch_half(cur, 0, 1, 1, npatch > 1); }
+    if (vset == 0) { patch_half(cur.b0, 0, 0, 0, true); u_pieces(cur.u, 0, 0, 5); }
+    else { patch_half(cur.b1, 1, 0, 0, true); u_pieces(cur.u, 0, 5, 9); patch_half(cur.b0, 0, 1, 1, npatch > 1); }
     __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
     __syncthreads();
     if (vset == 0) transform(0, 0, 0);
@@ -261,7 +281,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
     for (;;) {
         const int nxt = item + (int)gridDim.x;
         const bool has_next = nxt < nitems;
-        const Item nx = item_of(has_next ? nxt : item);
+        const Item nx = item_of(has_next ? nxt : item, has_next);
 #ifdef DT_S4_TIMING
         unsigned long long tt_tr = 0, tt_mm = 0, tt_bw = 0, tt_dm = 0;
 #endif
@@ -280,16 +300,22 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
                 // stage: odd s -> block image 0 of patch stage (s+3)/2, even s -> block image 1 of patch stage (s+2)/2 (the
                 // stage whose first half went out one stage earlier).  Past this item's patches the numbering continues
                 // into the next item's (npatch is even, so the buffers line up). ----
-                if (!last || has_next) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9);
+                if ((!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9);
                 const int pc_all = (s + 2 + (s & 1)) >> 1;
                 const bool pnx = pc_all >= npatch;
-                patch_half(pnx ? nx : cur, (s & 1) ^ 1, pnx ? pc_all - npatch : pc_all, pc_all & 1, !pnx || has_next);
+                if (!(S4_ABLATE & 2)) {
+                    // block image (s & 1) ^ 1 of this item or the next: four wave-uniform candidates, selected on scalars
+                    Blk B;
+                    if (s & 1) { B.base = pnx ? nx.b0.base : cur.b0.base; B.y0 = pnx ? nx.b0.y0 : cur.b0.y0; B.x0 = pnx ? nx.b0.x0 : cur.b0.x0; B.ok = pnx ? nx.b0.ok : cur.b0.ok; }
+                    else { B.base = pnx ? nx.b1.base : cur.b1.base; B.y0 = pnx ? nx.b1.y0 : cur.b1.y0; B.x0 = pnx ? nx.b1.x0 : cur.b1.x0; B.ok = pnx ? nx.b1.ok : cur.b1.ok; }
+                    patch_half(B, (s & 1) ^ 1, pnx ? pc_all - npatch : pc_all, pc_all & 1, !pnx || has_next);
+                }
                 if (S4_PRIO) __builtin_amdgcn_s_setprio(0);
             }
             [[maybe_unused]] const unsigned long long c1 = S4_NOW();
             mfma_block(s & 1);
             [[maybe_unused]] const unsigned long long c2 = S4_NOW();
-            if (!dset && (!last || has_next)) {
+            if (!dset && (!last || has_next) && !(S4_ABLATE & 4)) {
                 // ---- the other set: after its MFMAs, the input transform of stage s + 1 (stage 0 of the next item after the
                 // last stage): patch buffer ((s+1)/2) & 1, channel half (s+1) & 1, V buffer (s+1) & 1 ----
                 const int s1 = s + 1;
