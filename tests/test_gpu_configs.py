@@ -244,7 +244,7 @@ def test_configs2_track_416_reference_default_thresholds():
 
 def test_configs2_benched_track_416_vs_oracle():
     """BASELINE configs[2] as bench.py runs it: this is the path the headline number is measured on."""
-    _track_config_vs_oracle(416, 9, 30, 32, 128, "r02_track416",
+    _track_config_vs_oracle(416, 9, 30, 32, 128, "r03_track416",
                             ["wino_input:convlstm_xproj", "wino_input:convlstm_step", "wino_input:conv_22",
                              "conv_fused:conv_3", "conv_fused:conv_5", "wino_input:conv_6", "conv_fused:conv_2",
                              "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4"],
@@ -253,7 +253,7 @@ def test_configs2_benched_track_416_vs_oracle():
 
 def test_configs4_track_608_128_boxes_vs_oracle():
     """BASELINE configs[4] single-GPU shard: 608x608 -> 19x19 grid, ~128 boxes/frame, 4 clips x 30 frames."""
-    _track_config_vs_oracle(608, 4, 30, 400, 640, "r02_track608",
+    _track_config_vs_oracle(608, 4, 30, 400, 640, "r03_track608",
                             ["wino_input:convlstm_xproj", "wino_input:convlstm_step", "wino_input:conv_22",
                              "conv_fused:conv_2", "conv_fused:conv_3"], min_boxes_per_frame=100)    # 400 candidates/frame -> >= 100 tracks after NMS
 
@@ -321,7 +321,7 @@ def test_configs3_tinytracker_T64_vs_oracle():
         ref[:, t] = orc.dense_sigmoid(h, tw["dense_kernel"], tw["dense_bias"])
     e_t = [float(np.abs(got[:, t] - ref[:, t]).max()) for t in range(T)]
     assert max(e_t) < 1e-4
-    _report("parity_r02_tiny64.json", dict(config="TinyTracker 32 sequences x T=64 @416", frames_with_box=int(nbox),
+    _report("parity_r03_tiny64.json", dict(config="TinyTracker 32 sequences x T=64 @416", frames_with_box=int(nbox),
                                            out_err_t0=e_t[0], out_err_t31=e_t[31], out_err_t63=e_t[63], out_err_max=max(e_t)))
 
 
@@ -347,5 +347,5 @@ def test_configs1_detector_batch8_vs_oracle_and_f64_graph(golden_dir):
     e64_oracle = chan_err(ref_net[:1].reshape(1, 13, 13, -1), d["netout"].reshape(1, 13, 13, -1))
     assert e_net < 3e-4 and e_feat < 3e-4
     assert e64 < 3e-4, "HIP path vs float64 graph: %g (oracle vs float64: %g)" % (e64, e64_oracle)
-    _report("parity_r02_detect8.json", dict(netout_chan_err_vs_oracle=e_net, feat_chan_err_vs_oracle=e_feat,
+    _report("parity_r03_detect8.json", dict(netout_chan_err_vs_oracle=e_net, feat_chan_err_vs_oracle=e_feat,
                                             netout_chan_err_vs_f64_graph=e64, oracle_vs_f64_graph=e64_oracle))
