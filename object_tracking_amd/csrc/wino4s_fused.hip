@@ -16,15 +16,16 @@
 //   * the workgroup is PERSISTENT and the stage pipeline runs ACROSS items: during the last stages of an item the DMA
 //     already fetches the next item's first patch stages and U stage, and the last stage's transform slot produces the
 //     next item's V(0) -- only the first item of a workgroup pays a prologue;
-//   * data movement and the input transform are issued BETWEEN the MFMA quads of a stage (one DMA piece / one window
-//     column per quad), so they run in the shadow of the matrix pipe instead of in front of it.
+//   * two wave sets swap roles every stage: one issues the stage's data movement and then its MFMAs, the other its MFMAs
+//     and then the input transform of the next stage -- on every SIMD one wave feeds the matrix pipe while its partner does
+//     the side work (issuing the side work BETWEEN the MFMA quads of every wave was measured slower: DESIGN.md 4.2e).
 //
 // Workgroup = 8 waves = 2 blocks (4x4 tiles of 4x4 pixels each) x 4 column groups of 16 channels; v_mfma_f32_16x16x4_f32
 // (row = tile, column = channel, k = input channel).  K runs in stages of 4 input channels (one MFMA k-step), one
 // barrier per stage:
-//      stage s :  DMA U(s+1) -> Ubuf[(s+1)&1];   DMA patch(c+1) -> Pbuf (8 channels, every second stage);
-//                 4 of the 8 waves: V(s+1) = Bt d B for (block, xi-half) from the patch, -> Vbuf[(s+1)&1];
-//                 all waves: 36 MFMAs on V(s), U(s);   vmcnt(0); barrier.
+//      stage s :  set s&1:      DMA U(s+1) -> Ubuf[(s+1)&1], half a patch stage -> Pbuf;  36 MFMAs on V(s), U(s)
+//                 the other set: 36 MFMAs on V(s), U(s);  V(s+1) = Bt d B for (block, xi-half) from the patch -> Vbuf[(s+1)&1]
+//                 vmcnt(0); barrier.
 // LDS (157.7 KB of 160): U 2 x 36.9 KB | V 2 x 18.4 KB | patch 2 x 24.6 KB.
 // fp32 throughout; rounding identical in kind to wino4_fused / winograd.hip TS = 4 (products summed in another order).
 #include <type_traits>
@@ -124,6 +125,11 @@ __device__ __forceinline__ void s4_transform_half(const float *pl, float *o)
 #define S4_ABLATE 0         // timing-only ablation builds (results WRONG): 1 no U DMA, 2 no patch DMA, 4 no input transform, 8 no operand reads,
                             // 16 patch addresses as for a channel-blocked input, 32 patch pieces from a contiguous source
 #endif
+#ifndef S4_SRD
+#define S4_SRD 0            // 1: patch pieces through a per-frame buffer descriptor (buffer_load ... lds): an out-of-range offset reads
+#endif                      //    zeros, so padding needs no zero-source select and an interior block costs ONE add per piece; 0: global_load_lds
+                            //    with a zero-block source.  Both pass the parity tests; measured 1.5 % SLOWER with the descriptor
+                            //    (conv_2 / 3 / 5: 8.30 / 9.94 / 9.33 against 8.17 / 9.79 / 9.17 ms): the pieces' cost is not their address work
 #ifndef S4_PRIO
 #define S4_PRIO 1           // raise the wave's issue priority while it does side work (DMA issue, input transform) beside its
 #endif                      // partner's MFMA block
@@ -172,9 +178,21 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
         const int px = 4 * g + (r9 >> 1), hf = r9 & 1;
         pgeo[i] = (py << 8) | (px << 2) | (hf << 1) | ((py < 18 && r9 < 8 && px < 18) ? 1 : 0);
     }
+#if S4_SRD
+    // byte offset of the lane's 16 bytes from the block's patch origin (channel 0), or far out of range for the slots no
+    // pixel maps to: with the frame as a raw buffer (num_records = its byte size) such lanes read zeros
+    constexpr int S4_OOB = 0x40000000;
+    int pstat[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int py = pgeo[i] >> 8, px = (pgeo[i] >> 2) & 63, hf = (pgeo[i] >> 1) & 1;
+        pstat[i] = (pgeo[i] & 1) ? ((py * p.W + px) * p.in_ld + hf * 4) * 4 : S4_OOB;
+    }
+    const unsigned frame_bytes = (unsigned)(((long long)(p.H - 1) * p.W + p.W - 1) * p.in_ld + p.Cin) * 4u;   // last pixel's channels end here
+#endif
     // an item = (64-channel slice nq, block pair j0, j0 + 1).  The geometry of its two block images is decoded ONCE here (the
     // integer divisions cost hundreds of cycles): origin pixel of the patch, its address for channel 0, existence.
-    struct Blk { const float *base; int y0, x0; bool ok; };       // named members only: arrays indexed at run time land in scratch
+    struct Blk { const float *base; const float *frame; int boff; int y0, x0; bool ok, interior; };   // named members only: arrays indexed at run time land in scratch
     struct Item { int nq, j0; const float *u; Blk b0, b1; };
     auto blk_of = [&](int j, bool exists) {
         Blk B;
@@ -182,8 +200,11 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
         const int b = j / bxy, r = j - b * bxy;
         const int by = r / p.nbx, bx = r - by * p.nbx;
         B.y0 = by * 16 - 1; B.x0 = bx * 16 - 1;
-        B.base = p.in + (long long)b * p.in_bs + ((long long)B.y0 * p.W + B.x0) * p.in_ld;   // wave-uniform
+        B.frame = p.in + (long long)b * p.in_bs;
+        B.boff = (B.y0 * p.W + B.x0) * p.in_ld * 4;                   // bytes from the frame to the patch origin (negative on the top / left border)
+        B.base = B.frame + ((long long)B.y0 * p.W + B.x0) * p.in_ld;   // wave-uniform
         B.ok = exists && j < nblk;
+        B.interior = by > 0 && bx > 0 && B.y0 + 18 <= p.H && B.x0 + 18 <= p.W;
         return B;
     };
     auto item_of = [&](int it, bool exists) {
@@ -200,6 +221,24 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
         const int y0 = B.y0, x0 = B.x0;
         const float *base = B.base + 8 * c;
         const bool blk_ok = exists && B.ok;
+#if S4_SRD
+        if (!(S4_ABLATE & 48)) {
+            // raw buffer over the block's frame (word 3: 32-bit data format, no swizzle); the stage's channel offset rides in soffset
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B.frame), 0, blk_ok ? frame_bytes : 0u, 0x00020000);
+            const bool fast = B.interior;        // wave-uniform: every pixel of the 18x18 window is inside the image
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                int voff = pstat[i] + B.boff;
+                if (!fast) {
+                    const int py = pgeo[i] >> 8, px = (pgeo[i] >> 2) & 63;
+                    const bool in = y0 + py >= 0 && y0 + py < p.H && x0 + px >= 0 && x0 + px < p.W;
+                    voff = in ? voff : S4_OOB;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (s4_lptr_t *)(Pb + buf * S4_PBUF + (b01 * 12 + w4 + 4 * i) * 256), 16, voff, 32 * c, 0, 0);
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int py = pgeo[i] >> 8, px = (pgeo[i] >> 2) & 63, hf = (pgeo[i] >> 1) & 1;
@@ -306,8 +345,9 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
                 if (!(S4_ABLATE & 2)) {
                     // block image (s & 1) ^ 1 of this item or the next: four wave-uniform candidates, selected on scalars
                     Blk B;
-                    if (s & 1) { B.base = pnx ? nx.b0.base : cur.b0.base; B.y0 = pnx ? nx.b0.y0 : cur.b0.y0; B.x0 = pnx ? nx.b0.x0 : cur.b0.x0; B.ok = pnx ? nx.b0.ok : cur.b0.ok; }
-                    else { B.base = pnx ? nx.b1.base : cur.b1.base; B.y0 = pnx ? nx.b1.y0 : cur.b1.y0; B.x0 = pnx ? nx.b1.x0 : cur.b1.x0; B.ok = pnx ? nx.b1.ok : cur.b1.ok; }
+#define S4_SEL(m) B.m = (s & 1) ? (pnx ? nx.b0.m : cur.b0.m) : (pnx ? nx.b1.m : cur.b1.m)
+                    S4_SEL(base); S4_SEL(frame); S4_SEL(boff); S4_SEL(y0); S4_SEL(x0); S4_SEL(ok); S4_SEL(interior);
+#undef S4_SEL
                     patch_half(B, (s & 1) ^ 1, pnx ? pc_all - npatch : pc_all, pc_all & 1, !pnx || has_next);
                 }
                 if (S4_PRIO) __builtin_amdgcn_s_setprio(0);
