@@ -48,7 +48,7 @@ DT_API int dt_create(dt_ctx **out);
 DT_API void dt_destroy(dt_ctx *ctx);
 DT_API const char *dt_last_error(dt_ctx *ctx);
 DT_API int dt_set_stream(dt_ctx *ctx, void *hip_stream);
-/* ABI version of this header: major*100+minor (1.04: 1.03 + dt_pack_detections / dt_unpack_detections) */
+/* ABI version of this header: major*100+minor (1.05: 1.04 + dt_track_detect_xproj / dt_track_recurrent_xproj) */
 DT_API int dt_abi_version(void);
 
 /* ---- detector: KerasYOLO ---------------------------------------------- */
@@ -154,6 +154,17 @@ DT_API int dt_track_forward(dt_ctx *ctx, const void *d_frames, int frames_dtype,
 DT_API int dt_track_row_width(dt_ctx *ctx);
 DT_API int dt_track_detect(dt_ctx *ctx, const void *d_frames, int frames_dtype, int n_frames, float *d_z);
 DT_API int dt_track_recurrent(dt_ctx *ctx, const float *d_z, int n_clips, int T, float *d_trk, float *d_det);
+
+/* The same split ONE STEP LATER in the graph (the default of parallel.track_clips_frame_sharded): ConvLSTM2D's input
+ * projection W * x_t + b (MultiObjDetTracker.py:176) does not depend on the recurrence, so the rank that ran the detector on a
+ * frame runs it as well -- 55 % of the recurrent head's FLOPs move from the clip's owner (sequential in T) to the part that is
+ * spread over all GPUs -- and the rows that travel are the projection rows, dt_track_xproj_width = 4 * units floats per grid cell.
+ *   dt_track_detect_xproj:    d_frames [n_frames,H,W,3] -> d_xp [n_frames, G, G, 4U]  (+ d_det [n_frames,G,G,Cb], may be NULL)
+ *   dt_track_recurrent_xproj: d_xp [n_clips, T, G, G, 4U] -> d_trk [n_clips,T,G,G,Cb]
+ * dt_track_forward == dt_track_detect_xproj on all frames followed by dt_track_recurrent_xproj. */
+DT_API int dt_track_xproj_width(dt_ctx *ctx);
+DT_API int dt_track_detect_xproj(dt_ctx *ctx, const void *d_frames, int frames_dtype, int n_frames, float *d_xp, float *d_det);
+DT_API int dt_track_recurrent_xproj(dt_ctx *ctx, const float *d_xp, int n_clips, int T, float *d_trk);
 
 /* Track identity (BUILD-DEFINED, DESIGN.md "Track identity"; the reference has
  * none).  d_boxes [n_clips,T,cap,8], d_counts [n_clips,T]

@@ -157,7 +157,7 @@ static int upload(dt_ctx *ctx, float **dst, const std::vector<float> &h)
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int dt_abi_version(void) { return 104; }   // 1.04: + dt_pack_detections / dt_unpack_detections / dt_packed_row_ints
+extern "C" int dt_abi_version(void) { return 105; }   // 1.05: + dt_track_detect_xproj / dt_track_recurrent_xproj / dt_track_xproj_width
 
 extern "C" int dt_create(dt_ctx **out)
 {
@@ -1174,15 +1174,19 @@ extern "C" int dt_tracker_load(dt_ctx *ctx, int units, const float *h_kernel, co
     return DT_OK;
 }
 
-// xproj = conv3x3(z, Wx) + b for all frames; then the sequential recurrence
+// xproj = conv3x3(z, Wx) + b for all frames; then the sequential recurrence.
+//   z != null, xproj_ext == null : both halves, xproj in the library's workspace (dt_track_forward / dt_track_recurrent)
+//   z != null, xproj_ext != null, hseq == null : the input projection ONLY, into the caller's buffer (dt_track_detect_xproj:
+//       the projection does not depend on the recurrence, so a frame-sharded deployment runs it where the frame is)
+//   z == null, xproj_ext != null : the recurrence ONLY, on the caller's stitched projection rows (dt_track_recurrent_xproj)
 static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, int T, int gh, int gw, int U,
                              const float *wx, const float *bx, const float *wh, float *hseq /*[n_clips][T][GG][U]*/,
-                             const float *wx_wino = nullptr, const float *wh_wino = nullptr)
+                             const float *wx_wino = nullptr, const float *wh_wino = nullptr, float *xproj_ext = nullptr)
 {
     const int GG = gh * gw, F = n_clips * T, N4 = 4 * U;
-    float *xproj = ws_get(ctx, "trk_xproj", (size_t)F * GG * N4 * sizeof(float));
-    float *cst = ws_get(ctx, "trk_c", (size_t)n_clips * GG * U * sizeof(float));
-    if (!xproj || !cst) return DT_ERR_DEVICE;
+    float *xproj = xproj_ext ? xproj_ext : ws_get(ctx, "trk_xproj", (size_t)F * GG * N4 * sizeof(float));
+    float *cst = hseq ? ws_get(ctx, "trk_c", (size_t)n_clips * GG * U * sizeof(float)) : nullptr;
+    if (!xproj || (hseq && !cst)) return DT_ERR_DEVICE;
     // hseq, xproj and the cell state are library-owned, z only when it is the 'trk_z' workspace (dt_track_forward).  A
     // captured graph keeps the pointers it was captured with, so the input projection -- the one part that reads z --
     // is inside the replayed graph only for the library-owned z; for a caller's rows (dt_track_recurrent) it runs
@@ -1255,6 +1259,10 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
     }
     return DT_OK;
     };
+    if (xproj_ext) {       // caller-owned projection rows: nothing here may be baked into a replayed graph
+        if (z) { const int rc = input_projection(); if (rc || !hseq) return rc; }
+        return hseq ? recurrence() : DT_OK;
+    }
     if (z_owned)
         return graphed(ctx, "clstm:" + shape, [&]() -> int {
             const int rc = input_projection();
@@ -1340,6 +1348,55 @@ extern "C" int dt_track_recurrent(dt_ctx *ctx, const float *d_z, int n_clips, in
             return dt_fail(ctx, DT_ERR_DEVICE, "detection copy launch failed");
     }
     return DT_OK;
+}
+
+// The same split one step later in the graph: the ConvLSTM2D INPUT projection W * x_t + b (MultiObjDetTracker.py:176; 55 % of
+// the recurrent head's FLOPs) does not depend on the recurrence, so the rank that ran the detector on a frame runs it too and
+// the rows that travel are xproj rows [G, G, 4U] (1.38 MB per frame at 416x416); the clip's owner is left with the sequential part only.
+extern "C" int dt_track_xproj_width(dt_ctx *ctx)
+{
+    return (ctx && ctx->trk_loaded) ? 4 * ctx->trk_units : 0;
+}
+
+extern "C" int dt_track_detect_xproj(dt_ctx *ctx, const void *d_frames, int frames_dtype, int n_frames, float *d_xp, float *d_det)
+{
+    if (!ctx || !d_frames || !d_xp) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (!ctx->trk_loaded) return dt_fail(ctx, DT_ERR_STATE, "tracker weights not loaded");
+    if (n_frames <= 0) return dt_fail(ctx, DT_ERR_ARG, "n_frames must be positive");
+    const int gh = ctx->image_h / 32, gw = ctx->image_w / 32, GG = gh * gw;
+    const int Cx = ctx->trk_cx, Cb = ctx->cb;
+    float *z = ws_get(ctx, "trk_z", (size_t)n_frames * GG * Cx * sizeof(float), /*zero_on_grow=*/true);
+    if (!z) return DT_ERR_DEVICE;
+    int rc = detect_internal(ctx, d_frames, frames_dtype, n_frames, Dest{z, Cx}, Dest{z + 1024, Cx});
+    if (rc) return rc;
+    rc = convlstm_sequence(ctx, z, Cx, n_frames, 1, gh, gw, ctx->trk_units, ctx->trk_wx, ctx->trk_bx, ctx->trk_wh, nullptr,
+                           ctx->trk_wx_wino, ctx->trk_wh_wino, d_xp);
+    if (rc) return rc;
+    if (d_det && launch_copy_cols(ctx->stream, z + 1024, Cx, d_det, Cb, (long long)n_frames * GG, Cb))
+        return dt_fail(ctx, DT_ERR_DEVICE, "detection copy launch failed");
+    return DT_OK;
+}
+
+extern "C" int dt_track_recurrent_xproj(dt_ctx *ctx, const float *d_xp, int n_clips, int T, float *d_trk)
+{
+    if (!ctx || !d_xp) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (!ctx->trk_loaded) return dt_fail(ctx, DT_ERR_STATE, "tracker weights not loaded");
+    if (n_clips <= 0 || T <= 0) return dt_fail(ctx, DT_ERR_ARG, "n_clips and T must be positive");
+    const int gh = ctx->image_h / 32, gw = ctx->image_w / 32, GG = gh * gw;
+    const int F = n_clips * T, U = ctx->trk_units, Cb = ctx->cb;
+    float *hseq = ws_get(ctx, "trk_h", (size_t)F * GG * U * sizeof(float));
+    if (!hseq) return DT_ERR_DEVICE;
+    int rc = convlstm_sequence(ctx, nullptr, ctx->trk_cx, n_clips, T, gh, gw, U, ctx->trk_wx, ctx->trk_bx, ctx->trk_wh, hseq,
+                               ctx->trk_wx_wino, ctx->trk_wh_wino, const_cast<float *>(d_xp));
+    if (rc) return rc;
+    float *trk = d_trk;
+    if (!trk) {
+        trk = ws_get(ctx, "trk_out", (size_t)F * GG * Cb * sizeof(float));
+        if (!trk) return DT_ERR_DEVICE;
+    }
+    ConvLayer L;       // TimeDistributed(Conv2D(Cb,(1,1)))  'tconv_2'  (MultiObjDetTracker.py:182)
+    L.idx = 102; L.ks = 1; L.cin = U; L.cout = Cb; L.npad = ctx->trk_wo_npad; L.wt = ctx->trk_wo; L.bias = ctx->trk_bo;
+    return run_conv(ctx, L, hseq, U, F, gh, gw, trk, Cb, ORD_LINEAR, EPI_PLAIN, 1.0f);
 }
 
 // ---------------------------------------------------------------------------

@@ -28,6 +28,7 @@ SYMBOLS = [
     "dt_profile_enable", "dt_profile_reset", "dt_profile_read", "dt_profile_names", "dt_policy_reload", "dt_detector_extract", "dt_decode_per_frame",
     "dt_track_row_width", "dt_track_detect", "dt_track_recurrent",
     "dt_packed_row_ints", "dt_pack_detections", "dt_unpack_detections",
+    "dt_track_xproj_width", "dt_track_detect_xproj", "dt_track_recurrent_xproj",
 ]
 
 _lib = None
@@ -70,6 +71,9 @@ def load_library():
     L.dt_track_row_width.argtypes = [vp]
     L.dt_track_detect.argtypes = [vp, vp, ci, ci, vp]
     L.dt_track_recurrent.argtypes = [vp, vp, ci, ci, vp, vp]
+    L.dt_track_xproj_width.argtypes = [vp]
+    L.dt_track_detect_xproj.argtypes = [vp, vp, ci, ci, vp, vp]
+    L.dt_track_recurrent_xproj.argtypes = [vp, vp, ci, ci, vp]
     L.dt_packed_row_ints.argtypes = [ci, ci]
     L.dt_pack_detections.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.dt_unpack_detections.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp]
@@ -362,6 +366,30 @@ class Context(object):
         self._sync_stream()
         self._check(self.lib.dt_track_recurrent(self.h, _dptr(z), n_clips, T, _dptr(trk), _dptr(det)), "dt_track_recurrent")
         return (trk, det) if want_det else trk
+
+    def track_xproj_width(self):
+        return int(self.lib.dt_track_xproj_width(self.h))
+
+    def track_detect_xproj(self, frames):
+        """frames [F,H,W,3] -> ConvLSTM input-projection rows [F,G,G,4U] (frame-shard half 1, projection included)."""
+        assert frames.is_cuda and frames.is_contiguous() and frames.dim() == 4
+        F = frames.shape[0]
+        gh, gw = self.grid
+        xp = self._f32(F, gh, gw, self.track_xproj_width())
+        self._sync_stream()
+        self._check(self.lib.dt_track_detect_xproj(self.h, _dptr(frames), self._frames_dtype(frames), F, _dptr(xp), None),
+                    "dt_track_detect_xproj")
+        return xp
+
+    def track_recurrent_xproj(self, xp):
+        """xp [n_clips,T,G,G,4U] -> tracking grid [n_clips,T,G,G,NB,5+C] (frame-shard half 2: the recurrence alone)."""
+        assert xp.is_cuda and xp.is_contiguous() and xp.dim() == 5 and xp.dtype == self.torch.float32
+        n_clips, T = xp.shape[:2]
+        gh, gw = self.grid
+        trk = self._f32(n_clips, T, gh, gw, self.nb_box, 5 + self.nb_class)
+        self._sync_stream()
+        self._check(self.lib.dt_track_recurrent_xproj(self.h, _dptr(xp), n_clips, T, _dptr(trk)), "dt_track_recurrent_xproj")
+        return trk
 
     # ---- tiny tracker ---------------------------------------------------
     def tiny_load(self, D, units, kernel, recurrent, bias, dense_kernel, dense_bias):

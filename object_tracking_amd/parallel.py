@@ -157,13 +157,16 @@ def _all_to_all_rows(send, group, async_op):
     return out, work
 
 
-def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=2, stats=None):
+def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=2, stats=None, rows=None):
     """MultiObjDetTracker on clips whose frames are spread over the ranks of `group`: ONE stream can use all GPUs.
       1. detector (the 74 % of a frame's FLOPs) on this rank's time steps {t : t mod N = rank} of EVERY clip
          (dt_track_detect).  `frames` is either the whole [n_clips,T,H,W,3] batch (a rank then touches only its own
          time steps of it) or -- sharded ingest, pass T -- only this rank's frames [n_clips, len(frame_shard_times),
          H,W,3]: nothing but a rank's own frames has to reach its HBM;
-      2. the per-frame rows z = [conv_feat | x_bbox] (757 KB/frame at 416x416) go to the OWNER of their clip only
+         With rows="xproj" (the default where the context offers dt_track_detect_xproj) the same rank also runs the
+         ConvLSTM2D INPUT projection of its frames -- it does not depend on the recurrence, and it is 55 % of the recurrent
+         head's FLOPs -- so only the sequential part is left for the clip's owner; rows="z" exchanges the detector rows;
+      2. the per-frame rows (xproj [G,G,4U]: 1.38 MB/frame at 416x416; z = [conv_feat | x_bbox]: 757 KB) go to the OWNER of their clip only
          (round-robin owners, `owned_clips`): one all_to_all_single per chunk of the local time axis, issued
          asynchronously so that the exchange of chunk k runs under the detector pass of chunk k+1.  A rank receives
          (its clips) x T rows -- 1/N of what an all-gather would deliver;
@@ -187,7 +190,12 @@ def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=
     Tl = (T + world - 1) // world                      # local slots per clip, padded
     n_own = (n_clips + world - 1) // world             # clips per owner, padded
     gh, gw = ctx.grid
-    rw = ctx.track_row_width()
+    if rows is None:
+        rows = "xproj" if hasattr(ctx, "track_detect_xproj") else "z"
+    assert rows in ("xproj", "z")
+    rw = ctx.track_xproj_width() if rows == "xproj" else ctx.track_row_width()
+    detect = ctx.track_detect_xproj if rows == "xproj" else ctx.track_detect
+    recurrent = ctx.track_recurrent_xproj if rows == "xproj" else ctx.track_recurrent
     # clip order of the send buffer: owner-major, each owner's clips in increasing index
     perm = [c for r in range(world) for c in owned_clips(n_clips, r, world)]
     slot_of = {}
@@ -205,7 +213,7 @@ def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=
         jr = min(j1, len(mine_t))                      # slots of this chunk that exist on this rank
         if jr > j0:
             sub = (frames[:, j0:jr] if local_only else frames[:, mine_t[j0:jr]]).contiguous()
-            z = ctx.track_detect(sub.reshape((n_clips * (jr - j0),) + tuple(frames.shape[2:])))
+            z = detect(sub.reshape((n_clips * (jr - j0),) + tuple(frames.shape[2:])))
             z = z.reshape((n_clips, jr - j0) + tuple(z.shape[1:]))
             for c in range(n_clips):
                 r, k = slot_of[c]
@@ -227,7 +235,7 @@ def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=
                 if src != rank:
                     recv_bytes += len(my_owned) * len(ts) * gh * gw * rw * 4
     if my_owned:
-        res = trk.decode_and_associate(ctx.track_recurrent(z_mine), cap=cap)
+        res = trk.decode_and_associate(recurrent(z_mine), cap=cap)
     else:
         res = trk.empty_result(T, cap)
     if stats is not None:

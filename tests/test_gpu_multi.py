@@ -119,6 +119,13 @@ d = trk.detector.model.to_device(frames)
 z = ctx.track_detect(d.reshape(N * T, H, W, 3))
 halves = ctx.track_recurrent(z.reshape(N, T, 3, 3, -1))
 ok &= torch.equal(halves, ctx.track_forward(d, want_det=False))
+# ... and so does the split one step later (input projection on the detector's side), which is what the frame-shard ships by default
+xp = ctx.track_detect_xproj(d.reshape(N * T, H, W, 3))
+ok &= xp.shape[-1] == ctx.track_xproj_width() == 4 * 512
+ok &= torch.equal(ctx.track_recurrent_xproj(xp.reshape(N, T, 3, 3, -1)), ctx.track_forward(d, want_det=False))
+# both row kinds give the single-process ids
+out_z = track_clips_frame_sharded(trk, frames, rows="z")
+ok &= torch.equal(out_z["ids"], ref["ids"]) and torch.equal(out_z["counts"], ref["counts"])
 print("RANK", rank, "OK" if ok else "MISMATCH", int(ref["counts"].sum()), flush=True)
 dist.barrier(); dist.destroy_process_group()
 sys.exit(0 if ok else 1)

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(mi355_dt.LIB_PATH)
     for s in declared:
         assert hasattr(lib, s), "missing export " + s
-    assert lib.dt_abi_version() == 104
+    assert lib.dt_abi_version() == 105
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -296,6 +296,13 @@ class Ctx(object):                         # torch-CPU stand-in for the two halv
         return m.view(-1, 1, 1, 1) * torch.ones(fr.shape[0], 2, 3, 8) + torch.arange(8.0)
     def track_recurrent(self, z):          # a recurrence over T: running sum
         return torch.cumsum(z, dim=1)
+    # the split one step later: detector + input projection per frame (here: x2, rows twice as wide), recurrence on those rows
+    def track_xproj_width(self): return 16
+    def track_detect_xproj(self, fr):
+        z = self.track_detect(fr)
+        return torch.cat([z, 2.0 * z], dim=-1)
+    def track_recurrent_xproj(self, xp):
+        return torch.cumsum(xp[..., :8], dim=1)
 
 class Det(object):
     class model(object):
@@ -330,18 +337,19 @@ for (n_clips, T) in [(3, 5), (1, 4), (4, 2), (5, 9), (2, 1)]:   # uneven time sh
     want["gids"] = global_track_ids(want["ids"], want["nids"])
     mine = frame_shard_times(T, rank, world)
     for chunks in (1, 2, 3):
-        for local in (False, True):                # whole batch on every rank / sharded ingest: only this rank's frames
+        for local, rows in ((False, "z"), (True, "z"), (True, "xproj"), (False, None)):   # whole batch on every rank / sharded ingest; which rows travel
             Ctx.calls = []
             st = {}
+            rwid = 8 if rows == "z" else 16
             if local:
-                got = track_clips_frame_sharded(trk, frames[:, mine].contiguous(), cap=4, T=T, chunks=chunks, stats=st)
+                got = track_clips_frame_sharded(trk, frames[:, mine].contiguous(), cap=4, T=T, chunks=chunks, stats=st, rows=rows)
             else:
-                got = track_clips_frame_sharded(trk, frames, cap=4, chunks=chunks, stats=st)
+                got = track_clips_frame_sharded(trk, frames, cap=4, chunks=chunks, stats=st, rows=rows)
             ok &= all(torch.equal(got[k], want[k]) for k in ("boxes", "counts", "ids", "nids", "gids"))
             ok &= sum(Ctx.calls) == n_clips * len(mine)          # the detector ran on this rank's frames only
             # rows arrive at the clip's owner only: (own clips) x (other ranks' time steps) rows of 2*3*8 floats
             own = len(range(rank, n_clips, world))
-            want_rows = own * (T - len(mine)) * 2 * 3 * 8 * 4
+            want_rows = own * (T - len(mine)) * 2 * 3 * rwid * 4
             row_ints = T * 4 * 8 + T * 4 + T + 2
             want_det = (world - 1) * ((n_clips + world - 1) // world) * row_ints * 4
             ok &= st["bytes_received"] == want_rows + want_det
