@@ -96,6 +96,7 @@ struct WinoArgs {
     // P = (ts+2)^2 Winograd positions
     int B, H, W, th, tw, Mt, ts;
     int g;   // frames per side of the virtual mosaic the tiles live on (1: one frame; winograd.hip:vpixel)
+    int coop;  // F(6x6) lane-cooperative transform kernels: -1 small launches only (default), 0 never, 1 always (Policy::wino_coop)
     // input transform: in (NHWC, pixel stride in_ld, image stride in_bs), C channels -> v [P][Mt][C]
     const float *in;
     long long in_bs;
@@ -253,6 +254,7 @@ struct Policy {
     int conv_cfg = -1;       // DT_CONV_CFG
     int w4s = 2;             // DT_W4S: 2 (default) = the LDS-staged fused F(4x4) kernel (wino4s_fused.hip) where fused4 applies AND for
                              //         conv_2 (instead of its fused F(2x2) kernel); 1 = not for conv_2; 0 = wino4_fused.hip
+    int wino_coop = -1;      // DT_WINO_COOP: lane-cooperative F(6x6) transform kernels: -1 for small launches (default) / 0 never / 1 always
     int persist = 1;         // DT_PERSIST: 0 = one tile per workgroup for the GEMM-shaped launches (A/B runs)
     int xcd_remap = 1;       // DT_XCD_REMAP: 0 = plain tile numbering (L2 traffic experiments)
     int tile_gn = -1;        // DT_TILE_GN: column tiles per group of the tile order; -1 = per-layer default

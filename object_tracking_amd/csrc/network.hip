@@ -424,6 +424,7 @@ void policy_from_env(Policy &p)
     p.ksplit = geti("DT_KSPLIT", d.ksplit);
     p.conv_cfg = geti("DT_CONV_CFG", d.conv_cfg);
     p.w4s = geti("DT_W4S", d.w4s);
+    p.wino_coop = geti("DT_WINO_COOP", d.wino_coop);
     p.persist = geti("DT_PERSIST", d.persist);
     p.xcd_remap = geti("DT_XCD_REMAP", d.xcd_remap);
     p.tile_gn = geti("DT_TILE_GN", d.tile_gn);
@@ -561,6 +562,7 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
     WinoArgs w;
     memset(&w, 0, sizeof(w));
     w.B = B; w.H = H; w.W = W; w.ts = ts;
+    w.coop = ctx->pol.wino_coop;
     {
         const WinoGeom q = wino_geometry(ctx, ts, B, H, W, io.out2 != nullptr);
         w.g = q.g; w.th = q.th; w.tw = q.tw; w.Mt = q.Mt;

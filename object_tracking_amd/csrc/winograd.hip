@@ -375,10 +375,129 @@ static unsigned wino_blocks(long long items)
 
 // vector width per work item: 4 channels for the input transforms, 4 / 2 / 1 for the F(2,3) / F(4,3) / F(4,3)-gates
 // output transforms (register budget of the 36-plane patch)
+
+// ---- lane-cooperative F(6x6) transforms for SMALL launches (a few frames per call: BASELINE configs[1]) ------------------
+// With ~25 k work items the kernels above are ~100 workgroups of one serial chain per thread (64 loads, ~600 VALU, 64
+// stores: 10-28 us per launch, 26 launches per batch-8 forward).  Here EIGHT lanes share one (tile, 4 channels) item:
+// each lane does one column in the first pass and one row in the second, with an 8x8 transpose through LDS in between --
+// 8 loads and 8 stores per lane, 8x the workgroups.  Operation order per output value is exactly that of
+// wino_input_kernel / wino_output_kernel (column pass, then row pass), so results are bit-identical to them.
+// LDS image per item: [8][9] float4 (row stride 9: the column-major writes and the row-major reads are conflict-free;
+// 288 floats per item = 32 banks past a multiple of 64, so the two items of a 16-lane access group do not collide either).
+#define WINO_COOP_ITEM 288
+#define WINO_COOP_MAX_ITEMS (768 * WINO_THREADS)     // (tile, channel-pair) items below which a launch takes the cooperative kernels
+__global__ __launch_bounds__(WINO_THREADS) void wino_input_coop6_kernel(WinoArgs p)
+{
+    typedef VecOf<4>::T T;
+    __shared__ __attribute__((aligned(16))) float s_t[(WINO_THREADS / 8) * WINO_COOP_ITEM];
+    const int cq_n = p.C / 4;
+    const long long items = (long long)p.Mt * cq_n;
+    const long long plane = (long long)p.Mt * p.C;
+    const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;
+    float *st = s_t + slot * WINO_COOP_ITEM;
+    for (long long base = (long long)blockIdx.x * (WINO_THREADS / 8); base < items; base += (long long)gridDim.x * (WINO_THREADS / 8)) {
+        const long long it = base + slot;
+        const bool live = it < items;
+        const int tile = live ? (int)(it / cq_n) : 0;
+        const int c = live ? (int)(it - (long long)tile * cq_n) * 4 : 0;
+        const TileId t = tile_id(p, tile);
+        T col[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {           // this lane's column `sub` of the 8x8 window
+            int b, h, w;
+            const bool ok = live && vpixel(p, t.grp, 6 * t.ty - 1 + i, 6 * t.tx - 1 + sub, b, h, w);
+            col[i] = ok ? vload_in<4>(p.in + (long long)b * p.in_bs + (long long)(h * p.W + w) * p.in_ld + c) : vzero<4>();
+        }
+        bt_1d<6>(col);                           // Bt d : down the column
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vstore<4>(st + (sub * 9 + i) * 4, col[i]);      // [column][xi]
+        __syncthreads();
+        T row[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[j] = vload<4>(st + (j * 9 + sub) * 4);     // row xi = sub: all eight columns
+        bt_1d<6>(row);                           // (Bt d) B : along the row
+        if (live) {
+            float *dst = p.v + (long long)tile * p.C + c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vstore_v<4>(dst + (long long)(8 * sub + j) * plane, row[j]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArgs p)
+{
+    typedef VecOf<4>::T T;
+    __shared__ __attribute__((aligned(16))) float s_t[(WINO_THREADS / 8) * WINO_COOP_ITEM];
+    const int nq = p.N / 4;
+    const long long items = (long long)p.Mt * nq;
+    const long long plane = (long long)p.Mt * p.m_ld;
+    const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;
+    float *st = s_t + slot * WINO_COOP_ITEM;
+    for (long long base = (long long)blockIdx.x * (WINO_THREADS / 8); base < items; base += (long long)gridDim.x * (WINO_THREADS / 8)) {
+        const long long it = base + slot;
+        const bool live = it < items;
+        const int tile = live ? (int)(it / nq) : 0;
+        const int c = live ? (int)(it - (long long)tile * nq) * 4 : 0;
+        const TileId t = tile_id(p, tile);
+        T col[8];
+        const float *src = p.m + (long long)tile * p.m_ld + c;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) col[i] = live ? vload_nt<4>(src + (long long)(8 * i + sub) * plane) : vzero<4>();   // column nu = sub
+        at_1d<6>(col);                           // At m : down the column -> rows 0..5
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vstore<4>(st + (sub * 9 + i) * 4, col[i]);
+        __syncthreads();
+        T row[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[j] = vzero<4>();
+        if (sub < 6) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) row[j] = vload<4>(st + (j * 9 + sub) * 4);
+            at_1d<6>(row);                       // (At m) A : along the row -> 6 pixels of output row `sub`
+            const T bv = (live && p.bias) ? vload<4>(p.bias + c) : vzero<4>();
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                T v = row[j] + bv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) set_lane<4>(v, e, wino_leaky(lane_of<4>(v, e), p.slope));
+                row[j] = v;
+                int b, h, w;
+                if (live && p.out && vpixel(p, t.grp, 6 * t.ty + sub, 6 * t.tx + j, b, h, w))
+                    vstore_nt<4>(p.out + (long long)b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c, v);
+            }
+        }
+        if (p.out2) {   // MaxPooling2D(2,2) (g == 1: launcher): output rows 2k, 2k+1 sit in neighbouring lanes
+            const int H2 = p.H >> 1, W2 = p.W >> 1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                T mx;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = fmaxf(lane_of<4>(row[2 * k], e), lane_of<4>(row[2 * k + 1], e));
+                    set_lane<4>(mx, e, fmaxf(a, __shfl_xor(a, 1)));
+                }
+                const int h2 = 3 * t.ty + (sub >> 1), w2 = 3 * t.tx + k;
+                if (live && sub < 6 && !(sub & 1) && h2 < H2 && w2 < W2)
+                    vstore<4>(p.out2 + ((long long)(t.grp * H2 + h2) * W2 + w2) * p.out2_ld + c, mx);
+            }
+        }
+        __syncthreads();
+    }
+}
+// a launch this small is latency-bound on the one-thread-per-item kernels: take the cooperative form
+static inline bool wino_coop_wanted(const WinoArgs &a, long long items_pairs)
+{
+    return a.coop > 0 || (a.coop < 0 && items_pairs < (long long)WINO_COOP_MAX_ITEMS);
+}
+
 int launch_wino_input(hipStream_t st, const WinoArgs &a)
 {
     if (a.C % 4 || a.in_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4 && a.ts != 6) || a.g < 1) return 2;
-    if (a.ts == 6)
+    if (a.ts == 6 && wino_coop_wanted(a, (long long)a.Mt * (a.C / 2))) {
+        const long long wgs = ((long long)a.Mt * (a.C / 4) + WINO_THREADS / 8 - 1) / (WINO_THREADS / 8);
+        hipLaunchKernelGGL(wino_input_coop6_kernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
+    } else if (a.ts == 6)
         hipLaunchKernelGGL((wino_input_kernel<6, 2>), dim3(wino_blocks((long long)a.Mt * (a.C / 2))), dim3(wino_threads((long long)a.Mt * (a.C / 2))), 0,
                            st, a);
     else if (a.ts == 2)
@@ -404,7 +523,10 @@ int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates)
     } else {
         // vector stores need aligned rows; ragged N (conv_23-like heads) never takes this path
         if (a.N % 4 || (a.out && a.out_ld % 4) || (a.out2 && a.out2_ld % 4)) return 2;
-        if (a.ts == 6)
+        if (a.ts == 6 && wino_coop_wanted(a, (long long)a.Mt * (a.N / 2))) {
+            const long long wgs = ((long long)a.Mt * (a.N / 4) + WINO_THREADS / 8 - 1) / (WINO_THREADS / 8);
+            hipLaunchKernelGGL(wino_output_coop6_kernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
+        } else if (a.ts == 6)
             hipLaunchKernelGGL((wino_output_kernel<6, 2>), dim3(wino_blocks((long long)a.Mt * (a.N / 2))), dim3(wino_threads((long long)a.Mt * (a.N / 2))),
                                0, st, a);
         else if (a.ts == 2)
