@@ -102,6 +102,8 @@ struct WinoArgs {
     long long in_bs;
     int in_ld, C;
     float *v;
+    unsigned short *v_s3;   // non-null: V as three bf16 terms [P][3][C/16][Mp][16] for wino_gemm_s3.hip instead of v (ts == 6, C % 32 == 0)
+    int Mp;                 // rows of that layout (Mt rounded up to the GEMM's row tile)
     // output transform: m [P][Mt][m_ld], N columns -> out (full resolution, may be null) / out2 (2x2 pooled, may be null)
     const float *m;
     int m_ld, N;
@@ -151,9 +153,24 @@ void wino4_fused_pack(const float *u36, int npad, int cin, int cout, float *dst)
 // second-generation fused F(4x4,3x3) kernel: U staged through LDS by DMA, in-register output transform, persistent (wino4s_fused.hip)
 int launch_wino4s_fused(hipStream_t st, const Wino4FusedArgs &a, const float *zeros);
 void wino4s_fused_pack(const float *u36, int npad, int cin, int cout, float *dst);
+// split-bf16 batched GEMM of the F(6x6,3x3) layers (wino_gemm_s3.hip): fp32 operands as three bf16 terms, six MFMAs per product
+struct GemmS3Args {
+    const unsigned short *a;   // V terms  [P][3][K/16][Mp][16]   (winograd.hip split input transform)
+    const unsigned short *b;   // U terms  [P][3][K/16][Np][16]   (wino_s3_pack_weights)
+    float *c;                  // M'       [P] planes of [Mt][ldc], plane stride c_ps floats
+    long long c_ps;
+    int P, Mt, Mp, N, Np, K, ldc;
+};
+int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus);
+bool wino_gemm_s3_usable(int Mt, int K, int N);
+double wino_gemm_s3_flops(const GemmS3Args &a);
+void wino_s3_split_host(float x, unsigned short t[3]);
+void wino_s3_pack_weights(const float *u, int P, int npad, int K, unsigned short *dst);
 int launch_wino2_fused_pool(hipStream_t st, const WinoFusedArgs &a);
 void wino2_fused_pack(const float *hwio, const float *scale, float *dst);
 int launch_wino_input(hipStream_t st, const WinoArgs &a);
+// U [P][npad][K] fp32 (device) -> split-bf16 [P][3][K/16][npad][16] (device)
+int launch_wino_s3_pack(hipStream_t st, const float *u, int P, int npad, int K, unsigned short *dst);
 int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates);
 void wino_pack_weights(int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map, int cin_dst, const int *n_map,
                        int npad, const float *scale, float *dst);
@@ -254,6 +271,9 @@ struct Policy {
     int conv_cfg = -1;       // DT_CONV_CFG
     int w4s = 2;             // DT_W4S: 2 (default) = the LDS-staged fused F(4x4) kernel (wino4s_fused.hip) where fused4 applies AND for
                              //         conv_2 (instead of its fused F(2x2) kernel); 1 = not for conv_2; 0 = wino4_fused.hip
+    int s3 = 1;              // DT_S3: the F(6x6) layers' batched GEMMs on the bf16 matrix pipe with 3-term split operands (wino_gemm_s3.hip):
+                             //        0 never (fp32 MFMA) / 1 where it wins (K >= s3_mink, GEMM rows >= s3_minrows) / 2 wherever the shape allows
+    int s3_mink = 256, s3_minrows = 2048;   // DT_S3_MINK / DT_S3_MINROWS
     int wino_coop = -1;      // DT_WINO_COOP: lane-cooperative F(6x6) transform kernels: -1 for small launches (default) / 0 never / 1 always
     int persist = 1;         // DT_PERSIST: 0 = one tile per workgroup for the GEMM-shaped launches (A/B runs)
     int xcd_remap = 1;       // DT_XCD_REMAP: 0 = plain tile numbering (L2 traffic experiments)
@@ -274,6 +294,7 @@ struct dt_ctx {
     int dec_anchors_n = 0;
     bool det_loaded = false;
     ConvLayer layers[24];   // 1..23
+    std::map<const void *, unsigned short *> wino_s3;   // F(6x6) Winograd weights (device pointer) -> their split-bf16 form (wino_gemm_s3.hip), when built
     float *conv1_w = nullptr, *conv1_b = nullptr, *lut255 = nullptr;
     std::vector<float> conv1_hwio32, conv1_scale, conv1_shift;   // host copy of conv_1 as a Cin = 32 layer (dt_detector_extract)
     // tracker head

@@ -148,6 +148,13 @@ ProfScope::~ProfScope()
     ctx->pending.push_back(ev);
 }
 
+// forget (and free) the split-bf16 twin of a Winograd weight buffer that is about to be freed
+static void s3_drop(dt_ctx *ctx, const void *wino)
+{
+    auto it = ctx->wino_s3.find(wino);
+    if (wino && it != ctx->wino_s3.end()) { (void)hipFree(it->second); ctx->wino_s3.erase(it); }
+}
+
 static int upload(dt_ctx *ctx, float **dst, const std::vector<float> &h)
 {
     if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
@@ -198,6 +205,7 @@ extern "C" void dt_destroy(dt_ctx *ctx)
     for (int i = 0; i <= 23; ++i) {
         if (ctx->layers[i].wt) (void)hipFree(ctx->layers[i].wt);
         if (ctx->layers[i].bias) (void)hipFree(ctx->layers[i].bias);
+        s3_drop(ctx, ctx->layers[i].wino);
         if (ctx->layers[i].wino) (void)hipFree(ctx->layers[i].wino);
         if (ctx->layers[i].wino_alt) (void)hipFree(ctx->layers[i].wino_alt);
         if (ctx->layers[i].fused) (void)hipFree(ctx->layers[i].fused);
@@ -208,6 +216,7 @@ extern "C" void dt_destroy(dt_ctx *ctx)
     float *singles[] = {ctx->conv1_w, ctx->conv1_b, ctx->lut255, ctx->anchors_dev, ctx->trk_wx, ctx->trk_bx,
                         ctx->trk_wh,  ctx->trk_wo,  ctx->trk_bo, ctx->trk_wx_wino, ctx->trk_wh_wino, ctx->tiny_wx,     ctx->tiny_bx, ctx->tiny_ur,
                         ctx->tiny_wd, ctx->tiny_bd};
+    s3_drop(ctx, ctx->trk_wx_wino);
     for (float *p : singles)
         if (p) (void)hipFree(p);
     for (auto &e : ctx->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -284,7 +293,7 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
         for (float v : sc) L.scale_has_zero |= (v == 0.0f);
         if ((rc = upload(ctx, &L.scale, sc))) return rc;
     }
-    if (L.wino) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino); L.wino = nullptr; }
+    if (L.wino) { (void)hipStreamSynchronize(ctx->stream); s3_drop(ctx, L.wino); (void)hipFree(L.wino); L.wino = nullptr; }
     if (L.wino_alt) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino_alt); L.wino_alt = nullptr; }
     if (L.fused) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused); L.fused = nullptr; }
     if (L.fused4) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused4); L.fused4 = nullptr; }
@@ -425,6 +434,9 @@ void policy_from_env(Policy &p)
     p.conv_cfg = geti("DT_CONV_CFG", d.conv_cfg);
     p.w4s = geti("DT_W4S", d.w4s);
     p.wino_coop = geti("DT_WINO_COOP", d.wino_coop);
+    p.s3 = geti("DT_S3", d.s3);
+    p.s3_mink = geti("DT_S3_MINK", d.s3_mink);
+    p.s3_minrows = geti("DT_S3_MINROWS", d.s3_minrows);
     p.persist = geti("DT_PERSIST", d.persist);
     p.xcd_remap = geti("DT_XCD_REMAP", d.xcd_remap);
     p.tile_gn = geti("DT_TILE_GN", d.tile_gn);
@@ -467,7 +479,18 @@ static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int 
 {
     std::vector<float> u((size_t)(ts + 2) * (ts + 2) * npad * cin_dst);
     wino_pack_weights(ts, hwio, cin_src, cout_src, cin_map, cin_dst, n_map, npad, scale, u.data());
-    return upload(ctx, dst, u);
+    s3_drop(ctx, *dst);
+    int rc = upload(ctx, dst, u);
+    if (rc) return rc;
+    // F(6x6) weights also in the split-bf16 form of wino_gemm_s3.hip (the split runs on the device, from the fp32 copy)
+    if (ts == 6 && ctx->pol.s3 != 0 && cin_dst % 32 == 0 && npad % 128 == 0) {
+        unsigned short *s3 = nullptr;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s3), u.size() * 3 * sizeof(unsigned short)));
+        if (launch_wino_s3_pack(ctx->stream, *dst, 64, npad, cin_dst, s3)) { (void)hipFree(s3); return dt_fail(ctx, DT_ERR_DEVICE, "split-bf16 weight pack launch failed"); }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->wino_s3[*dst] = s3;
+    }
+    return DT_OK;
 }
 
 // Tile configuration of the P batched GEMMs [Mt x Cin] x [Cin x N] (persistent launch, conv_igemm.hip).
@@ -574,20 +597,41 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
     }
     const int P = (ts + 2) * (ts + 2);
     const size_t mt = (size_t)w.Mt;
-    float *V = ws_get(ctx, "wino_v", P * mt * cin * sizeof(float));
+    // the GEMMs on the bf16 pipe with split operands (wino_gemm_s3.hip) where that form exists and wins: long K, enough rows
+    const unsigned short *u_s3 = nullptr;
+    if (ts == 6 && !io.cstate && ctx->pol.s3 != 0 && cin % 32 == 0 && N % 128 == 0 && npad % 128 == 0 && wino_gemm_s3_usable(w.Mt, cin, N) &&
+        (ctx->pol.s3 == 2 || (cin >= ctx->pol.s3_mink && w.Mt >= ctx->pol.s3_minrows))) {
+        auto it = ctx->wino_s3.find(wino_wt);
+        if (it != ctx->wino_s3.end()) u_s3 = it->second;
+    }
+    const size_t mp = (mt + 255) / 256 * 256;
+    float *V = ws_get(ctx, "wino_v", u_s3 ? (size_t)P * 3 * mp * cin * sizeof(unsigned short) : P * mt * cin * sizeof(float));
     float *Mp = ws_get(ctx, "wino_m", P * mt * N * sizeof(float));
     if (!V || !Mp) return DT_ERR_DEVICE;
+    if (u_s3) { w.v_s3 = reinterpret_cast<unsigned short *>(V); w.Mp = (int)mp; }
     w.in = io.in; w.in_bs = io.in_bs; w.in_ld = io.in_ld; w.C = cin; w.v = V;
     w.m = Mp; w.m_ld = N; w.N = N; w.bias = bias; w.slope = slope;
     w.out = io.out; w.out_bs = io.out_bs; w.out_ld = io.out_ld; w.out2 = io.out2; w.out2_ld = io.out2_ld;
     w.xproj = io.xproj; w.xp_bs = io.xp_bs; w.xp_ld = io.xp_ld;
     w.cstate = io.cstate; w.c_bs = io.c_bs; w.c_ld = io.c_ld;
     {
-        ProfScope ps(ctx, "wino_input", 0.0, 4.0 * ((double)B * H * W * cin + (double)P * mt * cin), tag);
+        ProfScope ps(ctx, "wino_input", 0.0, 4.0 * (double)B * H * W * cin + (u_s3 ? 6.0 : 4.0) * (double)P * mt * cin, tag);
         const int rc = launch_wino_input(ctx->stream, w);
         if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: Winograd input transform launch failed", tag);
     }
-    {
+    if (u_s3) {
+        GemmS3Args g;
+        memset(&g, 0, sizeof(g));
+        g.a = w.v_s3; g.b = u_s3; g.c = Mp; g.c_ps = (long long)mt * N; g.P = P; g.Mt = w.Mt; g.Mp = (int)mp; g.N = N; g.Np = npad;
+        g.K = cin; g.ldc = N;
+        // flops = EXECUTED bf16 MFMA work (six partial products per multiply); bytes = V + U (three bf16 terms each) + M'
+        ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), (double)P * (6.0 * mt * cin + 6.0 * (double)cin * N + 4.0 * (double)mt * N), tag);
+        prof_direct_form(ctx, 2.0 * B * H * W * 9.0 * cin * N,
+                         4.0 * ((double)B * H * W * cin + 9.0 * cin * N + (io.out ? (double)B * H * W * N : 0.0) +
+                                (io.out2 ? (double)B * H * W * N / 4.0 : 0.0)));
+        const int rc = launch_wino_gemm_s3(ctx->stream, g, 0);
+        if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: split-bf16 Winograd GEMM launch failed (rc=%d)", tag, rc);
+    } else {
         ConvArgs a;
         memset(&a, 0, sizeof(a));
         a.in = V; a.in_ld = cin; a.in_bs = (long long)mt * cin;
@@ -1159,7 +1203,7 @@ extern "C" int dt_tracker_load(dt_ctx *ctx, int units, const float *h_kernel, co
     if ((rc = upload(ctx, &ctx->trk_wo, wo))) return rc;
     if ((rc = upload(ctx, &ctx->trk_bo, bo))) return rc;
     for (float **w : {&ctx->trk_wx_wino, &ctx->trk_wh_wino})
-        if (*w) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(*w); *w = nullptr; }
+        if (*w) { (void)hipStreamSynchronize(ctx->stream); s3_drop(ctx, *w); (void)hipFree(*w); *w = nullptr; }
     ctx->trk_wino_ts = wino_tile(ctx, false);
     ctx->trk_wh_ts = wino_tile(ctx, true);
     if (wino_wanted(ctx, 3, Cx, 4 * U) &&

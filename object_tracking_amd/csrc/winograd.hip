@@ -386,20 +386,48 @@ static unsigned wino_blocks(long long items)
 // 288 floats per item = 32 banks past a multiple of 64, so the two items of a 16-lane access group do not collide either).
 #define WINO_COOP_ITEM 288
 #define WINO_COOP_MAX_ITEMS (768 * WINO_THREADS)     // (tile, channel-pair) items below which a launch takes the cooperative kernels
+// fp32 -> three bf16 terms (round to nearest even at every step; host twin: wino_gemm_s3.hip:wino_s3_split_host)
+typedef __bf16 wino_bf4 __attribute__((ext_vector_type(4)));
+typedef unsigned int wino_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void s3_split4(const VecOf<4>::T x, wino_u2 t[3])
+{
+    const wino_bf4 h = __builtin_convertvector(x, wino_bf4);
+    const VecOf<4>::T r1 = x - __builtin_convertvector(h, VecOf<4>::T);
+    const wino_bf4 m = __builtin_convertvector(r1, wino_bf4);
+    const VecOf<4>::T r2 = r1 - __builtin_convertvector(m, VecOf<4>::T);
+    const wino_bf4 l = __builtin_convertvector(r2, wino_bf4);
+    t[0] = __builtin_bit_cast(wino_u2, h); t[1] = __builtin_bit_cast(wino_u2, m); t[2] = __builtin_bit_cast(wino_u2, l);
+}
+
+// S3: V leaves as the split-bf16 operand of wino_gemm_s3.hip, [P][3][C/16][Mp][16]; the item order then puts 4 channel
+// quads x 2 tiles in a wavefront and 2 k-blocks x 2 tile pairs in a workgroup (64-byte store runs per wave-instruction,
+// neighbours of the same 128-byte lines in the same workgroup, for the loads as well)
+template <bool S3>
 __global__ __launch_bounds__(WINO_THREADS) void wino_input_coop6_kernel(WinoArgs p)
 {
     typedef VecOf<4>::T T;
     __shared__ __attribute__((aligned(16))) float s_t[(WINO_THREADS / 8) * WINO_COOP_ITEM];
     const int cq_n = p.C / 4;
-    const long long items = (long long)p.Mt * cq_n;
+    const int mt4 = (p.Mt + 3) & ~3;
+    const long long items = S3 ? (long long)mt4 * cq_n : (long long)p.Mt * cq_n;
     const long long plane = (long long)p.Mt * p.C;
     const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;
     float *st = s_t + slot * WINO_COOP_ITEM;
     for (long long base = (long long)blockIdx.x * (WINO_THREADS / 8); base < items; base += (long long)gridDim.x * (WINO_THREADS / 8)) {
         const long long it = base + slot;
-        const bool live = it < items;
-        const int tile = live ? (int)(it / cq_n) : 0;
-        const int c = live ? (int)(it - (long long)tile * cq_n) * 4 : 0;
+        bool live = it < items;
+        int tile, c;
+        if (S3) {
+            const long long hi = it >> 5;                    // (k-block pair, tile group of 4), tile group fastest
+            const int tg = (int)(hi % (mt4 >> 2)), kp = (int)(hi / (mt4 >> 2));
+            tile = tg * 4 + (int)((it >> 4) & 1) * 2 + (int)((it >> 2) & 1);
+            c = (kp * 2 + (int)((it >> 3) & 1)) * 16 + (int)(it & 3) * 4;
+            live = live && tile < p.Mt;
+            if (!live) { tile = 0; c = 0; }
+        } else {
+            tile = live ? (int)(it / cq_n) : 0;
+            c = live ? (int)(it - (long long)tile * cq_n) * 4 : 0;
+        }
         const TileId t = tile_id(p, tile);
         T col[8];
 #pragma unroll
@@ -416,7 +444,18 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_input_coop6_kernel(WinoArgs
 #pragma unroll
         for (int j = 0; j < 8; ++j) row[j] = vload<4>(st + (j * 9 + sub) * 4);     // row xi = sub: all eight columns
         bt_1d<6>(row);                           // (Bt d) B : along the row
-        if (live) {
+        if (live && S3) {
+            const long long term = (long long)(p.C >> 4) * p.Mp * 16;        // elements of one (plane, term)
+            unsigned short *dst = p.v_s3 + ((long long)(c >> 4) * p.Mp + tile) * 16 + (c & 15);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                wino_u2 tr[3];
+                s3_split4(row[j], tr);
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    *reinterpret_cast<wino_u2 *>(dst + ((long long)(8 * sub + j) * 3 + k) * term) = tr[k];
+            }
+        } else if (live) {
             float *dst = p.v + (long long)tile * p.C + c;
 #pragma unroll
             for (int j = 0; j < 8; ++j) vstore_v<4>(dst + (long long)(8 * sub + j) * plane, row[j]);
@@ -485,6 +524,33 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
         __syncthreads();
     }
 }
+// weights of the split-bf16 GEMM: one thread per (position, output channel, 4 input channels)
+__global__ __launch_bounds__(256) void wino_s3_pack_kernel(const float *u, int P, int npad, int K, unsigned short *dst)
+{
+    const int kq = K / 4;
+    const long long n_items = (long long)P * npad * kq;
+    const long long term = (long long)(K >> 4) * npad * 16;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < n_items; it += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(it % kq) * 4;
+        const long long r = it / kq;
+        const int n = (int)(r % npad), pz = (int)(r / npad);
+        wino_u2 tr[3];
+        s3_split4(vload<4>(u + r * K + k), tr);
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3)
+            *reinterpret_cast<wino_u2 *>(dst + ((long long)pz * 3 + t3) * term + ((long long)(k >> 4) * npad + n) * 16 + (k & 15)) = tr[t3];
+    }
+}
+int launch_wino_s3_pack(hipStream_t st, const float *u, int P, int npad, int K, unsigned short *dst)
+{
+    if (!u || !dst || P <= 0 || npad <= 0 || K % 16) return 2;
+    const long long n_items = (long long)P * npad * (K / 4);
+    long long nb = (n_items + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(wino_s3_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, u, P, npad, K, dst);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 // a launch this small is latency-bound on the one-thread-per-item kernels: take the cooperative form
 static inline bool wino_coop_wanted(const WinoArgs &a, long long items_pairs)
 {
@@ -494,9 +560,13 @@ static inline bool wino_coop_wanted(const WinoArgs &a, long long items_pairs)
 int launch_wino_input(hipStream_t st, const WinoArgs &a)
 {
     if (a.C % 4 || a.in_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4 && a.ts != 6) || a.g < 1) return 2;
-    if (a.ts == 6 && wino_coop_wanted(a, (long long)a.Mt * (a.C / 2))) {
+    if (a.v_s3) {
+        if (a.ts != 6 || a.C % 32 || a.Mp < a.Mt) return 2;
+        const long long wgs = ((long long)((a.Mt + 3) & ~3) * (a.C / 4) + WINO_THREADS / 8 - 1) / (WINO_THREADS / 8);
+        hipLaunchKernelGGL(wino_input_coop6_kernel<true>, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
+    } else if (a.ts == 6 && wino_coop_wanted(a, (long long)a.Mt * (a.C / 2))) {
         const long long wgs = ((long long)a.Mt * (a.C / 4) + WINO_THREADS / 8 - 1) / (WINO_THREADS / 8);
-        hipLaunchKernelGGL(wino_input_coop6_kernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
+        hipLaunchKernelGGL(wino_input_coop6_kernel<false>, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
     } else if (a.ts == 6)
         hipLaunchKernelGGL((wino_input_kernel<6, 2>), dim3(wino_blocks((long long)a.Mt * (a.C / 2))), dim3(wino_threads((long long)a.Mt * (a.C / 2))), 0,
                            st, a);

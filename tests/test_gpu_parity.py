@@ -1259,3 +1259,100 @@ def test_conv_fused_f4x4_one_hot(ctx, monkeypatch, w4s):
         w[n % 3, (n // 3) % 3, (n * 7) % Cin, n] = 1.0
     got = ctx.conv2d(dev(x, ctx), w, None, leaky_slope=1.0, pool=0).cpu().numpy()
     assert np.abs(got - orc.conv2d(x, w)).max() < 0.05       # integers up to 250: a misplaced tap is off by >= 1
+
+
+# ---- F(6x6) layers' GEMMs on the bf16 matrix pipe with 3-term split operands (csrc/wino_gemm_s3.hip) ------------
+def _conv_case(rs, B, H, W, Cin, Cout, heavy_tail=False):
+    x = rs.randn(B, H, W, Cin).astype(np.float32)
+    if heavy_tail:
+        x *= np.exp(rs.randn(B, H, W, Cin)).astype(np.float32)      # values over several binades: the split must not care
+    w = (rs.randn(3, 3, Cin, Cout) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32)
+    return x, w, b
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [
+    (2, 13, 13, 64, 128, 0),     # one ragged row tile, 128-wide column tile, K = 4 stages
+    (6, 13, 13, 256, 256, 0),    # mosaic g = 2, 256-wide column tile
+    (3, 26, 26, 128, 512, 2),    # pooled + full resolution outputs, two column tiles
+    (1, 13, 13, 1280, 256, 0),   # conv_22's K = 1280 (80 stages)
+    (40, 26, 26, 32, 128, 1),    # several row tiles (Mt > 256), the shortest K the kernel takes (2 stages), pooled
+    (7, 12, 18, 96, 384, 0),     # K = 6 stages, N = 3 x 128
+])
+def test_conv2d_split_bf16_gemm_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool):
+    """The split-operand GEMM (DT_S3=2: wherever the shape allows) against the oracle AND against the fp32 MFMA path of
+    the same layer: the two differ by no more than the fp32 path differs from the oracle."""
+    monkeypatch.setenv("DT_WINO", "2")
+    monkeypatch.setenv("DT_WINO_TILE", "6")
+    x, w, b = _conv_case(np.random.RandomState(B * 7 + Cin + Cout), B, H, W, Cin, Cout)
+    ref = orc.conv2d(x, w, b)
+    ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
+    outs = {}
+    for s3 in ("2", "0"):
+        monkeypatch.setenv("DT_S3", s3)
+        ctx.profile_reset(); ctx.profile_enable(True)
+        got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=pool)
+        ctx.profile_enable(False)
+        assert ctx.profile_read("conv_gemm_s3")["launches"] == (1 if s3 == "2" else 0)
+        assert ctx.profile_read("conv_igemm")["launches"] == (0 if s3 == "2" else 1)
+        outs[s3] = [g.cpu().numpy() for g in (got if pool == 2 else (got,))]
+    refs = {0: [ref], 1: [orc.maxpool2(ref)], 2: [ref, orc.maxpool2(ref)]}[pool]
+    for a, f, r in zip(outs["2"], outs["0"], refs):
+        e_s3, e_f32 = relerr(a, r), relerr(f, r)
+        assert e_s3 < 2e-4 and e_f32 < 2e-4                 # the F(6x6) tolerance of test_conv2d_winograd_vs_oracle
+        assert e_s3 < 1.25 * e_f32 + 1e-6, (e_s3, e_f32)    # and the split form is as close to the oracle as fp32 MFMA is
+        assert relerr(a, f) < 5e-5                          # ... the two forms differ by GEMM rounding (amplified by the output transform) only
+
+
+def test_split_bf16_gemm_error_against_float64(ctx, monkeypatch):
+    """Accuracy claim of wino_gemm_s3.hip: against a float64 convolution of the same fp32 inputs the split form's error
+    is not larger than the fp32 MFMA form's (both are dominated by the F(6x6) transforms), also on inputs spread over
+    many binades."""
+    monkeypatch.setenv("DT_WINO", "2")
+    monkeypatch.setenv("DT_WINO_TILE", "6")
+    rs = np.random.RandomState(5)
+    x, w, b = _conv_case(rs, 4, 26, 26, 256, 256, heavy_tail=True)
+    xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    ref64 = np.zeros((4, 26, 26, 256)) + b.astype(np.float64)
+    for dy in range(3):
+        for dx in range(3):
+            ref64 += np.tensordot(xp[:, dy:dy + 26, dx:dx + 26, :], w[dy, dx].astype(np.float64), axes=([3], [0]))
+    err = {}
+    for s3 in ("2", "0"):
+        monkeypatch.setenv("DT_S3", s3)
+        got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=1.0, pool=0).cpu().numpy().astype(np.float64)
+        err[s3] = np.sqrt(np.mean((got - ref64) ** 2)) / np.sqrt(np.mean(ref64 ** 2))
+    assert err["2"] < 1.1 * err["0"] + 1e-8, err
+    assert err["2"] < 5e-5, err
+
+
+def test_split_bf16_gemm_one_hot_taps(ctx, monkeypatch):
+    """one-hot taps on small integers: every K block / term plane / row tile / column tile of the split layout must line up."""
+    monkeypatch.setenv("DT_WINO", "2")
+    monkeypatch.setenv("DT_WINO_TILE", "6")
+    monkeypatch.setenv("DT_S3", "2")
+    B, H, W, Cin, Cout = 9, 13, 13, 96, 384
+    x = (np.arange(B * H * W * Cin, dtype=np.float32).reshape(B, H, W, Cin) % 251)
+    w = np.zeros((3, 3, Cin, Cout), dtype=np.float32)
+    for n in range(Cout):
+        w[n % 3, (n // 3) % 3, (n * 7) % Cin, n] = 1.0
+    ctx.profile_reset(); ctx.profile_enable(True)
+    got = ctx.conv2d(dev(x, ctx), w, None, leaky_slope=1.0, pool=0).cpu().numpy()
+    ctx.profile_enable(False)
+    assert ctx.profile_read("conv_gemm_s3")["launches"] == 1
+    assert np.abs(got - orc.conv2d(x, w)).max() < 0.05
+
+
+def test_split_bf16_default_policy_engages_on_deep_layers(ctx, monkeypatch):
+    """Default policy (DT_S3=1): K >= 256 and >= 2048 GEMM rows take the split form, short K / few rows stay on fp32 MFMA."""
+    monkeypatch.delenv("DT_S3", raising=False)
+    rs = np.random.RandomState(11)
+    for (B, H, W, Cin, Cout), want in (((384, 13, 13, 256, 256), 1), ((8, 13, 13, 256, 256), 0), ((96, 26, 26, 128, 256), 0)):
+        x, w, b = _conv_case(rs, B, H, W, Cin, Cout)
+        ctx.profile_reset(); ctx.profile_enable(True)
+        got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=0)
+        ctx.profile_enable(False)
+        assert ctx.profile_read("conv_gemm_s3")["launches"] == want, (B, H, W, Cin, Cout)
+        ref = orc.conv2d(x[:2], w, b)
+        ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
+        assert relerr(got[:2].cpu().numpy(), ref) < 2e-4

@@ -1,0 +1,98 @@
+// micro-benchmark + check of wino_gemm_s3.hip (the split-bf16 batched GEMM) outside the library:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I object_tracking_amd/csrc tools/micro/gemm_s3_bench.hip \
+//         object_tracking_amd/csrc/wino_gemm_s3.hip -o tools/micro/gemm_s3_bench && tools/micro/gemm_s3_bench
+// Prints, per shape, the error against a float64 product of the fp32 inputs (also for a plain fp32 fmaf chain, as the
+// yardstick) and the executed-bf16 / fp32-equivalent TFLOP/s.
+#pragma clang diagnostic ignored "-Wunused-value"
+#include "dt_internal.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include <random>
+
+int dt_fail(dt_ctx *, int rc, const char *, ...) { return rc; }
+
+static void run(int P, int Mt, int K, int N, int check_rows, int iters)
+{
+    const int Mp = (Mt + 255) / 256 * 256, Np = (N + 255) / 256 * 256, KB = K / 16;
+    std::mt19937 rng(1234);
+    std::normal_distribution<float> nd(0.0f, 1.0f);
+    const int Pc = 2;      // planes with real data for the check (the rest reuse them through the same buffers)
+    std::vector<float> V((size_t)Pc * Mt * K), U((size_t)Pc * N * K);
+    for (auto &x : V) x = nd(rng) * std::exp(nd(rng));
+    for (auto &x : U) x = nd(rng) * 0.05f;
+    std::vector<unsigned short> Vs((size_t)P * 3 * KB * Mp * 16, 0), Us((size_t)P * 3 * KB * Np * 16, 0);
+    for (int p = 0; p < P; ++p)
+        for (int m = 0; m < Mt; ++m)
+            for (int k = 0; k < K; ++k) {
+                unsigned short t[3];
+                wino_s3_split_host(V[((size_t)(p % Pc) * Mt + m) * K + k], t);
+                for (int t3 = 0; t3 < 3; ++t3) Vs[((((size_t)p * 3 + t3) * KB + (k >> 4)) * Mp + m) * 16 + (k & 15)] = t[t3];
+            }
+    {
+        std::vector<float> Upad((size_t)P * Np * K, 0.0f);
+        for (int p = 0; p < P; ++p)
+            for (int n = 0; n < N; ++n)
+                for (int k = 0; k < K; ++k) Upad[((size_t)p * Np + n) * K + k] = U[((size_t)(p % Pc) * N + n) * K + k];
+        wino_s3_pack_weights(Upad.data(), P, Np, K, Us.data());
+    }
+    unsigned short *dV, *dU;
+    float *dC;
+    hipMalloc(&dV, Vs.size() * 2); hipMalloc(&dU, Us.size() * 2); hipMalloc(&dC, (size_t)P * Mt * N * 4);
+    hipMemcpy(dV, Vs.data(), Vs.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dU, Us.data(), Us.size() * 2, hipMemcpyHostToDevice);
+    hipMemset(dC, 0xff, (size_t)P * Mt * N * 4);
+    GemmS3Args a;
+    a.a = dV; a.b = dU; a.c = dC; a.c_ps = (long long)Mt * N; a.P = P; a.Mt = Mt; a.Mp = Mp; a.N = N; a.Np = Np; a.K = K; a.ldc = N;
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    int rc = launch_wino_gemm_s3(0, a, prop.multiProcessorCount);
+    if (rc || hipDeviceSynchronize() != hipSuccess) { printf("launch failed rc=%d %s\n", rc, hipGetErrorString(hipGetLastError())); exit(1); }
+    std::vector<float> C((size_t)P * Mt * N);
+    hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost);
+    // check: planes 0, 1 and the last; rows spread over the tile rows
+    double e_s3 = 0, e_f32 = 0, ref_rms = 0; long long cnt = 0; double worst = 0;
+    const int planes[3] = {0, 1 % P, P - 1};
+    for (int pi = 0; pi < 3; ++pi) {
+        const int p = planes[pi];
+        for (int r = 0; r < check_rows; ++r) {
+            const int m = (int)(((long long)r * 2654435761u) % Mt);
+            for (int n = 0; n < N; n += 7) {
+                const float *v = &V[((size_t)(p % Pc) * Mt + m) * K], *u = &U[((size_t)(p % Pc) * N + n) * K];
+                double ref = 0; float f = 0; double mag = 0;
+                for (int k = 0; k < K; ++k) { ref += (double)v[k] * (double)u[k]; f = fmaf(v[k], u[k], f); mag += fabs((double)v[k] * u[k]); }
+                const double got = C[((size_t)p * Mt + m) * N + n];
+                const double d = fabs(got - ref) / mag, d32 = fabs((double)f - ref) / mag;
+                e_s3 += d * d; e_f32 += d32 * d32; ref_rms += 1; ++cnt;
+                if (d > worst) worst = d;
+            }
+        }
+    }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) launch_wino_gemm_s3(0, a, prop.multiProcessorCount);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) launch_wino_gemm_s3(0, a, prop.multiProcessorCount);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= iters;
+    const double eq = 2.0 * P * (double)Mt * K * N / (ms * 1e-3) / 1e12;
+    printf("P=%d Mt=%d K=%d N=%d: %.3f ms  %.1f TF/s fp32-equivalent (%.0f executed bf16)  rel.err/|u||v|: s3 rms %.3g max %.3g, fp32 fmaf rms %.3g (%lld samples)\n",
+           P, Mt, K, N, ms, eq, eq * 6, sqrt(e_s3 / cnt), worst, sqrt(e_f32 / cnt), cnt);
+    hipFree(dV); hipFree(dU); hipFree(dC);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1) { run(64, 7840, 1024, 1024, 1, 5); run(64, 30240, 256, 512, 1, 5); run(64, 116640, 128, 256, 1, 3); return 0; }   // probes: timing only
+    run(4, 300, 64, 256, 64, 3);          // ragged Mt, short K
+    run(3, 700, 128, 128, 64, 3);         // BN = 128
+    run(64, 7840, 1024, 1024, 16, 5);     // conv_19 / conv_20 at 1440 frames (mosaic g = 3)
+    run(64, 7840, 512, 1024, 8, 5);       // conv_14 / 16 / 18
+    run(64, 30240, 256, 512, 8, 5);       // conv_9 / 11 / 13   (26x26: 21 tiles per frame)
+    run(64, 116640, 128, 256, 4, 3);      // conv_6 / conv_8   (52x52: 81 tiles per frame)
+    return 0;
+}
