@@ -34,7 +34,7 @@ typedef const __attribute__((address_space(1))) void s3_gptr_t;
 #define S3_BM 256
 #define S3_STAGES 3
 #ifndef S3_ABLATE
-#define S3_ABLATE 0      // probes (tools/micro/gemm_s3_bench.hip): 1 no DMA, 2 no operand reads, 4 no barrier
+#define S3_ABLATE 0      // probes (tools/micro/gemm_s3_bench.hip): 1 no DMA, 2 no operand reads, 4 no barrier, 8 DMA from one tile's panels only
 #endif
 
 template <int BN>
@@ -48,39 +48,53 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
     const int wm = wave & 3, wn = wave >> 2;
     const int KB = p.K >> 4;
     const int MT = (p.Mt + S3_BM - 1) / S3_BM, NT = p.N / BN;
-    const long long ntiles = (long long)p.P * MT * NT;
+    const int ntiles = p.P * MT * NT;              // < 2^31 (launcher)
     // XCD-aware order: workgroup w runs on XCD w % 8; each XCD walks a contiguous range of the n-fastest tile order, so
     // the 32 tiles resident on an XCD share their V / U panels through that XCD's L2
     const int G = gridDim.x;
-    const long long first = (G % 8 == 0) ? (long long)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int first = (G % 8 == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
 
     // ---- DMA geometry: wave w moves rows [32w, 32w+32) of every (operand, term) piece ----
     const int drow = 32 * wave + (lane >> 1);
     const int dgran = (lane & 1) ^ ((drow >> 3) & 1);           // source granule for LDS slot `lane`
     const long long a_term = (long long)KB * p.Mp * 16, b_term = (long long)KB * p.Np * 16;   // elements per term
     struct Tile { long long a0, b0; int m0, n0, pz; };
-    auto tile_of = [&](long long L) {
+    auto tile_of = [&](int L) {
         Tile t;
-        const int nt = (int)(L % NT);
-        const long long r = L / NT;
-        const int mt = (int)(r % MT);
-        t.pz = (int)(r / MT);
+        const int nt = L % NT;
+        const int r = L / NT;
+        const int mt = r % MT;
+        t.pz = r / MT;
         t.m0 = mt * S3_BM; t.n0 = nt * BN;
         t.a0 = (long long)t.pz * 3 * a_term + (long long)t.m0 * 16;
         t.b0 = (long long)t.pz * 3 * b_term + (long long)t.n0 * 16;
         return t;
     };
-    auto issue = [&](const Tile &t, int kb, int buf) {
+    // running DMA sources of this lane (term 0; the other terms sit a_term / b_term elements further): advanced by one
+    // K block per stage, recomputed when the issue cursor enters a new tile
+    const unsigned short *src_a = nullptr, *src_b = nullptr;
+    auto issue_src = [&](const Tile &t) {
+        src_b = p.b + ((S3_ABLATE & 8) ? 0 : t.b0) + (long long)drow * 16 + dgran * 8;       // probe 8: every tile streams the same panels (L2 hits only)
+        src_a = p.a + ((S3_ABLATE & 8) ? 0 : t.a0) + (long long)drow * 16 + dgran * 8;
+    };
+    // one stage = 6 pieces (term 0..2 x {U, V}); pieces [lo, hi) of the stage going to buffer `buf`
+    auto issue_pieces = [&](int buf, int lo, int hi) {
         if (S3_ABLATE & 1) return;
         unsigned char *dst = s3_lds + buf * STAGE + wave * 1024;
-        const unsigned short *bs = p.b + t.b0 + ((long long)kb * p.Np + drow) * 16 + dgran * 8;
-        const unsigned short *as = p.a + t.a0 + ((long long)kb * p.Mp + drow) * 16 + dgran * 8;
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) {
-            if (BN == 256 || wave < 4)
-                __builtin_amdgcn_global_load_lds((s3_gptr_t *)(bs + t3 * b_term), (s3_lptr_t *)(dst + t3 * BN * 32), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((s3_gptr_t *)(as + t3 * a_term), (s3_lptr_t *)(dst + OP_A + t3 * S3_BM * 32), 16, 0, 0);
+        for (int k = 0; k < 6; ++k) {
+            if (k < lo || k >= hi) continue;
+            const int t3 = k >> 1;
+            if (!(k & 1)) {
+                if (BN == 256 || wave < 4)
+                    __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_b + t3 * b_term), (s3_lptr_t *)(dst + t3 * BN * 32), 16, 0, 0);
+            } else
+                __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_a + t3 * a_term), (s3_lptr_t *)(dst + OP_A + t3 * S3_BM * 32), 16, 0, 0);
         }
+    };
+    auto issue_done = [&]() {
+        src_b += (long long)p.Np * 16;
+        src_a += (long long)p.Mp * 16;
     };
     // ---- operand read offsets (bytes inside a stage) ----
     const int rl = lane & 31, gl = lane >> 5;
@@ -97,19 +111,77 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
     }
 
     if (first >= ntiles) return;
-    Tile cur = tile_of(first);
-    long long Lnext = first + G;
+    // Two cursors walk this workgroup's sequence of (tile, k stage): `iss` three stages ahead (DMA), the compute cursor behind it.
+    struct Cursor { Tile t; int kb; int L; bool valid; };
+    auto advance = [&](Cursor &c) {
+        if (++c.kb == KB) {
+            c.kb = 0; c.L += G;
+            c.valid = c.L < ntiles;
+            if (c.valid) { c.t = tile_of(c.L); issue_src(c.t); }
+        }
+    };
+    Cursor iss;
+    iss.t = tile_of(first); iss.kb = 0; iss.L = first; iss.valid = true;
+    issue_src(iss.t);
+    Tile cur = iss.t;
+    int Lcur = first;
+    int n_ahead = 0;          // stages issued and not yet consumed
     int buf_issue = 0, buf_use = 0;
-    // prologue: stages 0 and 1 of the first tile
-    issue(cur, 0, 0);
-    if (KB > 1) issue(cur, 1, 1);
-    buf_issue = KB > 1 ? 2 : 1;
-    bool drain = false;       // the previous iteration issued global stores: wait for everything
+    auto issue_next = [&]() {            // a whole stage at once (prologue)
+        if (!iss.valid) return;
+        issue_pieces(buf_issue, 0, 6);
+        issue_done();
+        buf_issue = buf_issue == S3_STAGES - 1 ? 0 : buf_issue + 1;
+        ++n_ahead;
+        advance(iss);
+    };
+    // In the steady state a stage's six pieces are spread over the NBW MFMA groups that follow the barrier which frees
+    // its buffer: 48 DMA instructions issued by all eight waves at once queue up in the texture addresser and hold the
+    // issuing waves (and with them the MFMA pipe) for ~400 cycles per stage.
+    bool iss_go = false;       // a stage is being issued piecewise
+    int iss_buf = 0;
+    auto frag = [&](const unsigned char *sb, int off) {
+        if (S3_ABLATE & 2) {
+            typedef int s3_i4 __attribute__((ext_vector_type(4)));
+            const s3_i4 x = {0x3f803f80 + (off & 1), 0x3f803f80 + (lane & 1), 0x3f003f80, 0x3f803f00 + (int)(sb - s3_lds)};
+            return __builtin_bit_cast(s3_bf8, x);
+        }
+        return *reinterpret_cast<const s3_bf8 *>(sb + off);
+    };
+    // wait until at most `keep` of this wave's DMA stages are still in flight (each stage: 6 pieces, or 3 for the
+    // waves that move no U rows when BN = 128)
+    auto wait_dma = [&](int keep) {
+        if (keep <= 0) __builtin_amdgcn_s_waitcnt(0x0f70);                              // vmcnt(0)
+        else if (keep == 1) {
+            if (BN == 256 || wave < 4) __builtin_amdgcn_s_waitcnt(0x0f76);              // vmcnt(6)
+            else __builtin_amdgcn_s_waitcnt(0x0f73);                                    // vmcnt(3)
+        } else {
+            if (BN == 256 || wave < 4) __builtin_amdgcn_s_waitcnt(0x0f7c);              // vmcnt(12)
+            else __builtin_amdgcn_s_waitcnt(0x0f76);                                    // vmcnt(6)
+        }
+    };
+
+    // prologue: three stages in flight, the first one's leading fragments in registers
+    issue_next(); issue_next(); issue_next();
+    wait_dma(n_ahead - 1);
+    if (!(S3_ABLATE & 4)) __builtin_amdgcn_s_barrier();
+    s3_bf8 v[2][3], vn[2][3], ua[3], ub[3];
+    {
+        const unsigned char *sb = s3_lds;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = frag(sb, offV[i] + t3 * S3_BM * 32);
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) ua[t3] = frag(sb, offU[0] + t3 * BN * 32);
+    }
+    bool drain = false;       // global stores were issued since the last full wait
+#ifdef S3_TIMING
+    unsigned long long tm_lgkm = 0, tm_vm = 0, tm_bar = 0, tm_n = 0;
+    const unsigned long long tm_start = __builtin_readcyclecounter();
+#endif
 
     for (;;) {
-        const bool has_next = Lnext < ntiles;
-        Tile nxt = cur;
-        if (has_next) nxt = tile_of(Lnext);
         s3_f16 acc[NBW][2];
 #pragma unroll
         for (int j = 0; j < NBW; ++j)
@@ -120,44 +192,65 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
 
 #pragma unroll 1
         for (int kb = 0; kb < KB; ++kb) {
-            // stage kb of this tile has landed (the one after it may still be in flight)
-            const bool more_in_flight = (kb + 1 < KB) || has_next;
-            if (drain || !more_in_flight) __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0)
-            else if (BN == 256 || wave < 4) __builtin_amdgcn_s_waitcnt(0x0f76);                    // vmcnt(6)
-            else __builtin_amdgcn_s_waitcnt(0x0f73);                                               // vmcnt(3)
-            drain = false;
-            if (!(S3_ABLATE & 4)) __builtin_amdgcn_s_barrier();   // (no fence: a release fence would wait for the DMA pieces in flight) everyone's pieces of stage kb are in LDS; everyone is done with the buffer two stages back
-            // refill the buffer that was read in the previous iteration
-            {
-                const int k2 = kb + 2;
-                if (k2 < KB) issue(cur, k2, buf_issue);
-                else if (has_next && k2 - KB < KB) issue(nxt, k2 - KB, buf_issue);
-                if (k2 < KB || (has_next && k2 - KB < KB)) buf_issue = buf_issue == S3_STAGES - 1 ? 0 : buf_issue + 1;
-            }
-            const unsigned char *sb = s3_lds + ((S3_ABLATE & 2) ? 0 : buf_use * STAGE);
+            const unsigned char *sb = s3_lds + buf_use * STAGE;
             buf_use = buf_use == S3_STAGES - 1 ? 0 : buf_use + 1;
-            auto frag = [&](int off) {
-                if (S3_ABLATE & 2) {
-                    typedef int s3_i4 __attribute__((ext_vector_type(4)));
-                    const s3_i4 x = {0x3f803f80 + (off & 1), 0x3f803f80 + (lane & 1), 0x3f003f80, 0x3f803f00 + kb};
-                    return __builtin_bit_cast(s3_bf8, x);
-                }
-                return *reinterpret_cast<const s3_bf8 *>(sb + off);
-            };
-            s3_bf8 v[2][3];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = frag(offV[i] + t3 * S3_BM * 32);
+            const unsigned char *sn = s3_lds + buf_use * STAGE;          // the stage after this one
 #pragma unroll
             for (int j = 0; j < NBW; ++j) {
-                s3_bf8 u[3];
+                const s3_bf8 *u = (j & 1) ? ub : ua;
+                if (j == NBW - 1) {
+                    // every read of this stage has been issued: once they are back the buffer can be refilled.  The
+                    // stage after this one must have landed before its first fragments are read below.
+#ifdef S3_TIMING
+                    const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
+                    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
+#ifdef S3_TIMING
+                    const unsigned long long t1 = __builtin_readcyclecounter();
+#endif
+                    --n_ahead;                                           // this stage is consumed
+                    wait_dma(drain ? 0 : n_ahead - 1);
+                    drain = false;
+#ifdef S3_TIMING
+                    const unsigned long long t2 = __builtin_readcyclecounter();
+#endif
+                    if (!(S3_ABLATE & 4)) __builtin_amdgcn_s_barrier();  // (no fence: a release fence would wait for the DMA in flight)
+#ifdef S3_TIMING
+                    const unsigned long long t3 = __builtin_readcyclecounter();
+                    tm_lgkm += t1 - t0; tm_vm += t2 - t1; tm_bar += t3 - t2; ++tm_n;
+#endif
+                }
+                // the group's first MFMA goes ahead of the loads for the NEXT group: the wait the compiler puts in front of
+                // it (for this group's fragments, read one group ago) then does not cover those fresh loads
+                s3_f16 c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[2], v[0][0], acc[j][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == NBW - 1) {
+                    iss_go = iss.valid;                                  // refill the buffer this stage occupied, piecewise from here on
+                    iss_buf = buf_issue;
+                    if (iss_go) { buf_issue = buf_issue == S3_STAGES - 1 ? 0 : buf_issue + 1; ++n_ahead; }
 #pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) u[t3] = frag(offU[j] + t3 * BN * 32);
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int t3 = 0; t3 < 3; ++t3) vn[i][t3] = frag(sn, offV[i] + t3 * S3_BM * 32);
+#pragma unroll
+                    for (int t3 = 0; t3 < 3; ++t3) (j & 1 ? ua : ub)[t3] = frag(sn, offU[0] + t3 * BN * 32);
+                } else {
+#pragma unroll
+                    for (int t3 = 0; t3 < 3; ++t3) (j & 1 ? ua : ub)[t3] = frag(sb, offU[j + 1] + t3 * BN * 32);
+                }
+                {
+                    const int g = (j + 1) % NBW;                         // groups since the barrier: 0 = the barrier's own group
+                    constexpr int per = NBW == 4 ? 2 : 3, ng = 6 / per;  // pieces per group, groups that carry pieces
+                    if (g < ng && iss_go) {
+                        issue_pieces(iss_buf, g * per, g * per + per);
+                        if (g == ng - 1) { issue_done(); advance(iss); iss_go = false; }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    s3_f16 c = acc[j][i];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[2], v[i][0], c, 0, 0, 0);
+                    s3_f16 c = i == 0 ? c0 : acc[j][i];
+                    if (i != 0) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[2], v[i][0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[1], v[i][1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[0], v[i][2], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[1], v[i][0], c, 0, 0, 0);
@@ -165,9 +258,13 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[0], v[i][0], c, 0, 0, 0);
                     acc[j][i] = c;
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = vn[i][t3];
         }
-        // a tile with KB == 1 leaves the ring one stage ahead only: handled by the generic wait logic above
 
         // ---- epilogue: lane holds, per block, n = n0 + 8q + 4*(lane>>5) + (0..3) of row m = m0 + (lane & 31) ----
         float *cz = p.c + (long long)cur.pz * p.c_ps;
@@ -186,10 +283,16 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
                     }
             }
         }
-        if (!has_next) break;
+        Lcur += G;
+#ifdef S3_TIMING
+        if (Lcur >= ntiles && lane == 0 && p.dbg) {
+            unsigned long long *d = p.dbg + ((long long)blockIdx.x * 8 + wave) * 5;
+            d[0] = tm_lgkm; d[1] = tm_vm; d[2] = tm_bar; d[3] = tm_n; d[4] = __builtin_readcyclecounter() - tm_start;
+        }
+#endif
+        if (Lcur >= ntiles) break;
         drain = true;
-        cur = nxt;
-        Lnext += G;
+        cur = tile_of(Lcur);
     }
 }
 
@@ -219,6 +322,7 @@ int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
         attr128.done();
     }
     const long long tiles = (long long)a.P * ((a.Mt + S3_BM - 1) / S3_BM) * (a.N / BN);
+    if (tiles >= (1ll << 31) - 65536) return 2;
     if (cus <= 0) {
         static int cu_of[64];
         static PerDeviceOnce once;

@@ -45,8 +45,13 @@ static void run(int P, int Mt, int K, int N, int check_rows, int iters)
     hipMemset(dC, 0xff, (size_t)P * Mt * N * 4);
     GemmS3Args a;
     a.a = dV; a.b = dU; a.c = dC; a.c_ps = (long long)Mt * N; a.P = P; a.Mt = Mt; a.Mp = Mp; a.N = N; a.Np = Np; a.K = K; a.ldc = N;
+    a.dbg = nullptr;
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
+#ifdef S3_TIMING
+    hipMalloc(&a.dbg, 256 * 8 * 5 * 8);
+    hipMemset(a.dbg, 0, 256 * 8 * 5 * 8);
+#endif
     int rc = launch_wino_gemm_s3(0, a, prop.multiProcessorCount);
     if (rc || hipDeviceSynchronize() != hipSuccess) { printf("launch failed rc=%d %s\n", rc, hipGetErrorString(hipGetLastError())); exit(1); }
     std::vector<float> C((size_t)P * Mt * N);
@@ -82,11 +87,23 @@ static void run(int P, int Mt, int K, int N, int check_rows, int iters)
     const double eq = 2.0 * P * (double)Mt * K * N / (ms * 1e-3) / 1e12;
     printf("P=%d Mt=%d K=%d N=%d: %.3f ms  %.1f TF/s fp32-equivalent (%.0f executed bf16)  rel.err/|u||v|: s3 rms %.3g max %.3g, fp32 fmaf rms %.3g (%lld samples)\n",
            P, Mt, K, N, ms, eq, eq * 6, sqrt(e_s3 / cnt), worst, sqrt(e_f32 / cnt), cnt);
+#ifdef S3_TIMING
+    {
+        std::vector<unsigned long long> h(256 * 8 * 5);
+        hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        double s[5] = {0, 0, 0, 0, 0}; int n = 0;
+        for (int w = 0; w < 256 * 8; ++w) if (h[w * 5 + 3]) { for (int k = 0; k < 5; ++k) s[k] += (double)h[w * 5 + k]; ++n; }
+        if (n) printf("   timing (mean per wave over %d waves, clock64 ticks): total %.0f; per stage: lgkm wait %.1f, DMA wait %.1f, barrier %.1f, whole stage %.1f (%0.f stages)\n",
+                      n, s[4] / n, s[0] / s[3], s[1] / s[3], s[2] / s[3], s[4] / s[3], s[3] / n);
+        hipFree(a.dbg);
+    }
+#endif
     hipFree(dV); hipFree(dU); hipFree(dC);
 }
 
 int main(int argc, char **argv)
 {
+    if (argc > 1 && argv[1][0] == '2') { run(64, 7840, 1024, 1024, 1, 5); return 0; }      // PMC runs: one shape
     if (argc > 1) { run(64, 7840, 1024, 1024, 1, 5); run(64, 30240, 256, 512, 1, 5); run(64, 116640, 128, 256, 1, 3); return 0; }   // probes: timing only
     run(4, 300, 64, 256, 64, 3);          // ragged Mt, short K
     run(3, 700, 128, 128, 64, 3);         // BN = 128
