@@ -49,6 +49,7 @@ from parallel import gather_detections, init_from_env, track_clips_frame_sharded
 from utility import synth
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense (16x the fp32 MFMA rate)
 PEAK_HBM_GBS = 8000.0
 GFLOP_TRACK_416 = 39.460          # 29.346 detect (C=12) + 10.099 ConvLSTM + 0.015 1x1
 GFLOP_DETECT_416_C80 = 29.464
@@ -224,7 +225,7 @@ def tiny_extra(device, H, W, seqs, steps=3):
 
 
 def load_traffic(clips, T, size):
-    """PMC-derived bytes per conv_igemm launch for this exact workload, measured
+    """PMC-derived bytes per launch of the dominant GEMM kernel for this exact workload, measured
     with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over
     tools/pmc_probe.py and committed under profiles/ (tools/make_traffic_json.py).
     bench.py cannot collect hardware counters itself; returns None if no
@@ -395,7 +396,7 @@ def _run():
         elapsed = float(tmax.item())
 
     kern = {}
-    for name in ("conv_igemm", "conv_fused", "wino_input", "wino_output", "conv1_direct", "convlstm_gates", "decode_nms", "associate", "splitk_reduce", "pool",
+    for name in ("conv_gemm_s3", "conv_igemm", "conv_fused", "wino_input", "wino_output", "conv1_direct", "convlstm_gates", "decode_nms", "associate", "splitk_reduce", "pool",
                  "lstm_step", "misc"):
         p = ctx.profile_read(name)
         if p["launches"]:
@@ -403,7 +404,12 @@ def _run():
                               tflops=(p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["ms"] > 0 else None,
                               gbs=(p["bytes"] / (p["ms"] * 1e-3) / 1e9) if p["ms"] > 0 else None)
     ig = ctx.profile_read("conv_igemm")
-    achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+    achieved_f32 = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+    # the F(6x6) layers' batched GEMMs: bf16 MFMAs on 3-term split fp32 operands (six partial products per multiply);
+    # flops = EXECUTED bf16 FLOPs, so /6 is the fp32 multiply-add rate the layer sees
+    s3 = ctx.profile_read("conv_gemm_s3")
+    achieved_s3 = s3["flops"] / (s3["ms"] * 1e-3) / 1e12 if s3["ms"] > 0 else 0.0
+    dominant_s3 = s3["ms"] >= ig["ms"]
     # direct-form FLOPs (SURVEY.md 8d figures) of the layers those launches computed; > executed where the
     # wide 3x3 layers run in Winograd form.  Time base: the MFMA kernel alone / with its transform kernels.
     direct_form = ctx.profile_read("conv_direct_form")["flops"]
@@ -415,8 +421,12 @@ def _run():
     direct_form_fused = ctx.profile_read("conv_direct_form_fused")["flops"]
     # whole conv path: every MFMA FLOP the conv kernels execute (batched / direct GEMMs, the fused Winograd kernels,
     # conv_1) over ALL the time the conv path takes (those kernels + the Winograd transform kernels)
-    conv_path_ms = ig["ms"] + fused["ms"] + conv1["ms"] + wino_ms
-    conv_path_flops = ig["flops"] + fused["flops"] + conv1["flops"]
+    conv_path_ms = s3["ms"] + ig["ms"] + fused["ms"] + conv1["ms"] + wino_ms
+    conv_path_flops = ig["flops"] + fused["flops"] + conv1["flops"]        # executed on the fp32 MFMA instructions
+    # time the matrix pipe would need at its peaks for everything the conv path executes (bf16 and fp32 instructions
+    # have different peaks) / the time the conv path takes, transforms included
+    conv_path_pipe_frac = ((s3["flops"] / (PEAK_BF16_MFMA_TFLOPS * 1e12) + conv_path_flops / (PEAK_F32_MFMA_TFLOPS * 1e12)) /
+                           (conv_path_ms * 1e-3)) if conv_path_ms > 0 else None
     # split the family's launches by arithmetic intensity (executed FLOP per algorithmic byte): below the ridge
     # of the chip (157.3 TFLOP/s over ~6.3 TB/s achievable = 25 FLOP/B; 40 used as the class boundary) a launch is
     # HBM-bound whatever the kernel does, and is priced against the HBM roof instead
@@ -429,6 +439,15 @@ def _run():
             continue
         r = regimes["mfma" if p["flops"] / p["bytes"] >= 40.0 else "hbm"]
         r[0] += p["flops"]; r[1] += p["bytes"]; r[2] += p["ms"]; r[3].append(name.split(":", 1)[1])
+    s3_layers = {}
+    for name in ctx.profile_names():
+        if name.startswith("conv_gemm_s3:"):
+            p = ctx.profile_read(name)
+            if p["ms"] > 0:
+                s3_layers[name.split(":", 1)[1]] = {"ms_per_step": p["ms"] / args.steps,
+                                                    "executed_bf16_tflops": p["flops"] / (p["ms"] * 1e-3) / 1e12,
+                                                    "fp32_equivalent_tflops": p["flops"] / 6.0 / (p["ms"] * 1e-3) / 1e12,
+                                                    "algorithmic_GBps": p["bytes"] / (p["ms"] * 1e-3) / 1e9}
     boxes_per_frame = None
     if args.workload == "track" and res is not None and isinstance(res, dict):
         boxes_per_frame = float(res["counts"].float().mean().item())
@@ -454,6 +473,10 @@ def _run():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong" if (args.workload == "tiny" or (args.workload == "track" and args.shard == "frame" and world > 1)) else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_detail": ("fp32 storage, fp32 accumulation everywhere; the F(6x6,3x3) layers' GEMMs form each fp32 product from six bf16 MFMA "
+                             "partial products of 3-term split operands (x = x1 + x2 + x3, exact to 2^-25 |x|): error against float64 no "
+                             "larger than the fp32 MFMA path's (DT_S3=0), which the parity tests assert") if s3["ms"] > 0 else
+                            "fp32 storage, fp32 MFMA arithmetic, fp32 accumulation",
             "config": {"workload": ("BASELINE.json configs[2]: MultiObjDetTracker (YOLOv2 C=12 + ConvLSTM2D(512) + 1x1 "
                                     "+ decode/NMS + track ids), %d clips x %d frames per GPU per step, %dx%d uint8"
                                     % (args.clips, args.T, H, W)) if args.workload == "track" else
@@ -468,15 +491,36 @@ def _run():
             "whole_path_tflops": fps * gflop_per_frame / 1e3, "h2d_included": bool(args.h2d),
             "ranks_seen": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
             "exchange_bytes_received_per_step_rank0": int(xstats.get("bytes_received", 0)),
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32 implicit GEMM)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "frac_executed": achieved / PEAK_F32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma",
+                         "kernel": ("wino_gemm_s3_kernel (v_mfma_f32_32x32x16_bf16 on 3-term split fp32 operands: six bf16 products per "
+                                    "fp32 multiply, fp32 accumulate -- the F(6x6,3x3) layers' batched GEMMs)") if dominant_s3 else
+                                   "conv_igemm_f32 (v_mfma_f32_32x32x2_f32 implicit GEMM)",
+                         "achieved": achieved_s3 if dominant_s3 else achieved_f32,
+                         "peak": PEAK_BF16_MFMA_TFLOPS if dominant_s3 else PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (achieved_s3 / PEAK_BF16_MFMA_TFLOPS) if dominant_s3 else (achieved_f32 / PEAK_F32_MFMA_TFLOPS),
+                         "dominant_kernel_ms_per_step": (s3["ms"] if dominant_s3 else ig["ms"]) / max(1, args.steps),
+                         "split_bf16_gemm": None if s3["ms"] <= 0 else {
+                             "executed_bf16_tflops": achieved_s3, "peak_bf16_tflops": PEAK_BF16_MFMA_TFLOPS,
+                             "frac": achieved_s3 / PEAK_BF16_MFMA_TFLOPS,
+                             "fp32_equivalent_tflops": achieved_s3 / 6.0,
+                             "fp32_equivalent_over_fp32_mfma_peak": achieved_s3 / 6.0 / PEAK_F32_MFMA_TFLOPS,
+                             "ms_per_step": s3["ms"] / max(1, args.steps), "launches_per_step": s3["launches"] / max(1, args.steps),
+                             "avg_launch_ms": s3["ms"] / max(1, s3["launches"]),
+                             "executed_gflop_per_launch": s3["flops"] / max(1, s3["launches"]) / 1e9,
+                             "algorithmic_bytes_per_launch": s3["bytes"] / max(1, s3["launches"]),
+                             "layers": s3_layers},
+                         "fp32_mfma_kernel": {"kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)", "achieved": achieved_f32,
+                                              "peak": PEAK_F32_MFMA_TFLOPS, "frac": achieved_f32 / PEAK_F32_MFMA_TFLOPS,
+                                              "ms_per_step": ig["ms"] / max(1, args.steps)},
+                         "frac_executed": achieved_f32 / PEAK_F32_MFMA_TFLOPS,
                          # the transform kernels exist only because of the Winograd form: charge them to the conv path
                          "frac_incl_transforms": (ig["flops"] / ((ig["ms"] + wino_ms) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)
                          if ig["ms"] > 0 else None,
-                         "frac_whole_conv_path": (conv_path_flops / (conv_path_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)
-                         if conv_path_ms > 0 else None,
-                         "whole_conv_path": {"executed_tflop_per_step": conv_path_flops / max(1, args.steps) / 1e12,
+                         "frac_whole_conv_path": conv_path_pipe_frac,
+                         "whole_conv_path": {"executed_fp32_mfma_tflop_per_step": conv_path_flops / max(1, args.steps) / 1e12,
+                                             "executed_bf16_mfma_tflop_per_step": s3["flops"] / max(1, args.steps) / 1e12,
+                                             "fp32_equivalent_tflops": ((conv_path_flops + s3["flops"] / 6.0) / (conv_path_ms * 1e-3) / 1e12)
+                                             if conv_path_ms > 0 else None,
                                              "ms_per_step": conv_path_ms / max(1, args.steps),
                                              "direct_form_tflop_per_step": (direct_form + direct_form_fused + conv1["flops"]) / max(1, args.steps) / 1e12},
                          "transform_ms_per_step": wino_ms / max(1, args.steps),
@@ -484,7 +528,7 @@ def _run():
                          # reference's layers need (in + W + out, fp32) vs the bytes this implementation's kernels
                          # move by their own algorithmic count (V + U + M' for the GEMMs, the transforms' reads+writes)
                          "direct_form_bytes_per_step": direct_form_bytes / max(1, args.steps),
-                         "implementation_bytes_per_step": (ig["bytes"] + wino_in["bytes"] + wino_out["bytes"] + fused["bytes"]) / max(1, args.steps),
+                         "implementation_bytes_per_step": (s3["bytes"] + ig["bytes"] + wino_in["bytes"] + wino_out["bytes"] + fused["bytes"]) / max(1, args.steps),
                          "traffic": None, "traffic_per_step": None,
                          "launches_per_step": ig["launches"] / max(1, args.steps),
                          "avg_launch_ms": ig["ms"] / max(1, ig["launches"]),
@@ -503,8 +547,18 @@ def _run():
                              "achieved_GBps": regimes["hbm"][1] / (regimes["hbm"][2] * 1e-3) / 1e9,
                              "frac_of_8TBps": regimes["hbm"][1] / (regimes["hbm"][2] * 1e-3) / 8e12,
                              "executed_tflops": regimes["hbm"][0] / (regimes["hbm"][2] * 1e-3) / 1e12},
-                         "note": "achieved/frac = MFMA FLOPs the kernel EXECUTES / its HIP-event time (pipe utilisation, "
-                                 "<= 1). The 3x3 layers from conv_3 up and both ConvLSTM convolutions run in Winograd "
+                         "note": "achieved/frac = MFMA FLOPs the DOMINANT kernel executes / its HIP-event time, against the dense "
+                                 "peak of the instruction it issues (pipe utilisation, <= 1). With the default policy the dominant "
+                                 "kernel is wino_gemm_s3_kernel: the F(6x6,3x3) layers' GEMMs carry every fp32 operand as three bf16 "
+                                 "terms and form each product from six bf16 MFMA partial products with fp32 accumulation -- fp32 "
+                                 "accuracy (tests/test_gpu_parity.py::test_split_bf16_gemm_error_against_float64) at 16/6 of the "
+                                 "fp32 MFMA rate; split_bf16_gemm.fp32_equivalent_tflops = executed / 6 is what the layer sees "
+                                 "(DT_S3=0 runs the same GEMMs on v_mfma_f32_32x32x2_f32: fp32_mfma_kernel). "
+                                 "launches_per_step .. achieved_algorithmic and the mfma_/hbm_bound split below describe the fp32 "
+                                 "kernel family (conv_igemm_f32: 1x1 layers, short-K Winograd GEMMs, recurrent step). "
+                                 "frac_whole_conv_path = time the matrix pipe needs at its peaks for everything the conv path "
+                                 "executes (bf16 FLOPs / 2500 + fp32 FLOPs / 157.3) / the conv path's time incl. transforms. "
+                                 "The 3x3 layers from conv_3 up and both ConvLSTM convolutions run in Winograd "
                                  "form (F(6x6,3x3): 64 batched GEMMs through the same kernel; F(4x4,3x3) for the recurrent "
                                  "step), which executes up to 5x fewer FLOPs than the direct form SURVEY.md 8d counts; "
                                  "achieved_algorithmic = direct-form FLOPs of the layers THESE launches computed (layers run "

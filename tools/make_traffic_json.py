@@ -37,12 +37,14 @@ def main():
     cal_w = [v for _, k, v in write if "distribution" in k and v > 100000][0]     # 1 GiB written
     f_read = GIB / (cal_r * 1024.0)
     f_write = GIB / (cal_w * 1024.0)
-    fam = lambda k: k.startswith("void conv_igemm_f32")
+    fam = lambda k: k.startswith("void wino_gemm_s3_kernel")        # the dominant kernel (bench.py roofline.kernel)
+    if not [1 for _, k, _v in fetch if fam(k)]:
+        fam = lambda k: k.startswith("void conv_igemm_f32")        # DT_S3=0 runs
     fr = [v for _, k, v in fetch if fam(k)]
     wr = [v for _, k, v in write if fam(k)]
     out = {
         "workload": {"clips": clips, "T": 30, "size": 416},
-        "kernel_family": "conv_igemm_f32",
+        "kernel_family": "wino_gemm_s3_kernel" if any(k.startswith("void wino_gemm_s3_kernel") for _, k, _v in fetch) else "conv_igemm_f32",
         "launches_sampled": len(fr),
         "read_calibration_factor": f_read, "write_calibration_factor": f_write,
         "fetch_bytes_per_launch": sum(fr) * 1024.0 * f_read / len(fr),
@@ -55,7 +57,7 @@ def main():
     out["traffic_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
     # the whole conv family of ONE step (the probe runs the path twice: head calibration + the measured step):
     # MFMA GEMMs + Winograd transforms + the fused conv_2 / conv_3 / conv_5 kernels (conv_1 is listed separately: it was never part of this sum)
-    fam2 = lambda k: any(t in k for t in ("conv_igemm_f32", "wino_input_kernel", "wino_output", "wino2_fused", "wino4_fused", "wino4s_fused", "splitk_reduce"))
+    fam2 = lambda k: any(t in k for t in ("wino_gemm_s3_kernel", "conv_igemm_f32", "wino_input", "wino_output", "wino2_fused", "wino4_fused", "wino4s_fused", "splitk_reduce"))
     passes = 2.0
     out["conv_family_fetch_bytes_per_step"] = sum(v for _, k, v in fetch if fam2(k)) * 1024.0 * f_read / passes
     out["conv_family_write_bytes_per_step"] = sum(v for _, k, v in write if fam2(k)) * 1024.0 * f_write / passes
