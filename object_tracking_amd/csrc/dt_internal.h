@@ -160,6 +160,7 @@ struct GemmS3Args {
     float *c;                  // M'       [P] planes of [Mt][ldc], plane stride c_ps floats
     long long c_ps;
     int P, Mt, Mp, N, Np, K, ldc;
+    int waves;                 // 8 / 4 waves per workgroup (64 x BN/2 or 128 x BN/2 per wave); 0 = the default (Policy::s3_waves)
     unsigned long long *dbg;   // -DS3_TIMING builds of the micro-benchmark only: per-wave wait cycles; otherwise null
 };
 int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus);

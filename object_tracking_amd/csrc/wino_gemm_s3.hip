@@ -33,19 +33,36 @@ typedef const __attribute__((address_space(1))) void s3_gptr_t;
 #define S3_THREADS 512
 #define S3_BM 256
 #define S3_STAGES 3
+#ifndef S3_DEFAULT_WAVES
+#define S3_DEFAULT_WAVES 8
+#endif
 #ifndef S3_ABLATE
 #define S3_ABLATE 0      // probes (tools/micro/gemm_s3_bench.hip): 1 no DMA, 2 no operand reads, 4 no barrier, 8 DMA from one tile's panels only
 #endif
 
-template <int BN>
-__global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
+// vmcnt(N) alone (expcnt / lgkmcnt at their "don't wait" values); N < 64
+template <int N>
+__device__ __forceinline__ void s3_wait_vm() { __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14)); }
+
+// NW waves per workgroup: 8 = 4 (m) x 2 (n) waves of 64 x BN/2 at two waves per SIMD (<= 256 registers each);
+//                         4 = 2 x 2 waves of 128 x BN/2, one wave per SIMD with the whole 512-entry register file: a third
+//                             fewer LDS fragment reads per MFMA (0.25 instead of 0.375 ds_read_b128) -- the reads are what
+//                             pulls the clock down (tools/s3_clock.sh: 2.26 GHz without them, 1.70 GHz with)
+template <int BN, int NW>
+__global__ __launch_bounds__(NW * 64) void wino_gemm_s3_kernel(GemmS3Args p)
 {
+    constexpr int WM = NW / 2;                        // waves along m (two along n)
+    constexpr int MB = S3_BM / (WM * 32);             // 32-high m blocks per wave
     constexpr int NBW = BN / 64;                      // 32-wide n blocks per wave (BN/2 columns)
+    constexpr int PV = 8 / NW;                        // 32-row DMA pieces of a 256-row V region per wave
+    constexpr int PU = (BN / 32) / NW > 0 ? (BN / 32) / NW : 1;   // ... of a BN-row U region (BN = 128, NW = 8: waves 0..3 only)
+    constexpr bool U_HALF = (BN / 32) < NW;           // only the first BN / 32 waves move U rows
+    constexpr int PT = 3 * (PU + PV);                 // DMA instructions per wave per stage
     constexpr int OP_A = 3 * BN * 32;                 // bytes of U terms per stage
     constexpr int STAGE = OP_A + 3 * S3_BM * 32;      // + V terms
     extern __shared__ __attribute__((aligned(16))) unsigned char s3_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = wave % WM, wn = wave / WM;
     const int KB = p.K >> 4;
     const int MT = (p.Mt + S3_BM - 1) / S3_BM, NT = p.N / BN;
     const int ntiles = p.P * MT * NT;              // < 2^31 (launcher)
@@ -54,9 +71,9 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
     const int G = gridDim.x;
     const int first = (G % 8 == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
 
-    // ---- DMA geometry: wave w moves rows [32w, 32w+32) of every (operand, term) piece ----
-    const int drow = 32 * wave + (lane >> 1);
-    const int dgran = (lane & 1) ^ ((drow >> 3) & 1);           // source granule for LDS slot `lane`
+    // ---- DMA geometry: wave w moves PV (PU) pieces of 32 rows of every V (U) term region; lane = LDS slot inside a piece ----
+    const int lrow = lane >> 1;
+    const int dgran = (lane & 1) ^ ((lrow >> 3) & 1);           // source granule for LDS slot `lane` (32-row pieces: the row's bit 3 is the lane's)
     const long long a_term = (long long)KB * p.Mp * 16, b_term = (long long)KB * p.Np * 16;   // elements per term
     struct Tile { long long a0, b0; int m0, n0, pz; };
     auto tile_of = [&](int L) {
@@ -74,22 +91,26 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
     // K block per stage, recomputed when the issue cursor enters a new tile
     const unsigned short *src_a = nullptr, *src_b = nullptr;
     auto issue_src = [&](const Tile &t) {
-        src_b = p.b + ((S3_ABLATE & 8) ? 0 : t.b0) + (long long)drow * 16 + dgran * 8;       // probe 8: every tile streams the same panels (L2 hits only)
-        src_a = p.a + ((S3_ABLATE & 8) ? 0 : t.a0) + (long long)drow * 16 + dgran * 8;
+        src_b = p.b + ((S3_ABLATE & 8) ? 0 : t.b0) + (long long)(32 * PU * wave + lrow) * 16 + dgran * 8;   // probe 8: every tile streams the same panels (L2 hits only)
+        src_a = p.a + ((S3_ABLATE & 8) ? 0 : t.a0) + (long long)(32 * PV * wave + lrow) * 16 + dgran * 8;
     };
-    // one stage = 6 pieces (term 0..2 x {U, V}); pieces [lo, hi) of the stage going to buffer `buf`
+    // one stage = PT pieces per wave (term 0..2 x {U x PU, V x PV}); pieces [lo, hi) of the stage going to buffer `buf`
     auto issue_pieces = [&](int buf, int lo, int hi) {
         if (S3_ABLATE & 1) return;
-        unsigned char *dst = s3_lds + buf * STAGE + wave * 1024;
+        unsigned char *dst = s3_lds + buf * STAGE;
+        int k = 0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            if (k < lo || k >= hi) continue;
-            const int t3 = k >> 1;
-            if (!(k & 1)) {
-                if (BN == 256 || wave < 4)
-                    __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_b + t3 * b_term), (s3_lptr_t *)(dst + t3 * BN * 32), 16, 0, 0);
-            } else
-                __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_a + t3 * a_term), (s3_lptr_t *)(dst + OP_A + t3 * S3_BM * 32), 16, 0, 0);
+        for (int t3 = 0; t3 < 3; ++t3) {
+#pragma unroll
+            for (int sp = 0; sp < PU; ++sp, ++k)
+                if (k >= lo && k < hi && (!U_HALF || wave < BN / 32))
+                    __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_b + t3 * b_term + sp * 512),
+                                                     (s3_lptr_t *)(dst + t3 * BN * 32 + (wave * PU + sp) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int sp = 0; sp < PV; ++sp, ++k)
+                if (k >= lo && k < hi)
+                    __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_a + t3 * a_term + sp * 512),
+                                                     (s3_lptr_t *)(dst + OP_A + t3 * S3_BM * 32 + (wave * PV + sp) * 1024), 16, 0, 0);
         }
     };
     auto issue_done = [&]() {
@@ -98,15 +119,15 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
     };
     // ---- operand read offsets (bytes inside a stage) ----
     const int rl = lane & 31, gl = lane >> 5;
-    int offU[NBW], offV[2];
+    int offU[NBW], offV[MB];
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
         const int row = wn * (BN / 2) + 32 * j + rl;
         offU[j] = (2 * row + (gl ^ ((row >> 3) & 1))) * 16;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + 32 * i + rl;
+    for (int i = 0; i < MB; ++i) {
+        const int row = wm * (MB * 32) + 32 * i + rl;
         offV[i] = OP_A + (2 * row + (gl ^ ((row >> 3) & 1))) * 16;
     }
 
@@ -129,7 +150,7 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
     int buf_issue = 0, buf_use = 0;
     auto issue_next = [&]() {            // a whole stage at once (prologue)
         if (!iss.valid) return;
-        issue_pieces(buf_issue, 0, 6);
+        issue_pieces(buf_issue, 0, PT);
         issue_done();
         buf_issue = buf_issue == S3_STAGES - 1 ? 0 : buf_issue + 1;
         ++n_ahead;
@@ -148,16 +169,16 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
         }
         return *reinterpret_cast<const s3_bf8 *>(sb + off);
     };
-    // wait until at most `keep` of this wave's DMA stages are still in flight (each stage: 6 pieces, or 3 for the
-    // waves that move no U rows when BN = 128)
+    // wait until at most `keep` of this wave's DMA stages are still in flight (PT pieces per stage; 3 PV for the waves
+    // that move no U rows when BN = 128 at eight waves)
     auto wait_dma = [&](int keep) {
-        if (keep <= 0) __builtin_amdgcn_s_waitcnt(0x0f70);                              // vmcnt(0)
+        if (keep <= 0) s3_wait_vm<0>();
         else if (keep == 1) {
-            if (BN == 256 || wave < 4) __builtin_amdgcn_s_waitcnt(0x0f76);              // vmcnt(6)
-            else __builtin_amdgcn_s_waitcnt(0x0f73);                                    // vmcnt(3)
+            if (!U_HALF || wave < BN / 32) s3_wait_vm<PT>();
+            else s3_wait_vm<3 * PV>();
         } else {
-            if (BN == 256 || wave < 4) __builtin_amdgcn_s_waitcnt(0x0f7c);              // vmcnt(12)
-            else __builtin_amdgcn_s_waitcnt(0x0f76);                                    // vmcnt(6)
+            if (!U_HALF || wave < BN / 32) s3_wait_vm<2 * PT>();
+            else s3_wait_vm<6 * PV>();
         }
     };
 
@@ -165,11 +186,11 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
     issue_next(); issue_next(); issue_next();
     wait_dma(n_ahead - 1);
     if (!(S3_ABLATE & 4)) __builtin_amdgcn_s_barrier();
-    s3_bf8 v[2][3], vn[2][3], ua[3], ub[3];
+    s3_bf8 v[MB][3], vn[MB][3], ua[3], ub[3];
     {
         const unsigned char *sb = s3_lds;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = frag(sb, offV[i] + t3 * S3_BM * 32);
 #pragma unroll
@@ -182,11 +203,11 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
 #endif
 
     for (;;) {
-        s3_f16 acc[NBW][2];
+        s3_f16 acc[NBW][MB];
 #pragma unroll
         for (int j = 0; j < NBW; ++j)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.0f;
 
@@ -229,7 +250,7 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
                     iss_buf = buf_issue;
                     if (iss_go) { buf_issue = buf_issue == S3_STAGES - 1 ? 0 : buf_issue + 1; ++n_ahead; }
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < MB; ++i)
 #pragma unroll
                         for (int t3 = 0; t3 < 3; ++t3) vn[i][t3] = frag(sn, offV[i] + t3 * S3_BM * 32);
 #pragma unroll
@@ -240,28 +261,27 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
                 }
                 {
                     const int g = (j + 1) % NBW;                         // groups since the barrier: 0 = the barrier's own group
-                    constexpr int per = NBW == 4 ? 2 : 3, ng = 6 / per;  // pieces per group, groups that carry pieces
+                    constexpr int per = (PT + NBW - 1) / NBW, ng = (PT + per - 1) / per;   // pieces per group, groups that carry pieces
                     if (g < ng && iss_go) {
                         issue_pieces(iss_buf, g * per, g * per + per);
                         if (g == ng - 1) { issue_done(); advance(iss); iss_go = false; }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // six partial products per block, smallest first; consecutive MFMAs go to DIFFERENT accumulators (a wave that
+                // has the SIMD to itself would otherwise wait out every MFMA's latency on the dependent chain)
+                acc[j][0] = c0;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    s3_f16 c = i == 0 ? c0 : acc[j][i];
-                    if (i != 0) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[2], v[i][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[1], v[i][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[0], v[i][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[1], v[i][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[0], v[i][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[0], v[i][0], c, 0, 0, 0);
-                    acc[j][i] = c;
+                for (int pr = 0; pr < 6; ++pr) {
+                    constexpr int UT[6] = {2, 1, 0, 1, 0, 0}, VT[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                    for (int i = (pr == 0 ? 1 : 0); i < MB; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[UT[pr]], v[i][VT[pr]], acc[j][i], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = vn[i][t3];
         }
@@ -269,8 +289,8 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
         // ---- epilogue: lane holds, per block, n = n0 + 8q + 4*(lane>>5) + (0..3) of row m = m0 + (lane & 31) ----
         float *cz = p.c + (long long)cur.pz * p.c_ps;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = cur.m0 + wm * 64 + 32 * i + rl;
+        for (int i = 0; i < MB; ++i) {
+            const int m = cur.m0 + wm * (MB * 32) + 32 * i + rl;
             if (m < p.Mt) {
                 float *row = cz + (long long)m * p.ldc + cur.n0 + wn * (BN / 2) + 4 * gl;
 #pragma unroll
@@ -279,14 +299,18 @@ __global__ __launch_bounds__(S3_THREADS) void wino_gemm_s3_kernel(GemmS3Args p)
                     for (int q = 0; q < 4; ++q) {
                         s3_f4 o;
                         o[0] = acc[j][i][4 * q]; o[1] = acc[j][i][4 * q + 1]; o[2] = acc[j][i][4 * q + 2]; o[3] = acc[j][i][4 * q + 3];
+#if S3_ABLATE & 16
+                        *reinterpret_cast<s3_f4 *>(row + 32 * j + 8 * q) = o;      // probe 16: plain stores
+#else
                         __builtin_nontemporal_store(o, reinterpret_cast<s3_f4 *>(row + 32 * j + 8 * q));
+#endif
                     }
             }
         }
         Lcur += G;
 #ifdef S3_TIMING
         if (Lcur >= ntiles && lane == 0 && p.dbg) {
-            unsigned long long *d = p.dbg + ((long long)blockIdx.x * 8 + wave) * 5;
+            unsigned long long *d = p.dbg + ((long long)blockIdx.x * NW + wave) * 5;
             d[0] = tm_lgkm; d[1] = tm_vm; d[2] = tm_bar; d[3] = tm_n; d[4] = __builtin_readcyclecounter() - tm_start;
         }
 #endif
@@ -304,23 +328,25 @@ bool wino_gemm_s3_usable(int Mt, int K, int N)
     return Mt > 0 && K >= 32 && K % 16 == 0 && N >= 128 && N % 128 == 0;
 }
 
+template <int BN, int NW>
+static int s3_launch(hipStream_t st, const GemmS3Args &a, long long grid)
+{
+    static PerDeviceOnce attr;
+    const size_t lds = (size_t)S3_STAGES * (3 * BN * 32 + 3 * S3_BM * 32);
+    if (attr.first()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_kernel<BN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        attr.done();
+    }
+    hipLaunchKernelGGL((wino_gemm_s3_kernel<BN, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
 {
     if (!wino_gemm_s3_usable(a.Mt, a.K, a.N) || a.Mp % S3_BM || a.Mp < a.Mt || a.ldc % 4 || a.P <= 0) return 2;
-    static PerDeviceOnce attr256, attr128;
     const bool wide = a.N % 256 == 0 && a.Np % 256 == 0;
     if (!wide && a.Np % 128) return 2;
     const int BN = wide ? 256 : 128;
-    const size_t lds = (size_t)S3_STAGES * (3 * BN * 32 + 3 * S3_BM * 32);
-    if (wide) {
-        if (attr256.first()) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-            attr256.done();
-        }
-    } else if (attr128.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-        attr128.done();
-    }
     const long long tiles = (long long)a.P * ((a.Mt + S3_BM - 1) / S3_BM) * (a.N / BN);
     if (tiles >= (1ll << 31) - 65536) return 2;
     if (cus <= 0) {
@@ -334,11 +360,11 @@ int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
         }
         cus = cu_of[once.dev];
     }
-    long long grid = cus;      // one 8-wave workgroup per CU (108 / 144 KiB of LDS), persistent over the tiles
+    long long grid = cus;      // one workgroup per CU (108 / 144 KiB of LDS), persistent over the tiles
     if (grid > tiles) grid = tiles;
-    if (wide) hipLaunchKernelGGL(wino_gemm_s3_kernel<256>, dim3((unsigned)grid), dim3(S3_THREADS), lds, st, a);
-    else hipLaunchKernelGGL(wino_gemm_s3_kernel<128>, dim3((unsigned)grid), dim3(S3_THREADS), lds, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : 1;
+    const int nw = a.waves == 8 ? 8 : (a.waves == 4 ? 4 : S3_DEFAULT_WAVES);
+    if (wide) return nw == 8 ? s3_launch<256, 8>(st, a, grid) : s3_launch<256, 4>(st, a, grid);
+    return nw == 8 ? s3_launch<128, 8>(st, a, grid) : s3_launch<128, 4>(st, a, grid);
 }
 
 // fp32 -> three bf16 terms, round-to-nearest-even at every step (the same arithmetic as the device split, winograd.hip:s3_split)

@@ -464,6 +464,67 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_input_coop6_kernel(WinoArgs
     }
 }
 
+// The split-operand producer proper: EIGHT channels per lane (two float4 halves through the same column / row passes), so
+// that every (plane, term) store is 16 bytes and a wavefront -- 2 channel octets x 4 consecutive tiles -- writes whole
+// 128-byte lines of the [P][3][C/16][Mp][16] layout; the two wavefronts of a workgroup take neighbouring K blocks (the
+// other half of the same input lines).  wino_input_coop6_kernel<true> is the 4-channel form of the same thing (DT_S3_IN=0).
+#define WINO_S3IN_THREADS 128
+typedef unsigned int wino_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_input_s3_kernel(WinoArgs p)
+{
+    typedef VecOf<4>::T T;
+    constexpr int IPW = WINO_S3IN_THREADS / 8;      // items per workgroup
+    __shared__ __attribute__((aligned(16))) float s_t[2][IPW * WINO_COOP_ITEM];
+    const int mt4 = (p.Mt + 3) & ~3;
+    const long long items = (long long)mt4 * (p.C / 8);
+    const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;
+    float *st0 = s_t[0] + slot * WINO_COOP_ITEM, *st1 = s_t[1] + slot * WINO_COOP_ITEM;
+    const long long term = (long long)(p.C >> 4) * p.Mp * 16;        // elements of one (plane, term)
+    for (long long base = (long long)blockIdx.x * IPW; base < items; base += (long long)gridDim.x * IPW) {
+        const long long it = base + slot;
+        const long long hi = it >> 4;                    // (k-block pair, tile group of 4), tile group fastest
+        const int tg = (int)(hi % (mt4 >> 2)), kp = (int)(hi / (mt4 >> 2));
+        int tile = tg * 4 + (int)((it >> 1) & 3);
+        int c = (kp * 2 + (int)((it >> 3) & 1)) * 16 + (int)(it & 1) * 8;
+        const bool live = it < items && tile < p.Mt;
+        if (!live) { tile = 0; c = 0; }
+        const TileId t = tile_id(p, tile);
+        T ca[8], cb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {           // this lane's column `sub` of the 8x8 window, channels c .. c+7
+            int b = 0, h = 0, w = 0;
+            const bool ok = live && vpixel(p, t.grp, 6 * t.ty - 1 + i, 6 * t.tx - 1 + sub, b, h, w);
+            const float *src = p.in + (long long)b * p.in_bs + (long long)(h * p.W + w) * p.in_ld + c;
+            ca[i] = ok ? vload_in<4>(src) : vzero<4>();
+            cb[i] = ok ? vload_in<4>(src + 4) : vzero<4>();
+        }
+        bt_1d<6>(ca);                            // Bt d : down the column
+        bt_1d<6>(cb);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]); vstore<4>(st1 + (sub * 9 + i) * 4, cb[i]); }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ca[j] = vload<4>(st0 + (j * 9 + sub) * 4); cb[j] = vload<4>(st1 + (j * 9 + sub) * 4); }
+        bt_1d<6>(ca);                            // (Bt d) B : along the row
+        bt_1d<6>(cb);
+        if (live) {
+            unsigned short *dst = p.v_s3 + ((long long)(c >> 4) * p.Mp + tile) * 16 + (c & 15);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                wino_u2 ta[3], tb[3];
+                s3_split4(ca[j], ta);
+                s3_split4(cb[j], tb);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const wino_u4 o = {ta[k][0], ta[k][1], tb[k][0], tb[k][1]};
+                    *reinterpret_cast<wino_u4 *>(dst + ((long long)(8 * sub + j) * 3 + k) * term) = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArgs p)
 {
     typedef VecOf<4>::T T;
@@ -562,8 +623,13 @@ int launch_wino_input(hipStream_t st, const WinoArgs &a)
     if (a.C % 4 || a.in_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4 && a.ts != 6) || a.g < 1) return 2;
     if (a.v_s3) {
         if (a.ts != 6 || a.C % 32 || a.Mp < a.Mt) return 2;
-        const long long wgs = ((long long)((a.Mt + 3) & ~3) * (a.C / 4) + WINO_THREADS / 8 - 1) / (WINO_THREADS / 8);
-        hipLaunchKernelGGL(wino_input_coop6_kernel<true>, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
+        if (a.coop == 0) {      // A/B: the 4-channel form
+            const long long wgs = ((long long)((a.Mt + 3) & ~3) * (a.C / 4) + WINO_THREADS / 8 - 1) / (WINO_THREADS / 8);
+            hipLaunchKernelGGL(wino_input_coop6_kernel<true>, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
+        } else {
+            const long long wgs = ((long long)((a.Mt + 3) & ~3) * (a.C / 8) + WINO_S3IN_THREADS / 8 - 1) / (WINO_S3IN_THREADS / 8);
+            hipLaunchKernelGGL(wino_input_s3_kernel, dim3((unsigned)(wgs < 262144 ? wgs : 262144)), dim3(WINO_S3IN_THREADS), 0, st, a);
+        }
     } else if (a.ts == 6 && wino_coop_wanted(a, (long long)a.Mt * (a.C / 2))) {
         const long long wgs = ((long long)a.Mt * (a.C / 4) + WINO_THREADS / 8 - 1) / (WINO_THREADS / 8);
         hipLaunchKernelGGL(wino_input_coop6_kernel<false>, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);

@@ -46,6 +46,7 @@ static void run(int P, int Mt, int K, int N, int check_rows, int iters)
     GemmS3Args a;
     a.a = dV; a.b = dU; a.c = dC; a.c_ps = (long long)Mt * N; a.P = P; a.Mt = Mt; a.Mp = Mp; a.N = N; a.Np = Np; a.K = K; a.ldc = N;
     a.dbg = nullptr;
+    a.waves = getenv("S3_WAVES") ? atoi(getenv("S3_WAVES")) : 0;
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
 #ifdef S3_TIMING
