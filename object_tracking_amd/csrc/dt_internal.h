@@ -114,6 +114,10 @@ struct WinoArgs {
     int out_ld;
     float *out2;
     int out2_ld;
+    // non-null: the activation leaves as the split-bf16 A operand of the next (1x1) layer's GEMM instead of `out`:
+    // [3][N/16][out_mp][16], row = pixel index (b*H + h)*W + w  (ts == 6 cooperative kernel, N % 16 == 0)
+    unsigned short *out_s3;
+    int out_mp;
     // gate variant (ConvLSTM2D): xproj / cstate as in ConvArgs
     const float *xproj;
     long long xp_bs;
@@ -160,6 +164,11 @@ struct GemmS3Args {
     float *c;                  // M'       [P] planes of [Mt][ldc], plane stride c_ps floats
     long long c_ps;
     int P, Mt, Mp, N, Np, K, ldc;
+    // a 1x1 layer through this kernel: bias as one extra K stage -- ones = [3][256][16] terms of the row (1, 0, .., 0),
+    // bias_s3 = [3][Np][16] terms of (bias[n], 0, .., 0); both null for the Winograd GEMMs.  act: LeakyReLU(slope) in the epilogue
+    const unsigned short *ones, *bias_s3;
+    int act;
+    float slope;
     int waves;                 // 8 / 4 waves per workgroup (64 x BN/2 or 128 x BN/2 per wave); 0 = the default (Policy::s3_waves)
     unsigned long long *dbg;   // -DS3_TIMING builds of the micro-benchmark only: per-wave wait cycles; otherwise null
 };
@@ -246,6 +255,8 @@ struct DevBuf {
 struct ConvLayer {
     int idx, ks, cin, cout, npad, pool;  // pool: reference MaxPooling2D after this layer
     float *wt = nullptr;                 // device, packed
+    unsigned short *wt_s3 = nullptr;     // device, 1x1 layers: wt as split-bf16 terms [3][cin/16][npad][16] (wino_gemm_s3.hip) or null
+    unsigned short *bias_s3 = nullptr;   // device, with wt_s3: the bias as the B rows of one extra K stage, [3][npad][16]
     float *wino = nullptr;               // device, [P][npad][cin] Winograd-domain weights (wide 3x3 layers) or null
     int wino_ts = 0;                     // their output tile size (2, 4 or 6)
     float *wino_alt = nullptr;           // device, F(4x4) weights kept next to F(6x6) ones for small-batch launches, or null
@@ -276,6 +287,10 @@ struct Policy {
     int s3 = 1;              // DT_S3: the F(6x6) layers' batched GEMMs on the bf16 matrix pipe with 3-term split operands (wino_gemm_s3.hip):
                              //        0 never (fp32 MFMA) / 1 where it wins (K >= s3_mink, GEMM rows >= s3_minrows) / 2 wherever the shape allows
     int s3_mink = 256, s3_minrows = 2048;   // DT_S3_MINK / DT_S3_MINROWS
+    int s3_1x1_mink = 512;   // DT_S3_1X1_MINK: ... only for 1x1 layers with at least this many input channels (conv_10 / 12 / 15 / 17): the producer's
+                             //                  split output transform costs more than fp32 NHWC, which only the long-K GEMMs win back
+    int s3_1x1 = 1;          // DT_S3_1X1: a 1x1 layer that follows a Winograd layer takes its input as split-bf16 terms straight from that
+                             //            layer's output transform and runs on wino_gemm_s3.hip (same K / rows thresholds); 0 = fp32 MFMA
     int wino_coop = -1;      // DT_WINO_COOP: lane-cooperative F(6x6) transform kernels: -1 for small launches (default) / 0 never / 1 always
     int persist = 1;         // DT_PERSIST: 0 = one tile per workgroup for the GEMM-shaped launches (A/B runs)
     int xcd_remap = 1;       // DT_XCD_REMAP: 0 = plain tile numbering (L2 traffic experiments)
@@ -296,6 +311,7 @@ struct dt_ctx {
     int dec_anchors_n = 0;
     bool det_loaded = false;
     ConvLayer layers[24];   // 1..23
+    unsigned short *s3_ones = nullptr;   // device, [3][256][16]: split terms of the A rows (1, 0, .., 0) that carry a 1x1 layer's bias through wino_gemm_s3.hip
     std::map<const void *, unsigned short *> wino_s3;   // F(6x6) Winograd weights (device pointer) -> their split-bf16 form (wino_gemm_s3.hip), when built
     float *conv1_w = nullptr, *conv1_b = nullptr, *lut255 = nullptr;
     std::vector<float> conv1_hwio32, conv1_scale, conv1_shift;   // host copy of conv_1 as a Cin = 32 layer (dt_detector_extract)

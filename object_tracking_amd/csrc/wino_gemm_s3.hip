@@ -48,7 +48,9 @@ __device__ __forceinline__ void s3_wait_vm() { __builtin_amdgcn_s_waitcnt(0x0f70
 //                         4 = 2 x 2 waves of 128 x BN/2, one wave per SIMD with the whole 512-entry register file: a third
 //                             fewer LDS fragment reads per MFMA (0.25 instead of 0.375 ds_read_b128) -- the reads are what
 //                             pulls the clock down (tools/s3_clock.sh: 2.26 GHz without them, 1.70 GHz with)
-template <int BN, int NW>
+//   ACT: LeakyReLU(p.slope) on the accumulators before the epilogue's stores (the 1x1 layers); a template parameter, so that
+//   the Winograd instances carry none of it
+template <int BN, int NW, bool ACT>
 __global__ __launch_bounds__(NW * 64) void wino_gemm_s3_kernel(GemmS3Args p)
 {
     constexpr int WM = NW / 2;                        // waves along m (two along n)
@@ -90,7 +92,14 @@ __global__ __launch_bounds__(NW * 64) void wino_gemm_s3_kernel(GemmS3Args p)
     // running DMA sources of this lane (term 0; the other terms sit a_term / b_term elements further): advanced by one
     // K block per stage, recomputed when the issue cursor enters a new tile
     const unsigned short *src_a = nullptr, *src_b = nullptr;
+    long long ta = a_term, tb = b_term;      // term strides of the stage being issued
+    // A 1x1 layer's bias rides in the GEMM as ONE extra K stage: A rows = [1, 0, ..., 0] (p.ones, the same 256 rows for every
+    // tile), B rows = [bias[n], 0, ..., 0] as split terms (p.bias_s3) -- the three products b_t x 1.0 are among the six formed,
+    // so the accumulator receives the bias to 2^-25 and the epilogue needs no loads (a vector load there has to wait on
+    // vmcnt, i.e. on the stores before it and on the next tile's DMA in flight: measured 2.4x slower at K = 128)
+    const int KBX = KB + (p.bias_s3 ? 1 : 0);
     auto issue_src = [&](const Tile &t) {
+        ta = a_term; tb = b_term;
         src_b = p.b + ((S3_ABLATE & 8) ? 0 : t.b0) + (long long)(32 * PU * wave + lrow) * 16 + dgran * 8;   // probe 8: every tile streams the same panels (L2 hits only)
         src_a = p.a + ((S3_ABLATE & 8) ? 0 : t.a0) + (long long)(32 * PV * wave + lrow) * 16 + dgran * 8;
     };
@@ -104,12 +113,12 @@ __global__ __launch_bounds__(NW * 64) void wino_gemm_s3_kernel(GemmS3Args p)
 #pragma unroll
             for (int sp = 0; sp < PU; ++sp, ++k)
                 if (k >= lo && k < hi && (!U_HALF || wave < BN / 32))
-                    __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_b + t3 * b_term + sp * 512),
+                    __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_b + t3 * tb + sp * 512),
                                                      (s3_lptr_t *)(dst + t3 * BN * 32 + (wave * PU + sp) * 1024), 16, 0, 0);
 #pragma unroll
             for (int sp = 0; sp < PV; ++sp, ++k)
                 if (k >= lo && k < hi)
-                    __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_a + t3 * a_term + sp * 512),
+                    __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_a + t3 * ta + sp * 512),
                                                      (s3_lptr_t *)(dst + OP_A + t3 * S3_BM * 32 + (wave * PV + sp) * 1024), 16, 0, 0);
         }
     };
@@ -135,7 +144,11 @@ __global__ __launch_bounds__(NW * 64) void wino_gemm_s3_kernel(GemmS3Args p)
     // Two cursors walk this workgroup's sequence of (tile, k stage): `iss` three stages ahead (DMA), the compute cursor behind it.
     struct Cursor { Tile t; int kb; int L; bool valid; };
     auto advance = [&](Cursor &c) {
-        if (++c.kb == KB) {
+        ++c.kb;
+        if (c.kb == KB && KBX > KB) {          // next: the bias stage of this tile
+            src_a = p.ones + (long long)(32 * PV * wave + lrow) * 16 + dgran * 8; ta = S3_BM * 16;
+            src_b = p.bias_s3 + (long long)(c.t.n0 + 32 * PU * wave + lrow) * 16 + dgran * 8; tb = (long long)p.Np * 16;
+        } else if (c.kb == KBX) {
             c.kb = 0; c.L += G;
             c.valid = c.L < ntiles;
             if (c.valid) { c.t = tile_of(c.L); issue_src(c.t); }
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(NW * 64) void wino_gemm_s3_kernel(GemmS3Args p)
                 for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.0f;
 
 #pragma unroll 1
-        for (int kb = 0; kb < KB; ++kb) {
+        for (int kb = 0; kb < KBX; ++kb) {
             const unsigned char *sb = s3_lds + buf_use * STAGE;
             buf_use = buf_use == S3_STAGES - 1 ? 0 : buf_use + 1;
             const unsigned char *sn = s3_lds + buf_use * STAGE;          // the stage after this one
@@ -286,6 +299,16 @@ __global__ __launch_bounds__(NW * 64) void wino_gemm_s3_kernel(GemmS3Args p)
                 for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = vn[i][t3];
         }
 
+        if (ACT) {      // a 1x1 layer: LeakyReLU (its bias came in through the extra K stage).  ALL of it before the first store:
+                        // a VALU write to a register an in-flight store still reads waits for that store (32 serialised stores, 2.2x)
+#pragma unroll
+            for (int j = 0; j < NBW; ++j)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[j][i][e] = acc[j][i][e] > 0.0f ? acc[j][i][e] : acc[j][i][e] * p.slope;
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- epilogue: lane holds, per block, n = n0 + 8q + 4*(lane>>5) + (0..3) of row m = m0 + (lane & 31) ----
         float *cz = p.c + (long long)cur.pz * p.c_ps;
 #pragma unroll
@@ -328,22 +351,23 @@ bool wino_gemm_s3_usable(int Mt, int K, int N)
     return Mt > 0 && K >= 32 && K % 16 == 0 && N >= 128 && N % 128 == 0;
 }
 
-template <int BN, int NW>
+template <int BN, int NW, bool ACT>
 static int s3_launch(hipStream_t st, const GemmS3Args &a, long long grid)
 {
     static PerDeviceOnce attr;
     const size_t lds = (size_t)S3_STAGES * (3 * BN * 32 + 3 * S3_BM * 32);
     if (attr.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_kernel<BN, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_kernel<BN, NW, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
         attr.done();
     }
-    hipLaunchKernelGGL((wino_gemm_s3_kernel<BN, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((wino_gemm_s3_kernel<BN, NW, ACT>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
 {
     if (!wino_gemm_s3_usable(a.Mt, a.K, a.N) || a.Mp % S3_BM || a.Mp < a.Mt || a.ldc % 4 || a.P <= 0) return 2;
+    if ((a.bias_s3 != nullptr) != (a.ones != nullptr)) return 2;
     const bool wide = a.N % 256 == 0 && a.Np % 256 == 0;
     if (!wide && a.Np % 128) return 2;
     const int BN = wide ? 256 : 128;
@@ -363,8 +387,12 @@ int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
     long long grid = cus;      // one workgroup per CU (108 / 144 KiB of LDS), persistent over the tiles
     if (grid > tiles) grid = tiles;
     const int nw = a.waves == 8 ? 8 : (a.waves == 4 ? 4 : S3_DEFAULT_WAVES);
-    if (wide) return nw == 8 ? s3_launch<256, 8>(st, a, grid) : s3_launch<256, 4>(st, a, grid);
-    return nw == 8 ? s3_launch<128, 8>(st, a, grid) : s3_launch<128, 4>(st, a, grid);
+    if (a.act) return wide ? s3_launch<256, 8, true>(st, a, grid) : s3_launch<128, 8, true>(st, a, grid);
+#ifdef S3_WITH_4WAVES      // the one-wave-per-SIMD form (micro-benchmark builds): measured slower, see the kernel's header
+    if (nw == 4) return wide ? s3_launch<256, 4, false>(st, a, grid) : s3_launch<128, 4, false>(st, a, grid);
+#endif
+    (void)nw;
+    return wide ? s3_launch<256, 8, false>(st, a, grid) : s3_launch<128, 8, false>(st, a, grid);
 }
 
 // fp32 -> three bf16 terms, round-to-nearest-even at every step (the same arithmetic as the device split, winograd.hip:s3_split)

@@ -447,14 +447,15 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_input_coop6_kernel(WinoArgs
         if (live && S3) {
             const long long term = (long long)(p.C >> 4) * p.Mp * 16;        // elements of one (plane, term)
             unsigned short *dst = p.v_s3 + ((long long)(c >> 4) * p.Mp + tile) * 16 + (c & 15);
+            wino_u2 tr[8][3];       // all splits before the first store (see wino_input_s3_kernel)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                wino_u2 tr[3];
-                s3_split4(row[j], tr);
+            for (int j = 0; j < 8; ++j) s3_split4(row[j], tr[j]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                    *reinterpret_cast<wino_u2 *>(dst + ((long long)(8 * sub + j) * 3 + k) * term) = tr[k];
-            }
+                    *reinterpret_cast<wino_u2 *>(dst + ((long long)(8 * sub + j) * 3 + k) * term) = tr[j][k];
         } else if (live) {
             float *dst = p.v + (long long)tile * p.C + c;
 #pragma unroll
@@ -509,22 +510,28 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_input_s3_kernel(WinoAr
         bt_1d<6>(cb);
         if (live) {
             unsigned short *dst = p.v_s3 + ((long long)(c >> 4) * p.Mp + tile) * 16 + (c & 15);
+            // every split BEFORE the first store, each result in its own registers: a VALU write to a register that a store
+            // in flight still reads waits for that store (the stores then run one after the other)
+            wino_u4 o[8][3];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 wino_u2 ta[3], tb[3];
                 s3_split4(ca[j], ta);
                 s3_split4(cb[j], tb);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const wino_u4 o = {ta[k][0], ta[k][1], tb[k][0], tb[k][1]};
-                    *reinterpret_cast<wino_u4 *>(dst + ((long long)(8 * sub + j) * 3 + k) * term) = o;
-                }
+                for (int k = 0; k < 3; ++k) o[j][k] = wino_u4{ta[k][0], ta[k][1], tb[k][0], tb[k][1]};
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) *reinterpret_cast<wino_u4 *>(dst + ((long long)(8 * sub + j) * 3 + k) * term) = o[j][k];
         }
         __syncthreads();
     }
 }
 
+template <bool S3OUT>      // S3OUT: the activation leaves as split-bf16 rows (p.out_s3) instead of p.out / p.out2
 __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArgs p)
 {
     typedef VecOf<4>::T T;
@@ -543,8 +550,12 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
         T col[8];
         const float *src = p.m + (long long)tile * p.m_ld + c;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) col[i] = live ? vload_nt<4>(src + (long long)(8 * i + sub) * plane) : vzero<4>();   // column nu = sub
-        at_1d<6>(col);                           // At m : down the column -> rows 0..5
+        // S3OUT takes the two passes in the other order (along the rows first), so that the LANES of the second pass are
+        // consecutive pixels of one image row: a store instruction then covers 6 pixels x 32 bytes of a K block contiguously
+        // instead of one 32-byte piece per image row
+        for (int i = 0; i < 8; ++i)
+            col[i] = live ? vload_nt<4>(src + (long long)(S3OUT ? 8 * sub + i : 8 * i + sub) * plane) : vzero<4>();   // column nu = sub (S3OUT: row xi = sub)
+        at_1d<6>(col);                           // At m : down the column -> rows 0..5   (S3OUT: m A along the row -> columns 0..5)
 #pragma unroll
         for (int i = 0; i < 6; ++i) vstore<4>(st + (sub * 9 + i) * 4, col[i]);
         __syncthreads();
@@ -563,11 +574,28 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
                 for (int e = 0; e < 4; ++e) set_lane<4>(v, e, wino_leaky(lane_of<4>(v, e), p.slope));
                 row[j] = v;
                 int b, h, w;
-                if (live && p.out && vpixel(p, t.grp, 6 * t.ty + sub, 6 * t.tx + j, b, h, w))
+                if (!S3OUT && live && p.out && vpixel(p, t.grp, 6 * t.ty + sub, 6 * t.tx + j, b, h, w))
                     vstore_nt<4>(p.out + (long long)b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c, v);
             }
+            if (S3OUT) {      // the next layer's GEMM operand: three bf16 terms, K-blocked, row = pixel; this lane holds image column
+                              // `sub` of the tile, rows j = 0..5.  All splits before the first store, each in its own registers
+                wino_u2 tr[6][3];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) s3_split4(row[j], tr[j]);
+                __builtin_amdgcn_sched_barrier(0);
+                const long long term = (long long)(p.N >> 4) * p.out_mp * 16;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    int b, h, w;
+                    if (live && vpixel(p, t.grp, 6 * t.ty + j, 6 * t.tx + sub, b, h, w)) {
+                        unsigned short *d = p.out_s3 + ((long long)(c >> 4) * p.out_mp + ((long long)b * p.H + h) * p.W + w) * 16 + (c & 15);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) *reinterpret_cast<wino_u2 *>(d + k * term) = tr[j][k];
+                    }
+                }
+            }
         }
-        if (p.out2) {   // MaxPooling2D(2,2) (g == 1: launcher): output rows 2k, 2k+1 sit in neighbouring lanes
+        if (!S3OUT && p.out2) {   // MaxPooling2D(2,2) (g == 1: launcher): output rows 2k, 2k+1 sit in neighbouring lanes
             const int H2 = p.H >> 1, W2 = p.W >> 1;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -659,9 +687,11 @@ int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates)
     } else {
         // vector stores need aligned rows; ragged N (conv_23-like heads) never takes this path
         if (a.N % 4 || (a.out && a.out_ld % 4) || (a.out2 && a.out2_ld % 4)) return 2;
-        if (a.ts == 6 && wino_coop_wanted(a, (long long)a.Mt * (a.N / 2))) {
+        if (a.out_s3 && (a.ts != 6 || a.N % 16 || a.out || a.out2 || (long long)a.B * a.H * a.W > a.out_mp)) return 2;
+        if (a.ts == 6 && (a.out_s3 || wino_coop_wanted(a, (long long)a.Mt * (a.N / 2)))) {
             const long long wgs = ((long long)a.Mt * (a.N / 4) + WINO_THREADS / 8 - 1) / (WINO_THREADS / 8);
-            hipLaunchKernelGGL(wino_output_coop6_kernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
+            if (a.out_s3) hipLaunchKernelGGL(wino_output_coop6_kernel<true>, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
+            else hipLaunchKernelGGL(wino_output_coop6_kernel<false>, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
         } else if (a.ts == 6)
             hipLaunchKernelGGL((wino_output_kernel<6, 2>), dim3(wino_blocks((long long)a.Mt * (a.N / 2))), dim3(wino_threads((long long)a.Mt * (a.N / 2))),
                                0, st, a);

@@ -1356,3 +1356,28 @@ def test_split_bf16_default_policy_engages_on_deep_layers(ctx, monkeypatch):
         ref = orc.conv2d(x[:2], w, b)
         ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
         assert relerr(got[:2].cpu().numpy(), ref) < 2e-4
+
+
+def test_split_bf16_handover_to_1x1_layers(ctx, monkeypatch):
+    """conv_6 -> 7, 9 -> 10, 11 -> 12, 14 -> 15, 16 -> 17: the Winograd layer's output transform writes the split-bf16 rows
+    the 1x1 layer's GEMM reads (DT_S3_1X1=1, the default) instead of the fp32 tensor.  Same network output as with the
+    hand-over off (fp32 MFMA 1x1 layers), and the oracle's on the frames the oracle is run on."""
+    B, H, W, C = 16, 416, 416, 12
+    frames = np.random.RandomState(3).randint(0, 256, (B, H, W, 3)).astype(np.uint8)
+    outs = {}
+    layers = None
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DT_S3_1X1", mode)          # read when the context is created (dt_create)
+        monkeypatch.setenv("DT_S3_1X1_MINK", "256")    # every eligible pair (the default policy hands over to conv_15 / conv_17 only)
+        det, layers, _ = _detector(ctx, H, W, C, seed=77)
+        c = det.model.ctx
+        c.profile_reset(); c.profile_enable(True)
+        outs[mode] = c.detect_forward(dev(frames, c)).cpu().numpy()
+        c.profile_enable(False)
+        hand = sorted(int(n.split("_")[-1]) for n in c.profile_names() if n.startswith("conv_gemm_s3:conv_") and c.profile_read(n)["launches"]
+                      and int(n.split("_")[-1]) in (4, 7, 10, 12, 15, 17, 21, 23))
+        assert hand == ([7, 10, 12, 15, 17] if mode == "1" else []), hand
+        assert c.profile_read("wino_output:conv_14")["launches"] == 1
+    assert chan_err(flat_c(outs["1"]), flat_c(outs["0"])) < 1e-4          # two roundings of the same network (measured 5e-5)
+    ref_net, _, _ = orc.yolov2_forward(orc.normalize_u8(frames[:2]), layers, taps=())
+    assert chan_err(flat_c(outs["1"][:2]), flat_c(ref_net)) < NET_TOL

@@ -43,10 +43,11 @@ static void run(int P, int Mt, int K, int N, int check_rows, int iters)
     hipMemcpy(dV, Vs.data(), Vs.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(dU, Us.data(), Us.size() * 2, hipMemcpyHostToDevice);
     hipMemset(dC, 0xff, (size_t)P * Mt * N * 4);
-    GemmS3Args a;
+    GemmS3Args a = {};
     a.a = dV; a.b = dU; a.c = dC; a.c_ps = (long long)Mt * N; a.P = P; a.Mt = Mt; a.Mp = Mp; a.N = N; a.Np = Np; a.K = K; a.ldc = N;
     a.dbg = nullptr;
     a.waves = getenv("S3_WAVES") ? atoi(getenv("S3_WAVES")) : 0;
+    a.act = getenv("S3_ACT") ? 1 : 0; a.slope = 0.1f;      // timing only (the check below expects the plain product)
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
 #ifdef S3_TIMING
