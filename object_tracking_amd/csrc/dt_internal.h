@@ -287,6 +287,8 @@ struct Policy {
     int s3 = 1;              // DT_S3: the F(6x6) layers' batched GEMMs on the bf16 matrix pipe with 3-term split operands (wino_gemm_s3.hip):
                              //        0 never (fp32 MFMA) / 1 where it wins (K >= s3_mink, GEMM rows >= s3_minrows) / 2 wherever the shape allows
     int s3_mink = 256, s3_minrows = 2048;   // DT_S3_MINK / DT_S3_MINROWS
+    int s3_rec_minrows = 512; // DT_S3_REC_MINROWS: the ConvLSTM recurrent step's F(4x4) GEMM (gate update in its output transform) takes the split
+                              //                    kernel from this many GEMM rows (48 clips at 13x13: 588); 0 = never
     int s3_1x1_mink = 512;   // DT_S3_1X1_MINK: ... only for 1x1 layers with at least this many input channels (conv_10 / 12 / 15 / 17): the producer's
                              //                  split output transform costs more than fp32 NHWC, which only the long-K GEMMs win back
     int s3_1x1 = 1;          // DT_S3_1X1: a 1x1 layer that follows a Winograd layer takes its input as split-bf16 terms straight from that

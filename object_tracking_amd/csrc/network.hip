@@ -219,6 +219,7 @@ extern "C" void dt_destroy(dt_ctx *ctx)
                         ctx->trk_wh,  ctx->trk_wo,  ctx->trk_bo, ctx->trk_wx_wino, ctx->trk_wh_wino, ctx->tiny_wx,     ctx->tiny_bx, ctx->tiny_ur,
                         ctx->tiny_wd, ctx->tiny_bd};
     s3_drop(ctx, ctx->trk_wx_wino);
+    s3_drop(ctx, ctx->trk_wh_wino);
     if (ctx->s3_ones) (void)hipFree(ctx->s3_ones);
     for (float *p : singles)
         if (p) (void)hipFree(p);
@@ -275,7 +276,7 @@ static void oihw_to_hwio(const float *src, int O, int I, int k, std::vector<floa
 static bool wino_wanted(const dt_ctx *ctx, int ks, int cin, int cout);
 static int wino_tile(const dt_ctx *ctx, bool recurrent);
 static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map,
-                       int cin_dst, const int *n_map, int npad, const float *scale);
+                       int cin_dst, const int *n_map, int npad, const float *scale, bool want_s3 = true);
 
 static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, const float *hwio, const float *scale,
                            const float *bias_src)
@@ -352,7 +353,7 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
         // small batches of the 13x13 / 26x26 layers: F(4x4) needs 36 GEMMs of ONE (partly filled) row tile where F(6x6)
         // needs 64 -- keep both weight sets and choose per launch (run_conv); only with the default tile policy
         if (L.wino_ts == 6 && ctx->pol.wino_tile == 0 && cin >= 256) {
-            rc = upload_wino(ctx, &L.wino_alt, 4, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale);
+            rc = upload_wino(ctx, &L.wino_alt, 4, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale, false);
             if (rc) return rc;
         }
     }
@@ -465,6 +466,7 @@ void policy_from_env(Policy &p)
     p.s3_minrows = geti("DT_S3_MINROWS", d.s3_minrows);
     p.s3_1x1 = geti("DT_S3_1X1", d.s3_1x1);
     p.s3_1x1_mink = geti("DT_S3_1X1_MINK", d.s3_1x1_mink);
+    p.s3_rec_minrows = geti("DT_S3_REC_MINROWS", d.s3_rec_minrows);
     p.persist = geti("DT_PERSIST", d.persist);
     p.xcd_remap = geti("DT_XCD_REMAP", d.xcd_remap);
     p.tile_gn = geti("DT_TILE_GN", d.tile_gn);
@@ -503,7 +505,7 @@ static bool wino_runs(const dt_ctx *ctx, const float *wino_wt, int ts, int B, in
 }
 
 static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map,
-                       int cin_dst, const int *n_map, int npad, const float *scale)
+                       int cin_dst, const int *n_map, int npad, const float *scale, bool want_s3)
 {
     std::vector<float> u((size_t)(ts + 2) * (ts + 2) * npad * cin_dst);
     wino_pack_weights(ts, hwio, cin_src, cout_src, cin_map, cin_dst, n_map, npad, scale, u.data());
@@ -511,10 +513,11 @@ static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int 
     int rc = upload(ctx, dst, u);
     if (rc) return rc;
     // F(6x6) weights also in the split-bf16 form of wino_gemm_s3.hip (the split runs on the device, from the fp32 copy)
-    if (ts == 6 && ctx->pol.s3 != 0 && cin_dst % 32 == 0 && npad % 128 == 0) {
+    // (F(4x4): the ConvLSTM recurrent convolution)
+    if (want_s3 && (ts == 6 || ts == 4) && ctx->pol.s3 != 0 && cin_dst % 32 == 0 && npad % 128 == 0) {
         unsigned short *s3 = nullptr;
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s3), u.size() * 3 * sizeof(unsigned short)));
-        if (launch_wino_s3_pack(ctx->stream, *dst, 64, npad, cin_dst, s3)) { (void)hipFree(s3); return dt_fail(ctx, DT_ERR_DEVICE, "split-bf16 weight pack launch failed"); }
+        if (launch_wino_s3_pack(ctx->stream, *dst, (ts + 2) * (ts + 2), npad, cin_dst, s3)) { (void)hipFree(s3); return dt_fail(ctx, DT_ERR_DEVICE, "split-bf16 weight pack launch failed"); }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ctx->wino_s3[*dst] = s3;
     }
@@ -628,8 +631,9 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
     const size_t mt = (size_t)w.Mt;
     // the GEMMs on the bf16 pipe with split operands (wino_gemm_s3.hip) where that form exists and wins: long K, enough rows
     const unsigned short *u_s3 = nullptr;
-    if (ts == 6 && !io.cstate && ctx->pol.s3 != 0 && cin % 32 == 0 && N % 128 == 0 && npad % 128 == 0 && wino_gemm_s3_usable(w.Mt, cin, N) &&
-        (ctx->pol.s3 == 2 || (cin >= ctx->pol.s3_mink && w.Mt >= ctx->pol.s3_minrows))) {
+    const bool rec = ts == 4 && io.cstate;      // the recurrent step: F(4x4), gate update in the output transform
+    if (((ts == 6 && !io.cstate) || rec) && ctx->pol.s3 != 0 && cin % 32 == 0 && N % 128 == 0 && npad % 128 == 0 && wino_gemm_s3_usable(w.Mt, cin, N) &&
+        (ctx->pol.s3 == 2 || (cin >= ctx->pol.s3_mink && (rec ? (ctx->pol.s3_rec_minrows > 0 && w.Mt >= ctx->pol.s3_rec_minrows) : w.Mt >= ctx->pol.s3_minrows)))) {
         auto it = ctx->wino_s3.find(wino_wt);
         if (it != ctx->wino_s3.end()) u_s3 = it->second;
     }

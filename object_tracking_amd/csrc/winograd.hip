@@ -173,9 +173,23 @@ __device__ __forceinline__ bool vpixel(const WinoArgs &p, int grp, int vh, int v
 }
 
 // ---- input transform ----------------------------------------------------------------------------
+// fp32 -> three bf16 terms (round to nearest even at every step; host twin: wino_gemm_s3.hip:wino_s3_split_host)
+typedef __bf16 wino_bf4 __attribute__((ext_vector_type(4)));
+typedef unsigned int wino_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void s3_split4(const VecOf<4>::T x, wino_u2 t[3])
+{
+    const wino_bf4 h = __builtin_convertvector(x, wino_bf4);
+    const VecOf<4>::T r1 = x - __builtin_convertvector(h, VecOf<4>::T);
+    const wino_bf4 m = __builtin_convertvector(r1, wino_bf4);
+    const VecOf<4>::T r2 = r1 - __builtin_convertvector(m, VecOf<4>::T);
+    const wino_bf4 l = __builtin_convertvector(r2, wino_bf4);
+    t[0] = __builtin_bit_cast(wino_u2, h); t[1] = __builtin_bit_cast(wino_u2, m); t[2] = __builtin_bit_cast(wino_u2, l);
+}
+
 // One work item = (tile, V channels).  Tile (grp, ty, tx) covers virtual rows TS*ty-1 .. TS*ty+TS, cols
 // TS*tx-1 .. TS*tx+TS ('same' padding, separators and the rows/columns past the image read as zero).
-template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_input_kernel(WinoArgs p)
+// S3 (V == 4): V leaves as split-bf16 terms [P][3][C/16][Mp][16] (the recurrent step's F(4x4) GEMM on wino_gemm_s3.hip)
+template <int TS, int V, bool S3 = false> __global__ __launch_bounds__(WINO_THREADS) void wino_input_kernel(WinoArgs p)
 {
     typedef typename VecOf<V>::T T;
     constexpr int NI = TS + 2;
@@ -208,12 +222,28 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_in
             for (int i = 0; i < NI; ++i) d[i][j] = col[i];
         }
         // (Bt d) B : along the rows, stored plane by plane
-        float *dst = p.v + (long long)tile * p.C + c;
+        if constexpr (S3 && V == 4) {
+            const long long term = (long long)(p.C >> 4) * p.Mp * 16;
+            unsigned short *dst = p.v_s3 + ((long long)(c >> 4) * p.Mp + tile) * 16 + (c & 15);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            bt_1d<TS>(d[i]);
+            for (int i = 0; i < NI; ++i) {
+                bt_1d<TS>(d[i]);
+                wino_u2 tr[NI][3];       // a row's splits before its stores
 #pragma unroll
-            for (int j = 0; j < NI; ++j) vstore_v<V>(dst + (long long)(NI * i + j) * plane, d[i][j]);
+                for (int j = 0; j < NI; ++j) s3_split4(d[i][j], tr[j]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) *reinterpret_cast<wino_u2 *>(dst + ((long long)(NI * i + j) * 3 + k) * term) = tr[j][k];
+            }
+        } else {
+            float *dst = p.v + (long long)tile * p.C + c;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                bt_1d<TS>(d[i]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) vstore_v<V>(dst + (long long)(NI * i + j) * plane, d[i][j]);
+            }
         }
     }
 }
@@ -386,19 +416,6 @@ static unsigned wino_blocks(long long items)
 // 288 floats per item = 32 banks past a multiple of 64, so the two items of a 16-lane access group do not collide either).
 #define WINO_COOP_ITEM 288
 #define WINO_COOP_MAX_ITEMS (768 * WINO_THREADS)     // (tile, channel-pair) items below which a launch takes the cooperative kernels
-// fp32 -> three bf16 terms (round to nearest even at every step; host twin: wino_gemm_s3.hip:wino_s3_split_host)
-typedef __bf16 wino_bf4 __attribute__((ext_vector_type(4)));
-typedef unsigned int wino_u2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void s3_split4(const VecOf<4>::T x, wino_u2 t[3])
-{
-    const wino_bf4 h = __builtin_convertvector(x, wino_bf4);
-    const VecOf<4>::T r1 = x - __builtin_convertvector(h, VecOf<4>::T);
-    const wino_bf4 m = __builtin_convertvector(r1, wino_bf4);
-    const VecOf<4>::T r2 = r1 - __builtin_convertvector(m, VecOf<4>::T);
-    const wino_bf4 l = __builtin_convertvector(r2, wino_bf4);
-    t[0] = __builtin_bit_cast(wino_u2, h); t[1] = __builtin_bit_cast(wino_u2, m); t[2] = __builtin_bit_cast(wino_u2, l);
-}
-
 // S3: V leaves as the split-bf16 operand of wino_gemm_s3.hip, [P][3][C/16][Mp][16]; the item order then puts 4 channel
 // quads x 2 tiles in a wavefront and 2 k-blocks x 2 tile pairs in a workgroup (64-byte store runs per wave-instruction,
 // neighbours of the same 128-byte lines in the same workgroup, for the loads as well)
@@ -721,7 +738,10 @@ static inline bool wino_coop_wanted(const WinoArgs &a, long long items_pairs)
 int launch_wino_input(hipStream_t st, const WinoArgs &a)
 {
     if (a.C % 4 || a.in_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4 && a.ts != 6) || a.g < 1) return 2;
-    if (a.v_s3) {
+    if (a.v_s3 && a.ts == 4) {
+        if (a.C % 16 || a.Mp < a.Mt) return 2;
+        hipLaunchKernelGGL((wino_input_kernel<4, 4, true>), dim3(wino_blocks((long long)a.Mt * (a.C / 4))), dim3(wino_threads((long long)a.Mt * (a.C / 4))), 0, st, a);
+    } else if (a.v_s3) {
         if (a.ts != 6 || a.C % 32 || a.Mp < a.Mt) return 2;
         if (a.coop == 0) {      // A/B: the 4-channel form
             const long long wgs = ((long long)((a.Mt + 3) & ~3) * (a.C / 4) + WINO_THREADS / 8 - 1) / (WINO_THREADS / 8);
