@@ -44,14 +44,23 @@ typedef const __attribute__((address_space(1))) void s3_gptr_t;
 template <int N>
 __device__ __forceinline__ void s3_wait_vm() { __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14)); }
 
+template <bool UNUSED>
+__device__ __forceinline__ void s3_mfma(s3_f16 &c, const s3_bf8 &a, const s3_bf8 &b)
+{
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // NW waves per workgroup: 8 = 4 (m) x 2 (n) waves of 64 x BN/2 at two waves per SIMD (<= 256 registers each);
-//                         4 = 2 x 2 waves of 128 x BN/2, one wave per SIMD with the whole 512-entry register file: a third
-//                             fewer LDS fragment reads per MFMA (0.25 instead of 0.375 ds_read_b128) -- the reads are what
-//                             pulls the clock down (tools/s3_clock.sh: 2.26 GHz without them, 1.70 GHz with)
+//                         4 = 2 x 2 waves of 128 x BN/2, one wave per SIMD with the whole 512-entry register file (256 accumulators
+//                             in AGPRs): a third fewer LDS fragment reads per MFMA (0.25 instead of 0.375 ds_read_b128).  Built
+//                             with -DS3_WITH_4WAVES only (tools/micro/gemm_s3_bench.hip, S3_WAVES=4): with one read or DMA piece
+//                             placed between every two MFMAs it runs exactly as fast as the 8-wave form -- 5.10 vs 5.03 ms, 70 %
+//                             MFMA-busy at 1.63 GHz either way.  Two very different issue streams ending at the same busy share
+//                             and clock says the matrix pipe is being throttled (power), not starved
 //   ACT: LeakyReLU(p.slope) on the accumulators before the epilogue's stores (the 1x1 layers); a template parameter, so that
 //   the Winograd instances carry none of it
 template <int BN, int NW, bool ACT>
-__global__ __launch_bounds__(NW * 64) void wino_gemm_s3_kernel(GemmS3Args p)
+__device__ __forceinline__ void s3_body(const GemmS3Args &p)
 {
     constexpr int WM = NW / 2;                        // waves along m (two along n)
     constexpr int MB = S3_BM / (WM * 32);             // 32-high m blocks per wave
@@ -256,40 +265,48 @@ __global__ __launch_bounds__(NW * 64) void wino_gemm_s3_kernel(GemmS3Args p)
                 }
                 // the group's first MFMA goes ahead of the loads for the NEXT group: the wait the compiler puts in front of
                 // it (for this group's fragments, read one group ago) then does not cover those fresh loads
-                s3_f16 c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[2], v[0][0], acc[j][0], 0, 0, 0);
+                s3_mfma<false>(acc[j][0], u[2], v[0][0]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (j == NBW - 1) {
                     iss_go = iss.valid;                                  // refill the buffer this stage occupied, piecewise from here on
                     iss_buf = buf_issue;
                     if (iss_go) { buf_issue = buf_issue == S3_STAGES - 1 ? 0 : buf_issue + 1; ++n_ahead; }
-#pragma unroll
-                    for (int i = 0; i < MB; ++i)
-#pragma unroll
-                        for (int t3 = 0; t3 < 3; ++t3) vn[i][t3] = frag(sn, offV[i] + t3 * S3_BM * 32);
-#pragma unroll
-                    for (int t3 = 0; t3 < 3; ++t3) (j & 1 ? ua : ub)[t3] = frag(sn, offU[0] + t3 * BN * 32);
-                } else {
-#pragma unroll
-                    for (int t3 = 0; t3 < 3; ++t3) (j & 1 ? ua : ub)[t3] = frag(sb, offU[j + 1] + t3 * BN * 32);
                 }
-                {
-                    const int g = (j + 1) % NBW;                         // groups since the barrier: 0 = the barrier's own group
-                    constexpr int per = (PT + NBW - 1) / NBW, ng = (PT + per - 1) / per;   // pieces per group, groups that carry pieces
-                    if (g < ng && iss_go) {
-                        issue_pieces(iss_buf, g * per, g * per + per);
-                        if (g == ng - 1) { issue_done(); advance(iss); iss_go = false; }
+                // The group's other MFMAs -- six partial products per block, smallest first, consecutive MFMAs to DIFFERENT
+                // accumulators -- with the side work placed between them in source order and frozen there (sched_barrier): one
+                // LDS fragment read or one DMA piece per MFMA slot, so that the issuing wave never leaves the pipe idle for
+                // longer than one instruction (it matters when the wave has the SIMD to itself, NW = 4).
+                //   side work: next group's U fragments (3 reads; last group: the next stage's V and first U fragments,
+                //   3 MB + 3 reads), then this group's share of the DMA pieces
+                constexpr int per = (PT + NBW - 1) / NBW, ng = (PT + per - 1) / per;   // pieces per group, groups that carry pieces
+                const int g = (j + 1) % NBW;                             // groups since the barrier: 0 = the barrier's own group
+                const int n_reads = (j == NBW - 1) ? 3 * MB + 3 : 3;
+                const int n_side = n_reads + ((g < ng) ? per : 0);
+                auto side = [&](int k) {
+                    if (k < n_reads) {
+                        if (j == NBW - 1) {
+                            if (k < 3 * MB) vn[k / 3][k % 3] = frag(sn, offV[k / 3] + (k % 3) * S3_BM * 32);
+                            else (j & 1 ? ua : ub)[k - 3 * MB] = frag(sn, offU[0] + (k - 3 * MB) * BN * 32);
+                        } else
+                            (j & 1 ? ua : ub)[k] = frag(sb, offU[j + 1] + k * BN * 32);
+                    } else if (iss_go) {
+                        const int pc = g * per + (k - n_reads);
+                        issue_pieces(iss_buf, pc, pc + 1);
+                        if (g == ng - 1 && k == n_side - 1) { issue_done(); advance(iss); iss_go = false; }
                     }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // six partial products per block, smallest first; consecutive MFMAs go to DIFFERENT accumulators (a wave that
-                // has the SIMD to itself would otherwise wait out every MFMA's latency on the dependent chain)
-                acc[j][0] = c0;
-#pragma unroll
-                for (int pr = 0; pr < 6; ++pr) {
+                };
+                {
                     constexpr int UT[6] = {2, 1, 0, 1, 0, 0}, VT[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-                    for (int i = (pr == 0 ? 1 : 0); i < MB; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[UT[pr]], v[i][VT[pr]], acc[j][i], 0, 0, 0);
+                    for (int m = 1; m < 6 * MB; ++m) {
+                        if (m - 1 < n_side) side(m - 1);                 // (indices are compile-time constants after unrolling)
+                        const int pr = m / MB, i = m % MB;
+                        s3_mfma<false>(acc[j][i], u[UT[pr]], v[i][VT[pr]]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int kk = 6 * MB - 1; kk < 3 * MB + 3 + per; ++kk)    // (more side work than MFMA slots: MB = 2, last group)
+                        if (kk < n_side) side(kk);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -343,6 +360,20 @@ __global__ __launch_bounds__(NW * 64) void wino_gemm_s3_kernel(GemmS3Args p)
     }
 }
 
+template <int BN, int NW, bool ACT>
+__global__ __launch_bounds__(NW * 64) void wino_gemm_s3_kernel(GemmS3Args p)
+{
+    s3_body<BN, NW, ACT>(p);
+}
+#ifdef S3_WITH_4WAVES
+// the one-wave-per-SIMD form: told so, or the register allocator budgets for two waves and spills the accumulators
+template <int BN, bool ACT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_gemm_s3_kernel_w4(GemmS3Args p)
+{
+    s3_body<BN, 4, ACT>(p);
+}
+#endif
+
 // executed bf16 MFMA FLOPs of one launch (six partial products per multiply, whole tiles)
 double wino_gemm_s3_flops(const GemmS3Args &a) { return 12.0 * a.P * (double)a.Mt * a.K * a.N; }
 
@@ -388,8 +419,19 @@ int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
     if (grid > tiles) grid = tiles;
     const int nw = a.waves == 8 ? 8 : (a.waves == 4 ? 4 : S3_DEFAULT_WAVES);
     if (a.act) return wide ? s3_launch<256, 8, true>(st, a, grid) : s3_launch<128, 8, true>(st, a, grid);
-#ifdef S3_WITH_4WAVES      // the one-wave-per-SIMD form (micro-benchmark builds): measured slower, see the kernel's header
-    if (nw == 4) return wide ? s3_launch<256, 4, false>(st, a, grid) : s3_launch<128, 4, false>(st, a, grid);
+#ifdef S3_WITH_4WAVES      // the one-wave-per-SIMD form (micro-benchmark builds)
+    if (nw == 4) {
+        static PerDeviceOnce attr4[2];
+        const size_t lds = (size_t)S3_STAGES * (3 * BN * 32 + 3 * S3_BM * 32);
+        const void *fn = wide ? reinterpret_cast<const void *>(wino_gemm_s3_kernel_w4<256, false>) : reinterpret_cast<const void *>(wino_gemm_s3_kernel_w4<128, false>);
+        if (attr4[wide].first()) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+            attr4[wide].done();
+        }
+        if (wide) hipLaunchKernelGGL((wino_gemm_s3_kernel_w4<256, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((wino_gemm_s3_kernel_w4<128, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
 #endif
     (void)nw;
     return wide ? s3_launch<256, 8, false>(st, a, grid) : s3_launch<128, 8, false>(st, a, grid);
