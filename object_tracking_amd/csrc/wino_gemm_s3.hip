@@ -44,7 +44,6 @@ typedef const __attribute__((address_space(1))) void s3_gptr_t;
 template <int N>
 __device__ __forceinline__ void s3_wait_vm() { __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14)); }
 
-template <bool UNUSED>
 __device__ __forceinline__ void s3_mfma(s3_f16 &c, const s3_bf8 &a, const s3_bf8 &b)
 {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -265,7 +264,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                 }
                 // the group's first MFMA goes ahead of the loads for the NEXT group: the wait the compiler puts in front of
                 // it (for this group's fragments, read one group ago) then does not cover those fresh loads
-                s3_mfma<false>(acc[j][0], u[2], v[0][0]);
+                s3_mfma(acc[j][0], u[2], v[0][0]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (j == NBW - 1) {
                     iss_go = iss.valid;                                  // refill the buffer this stage occupied, piecewise from here on
@@ -301,7 +300,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                     for (int m = 1; m < 6 * MB; ++m) {
                         if (m - 1 < n_side) side(m - 1);                 // (indices are compile-time constants after unrolling)
                         const int pr = m / MB, i = m % MB;
-                        s3_mfma<false>(acc[j][i], u[UT[pr]], v[i][VT[pr]]);
+                        s3_mfma(acc[j][i], u[UT[pr]], v[i][VT[pr]]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll

@@ -1381,3 +1381,42 @@ def test_split_bf16_handover_to_1x1_layers(ctx, monkeypatch):
     assert chan_err(flat_c(outs["1"]), flat_c(outs["0"])) < 1e-4          # two roundings of the same network (measured 5e-5)
     ref_net, _, _ = orc.yolov2_forward(orc.normalize_u8(frames[:2]), layers, taps=())
     assert chan_err(flat_c(outs["1"][:2]), flat_c(ref_net)) < NET_TOL
+
+
+@pytest.mark.parametrize("tile", ["", "4"], ids=["projection_F6x6", "recurrent_F4x4"])
+@pytest.mark.parametrize("B,H,W,Cx,U", [(6, 13, 13, 64, 32), (50, 13, 13, 96, 64), (3, 19, 19, 128, 128)])
+def test_convlstm_step_split_bf16_gemm_vs_oracle(ctx, monkeypatch, B, H, W, Cx, U, tile):
+    """ConvLSTM2D step with one of its convolutions on the split-operand GEMM (DT_S3=2): with the default tile the input
+    projection as F(6x6); with DT_WINO_TILE=4 the recurrent convolution as F(4x4) with the gate update in its output transform
+    (wino_input_kernel<4,4,S3>, P = 36) -- the form the tracker's recurrence takes.  Against the oracle and against the fp32 MFMA
+    form of the same step."""
+    monkeypatch.setenv("DT_WINO", "2")
+    if tile:
+        monkeypatch.setenv("DT_WINO_TILE", tile)
+    rs = np.random.RandomState(B + U)
+    x = rs.randn(B, H, W, Cx).astype(np.float32)
+    h = (rs.randn(B, H, W, U) * .5).astype(np.float32); c = rs.randn(B, H, W, U).astype(np.float32)
+    Wk = (rs.randn(3, 3, Cx, 4 * U) * .05).astype(np.float32); Uk = (rs.randn(3, 3, U, 4 * U) * .05).astype(np.float32)
+    b = rs.randn(4 * U).astype(np.float32) * .1
+    rh, rc = orc.convlstm_step(x, h, c, Wk, Uk, b)
+    out = {}
+    for s3 in ("2", "0"):
+        monkeypatch.setenv("DT_S3", s3)
+        ctx.profile_reset(); ctx.profile_enable(True)
+        gh, gc = ctx.convlstm_step(dev(x, ctx), dev(h, ctx), dev(c, ctx), Wk, Uk, b)
+        ctx.profile_enable(False)
+        tag = "conv_gemm_s3:convlstm_step" if tile else "conv_gemm_s3:convlstm_xproj"
+        assert ctx.profile_read(tag)["launches"] == (1 if s3 == "2" else 0)
+        assert ctx.profile_read("conv_gemm_s3")["launches"] == (1 if s3 == "2" else 0)
+        out[s3] = (gh.cpu().numpy(), gc.cpu().numpy())
+        np.testing.assert_allclose(out[s3][0], rh, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(out[s3][1], rc, rtol=1e-4, atol=1e-4)
+    assert np.abs(out["2"][0] - out["0"][0]).max() < 1e-4 and np.abs(out["2"][1] - out["0"][1]).max() < 1e-4      # two roundings of one GEMM through F(6x6): measured 3e-5
+
+
+def test_tracker_recurrence_on_split_bf16_gemm(ctx, monkeypatch):
+    """A whole tracker forward (detector + ConvLSTM over T + 1x1 head) with every eligible GEMM forced onto the split kernel
+    (DT_S3=2, thresholds off) against the oracle chain -- the path the bench takes at 48 clips, at a size the oracle finishes."""
+    monkeypatch.setenv("DT_S3", "2")
+    test_track_forward_vs_oracle_small(ctx)
+    test_track_clips_boxes_and_ids_vs_oracle(ctx)
