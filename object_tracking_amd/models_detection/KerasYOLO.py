@@ -98,7 +98,7 @@ class NativeDetectorModel(object):
 
     def summary(self):
         o = self.owner
-        print("NativeDetectorModel: YOLOv2 %dx%dx3 -> %dx%dx%dx%d on %s (23 conv, fp32 MFMA implicit GEMM)" % (
+        print("NativeDetectorModel: YOLOv2 %dx%dx3 -> %dx%dx%dx%d on %s (23 conv, fp32 results: Winograd + MFMA GEMMs)" % (
             o.IMAGE_H, o.IMAGE_W, o.GRID_H, o.GRID_W, o.BOX, 5 + o.CLASS, self.ctx.device))
 
 
