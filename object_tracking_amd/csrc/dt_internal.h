@@ -169,11 +169,13 @@ struct GemmS3Args {
     const unsigned short *ones, *bias_s3;
     int act;
     float slope;
+    int half;                  // 0: the launcher chooses between 256-row tiles (one workgroup per CU) and 128-row tiles (two per CU); 1 / -1: force
     int waves;                 // 8 / 4 waves per workgroup (64 x BN/2 or 128 x BN/2 per wave); 0 = the default (Policy::s3_waves)
     unsigned long long *dbg;   // -DS3_TIMING builds of the micro-benchmark only: per-wave wait cycles; otherwise null
 };
 int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus);
 bool wino_gemm_s3_usable(int Mt, int K, int N);
+bool wino_gemm_s3_half_chosen(const GemmS3Args &a, int cus);
 double wino_gemm_s3_flops(const GemmS3Args &a);
 void wino_s3_split_host(float x, unsigned short t[3]);
 void wino_s3_pack_weights(const float *u, int P, int npad, int K, unsigned short *dst);
@@ -287,6 +289,7 @@ struct Policy {
     int s3 = 1;              // DT_S3: the F(6x6) layers' batched GEMMs on the bf16 matrix pipe with 3-term split operands (wino_gemm_s3.hip):
                              //        0 never (fp32 MFMA) / 1 where it wins (K >= s3_mink, GEMM rows >= s3_minrows) / 2 wherever the shape allows
     int s3_mink = 256, s3_minrows = 2048;   // DT_S3_MINK / DT_S3_MINROWS
+    int s3_half = 0;          // DT_S3_HALF: 128-row tiles / two workgroups per CU in the split GEMM: 0 where it needs fewer rounds (default) / 1 always (N % 256 == 0) / -1 never
     int s3_rec_minrows = 512; // DT_S3_REC_MINROWS: the ConvLSTM recurrent step's F(4x4) GEMM (gate update in its output transform) takes the split
                               //                    kernel from this many GEMM rows (48 clips at 13x13: 588); 0 = never
     int s3_1x1_mink = 512;   // DT_S3_1X1_MINK: ... only for 1x1 layers with at least this many input channels (conv_10 / 12 / 15 / 17): the producer's

@@ -467,6 +467,7 @@ void policy_from_env(Policy &p)
     p.s3_1x1 = geti("DT_S3_1X1", d.s3_1x1);
     p.s3_1x1_mink = geti("DT_S3_1X1_MINK", d.s3_1x1_mink);
     p.s3_rec_minrows = geti("DT_S3_REC_MINROWS", d.s3_rec_minrows);
+    p.s3_half = geti("DT_S3_HALF", d.s3_half);
     p.persist = geti("DT_PERSIST", d.persist);
     p.xcd_remap = geti("DT_XCD_REMAP", d.xcd_remap);
     p.tile_gn = geti("DT_TILE_GN", d.tile_gn);
@@ -657,12 +658,13 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
         GemmS3Args g;
         memset(&g, 0, sizeof(g));
         g.a = w.v_s3; g.b = u_s3; g.c = Mp; g.c_ps = (long long)mt * N; g.P = P; g.Mt = w.Mt; g.Mp = (int)mp; g.N = N; g.Np = npad;
-        g.K = cin; g.ldc = N;
+        g.K = cin; g.ldc = N; g.half = ctx->pol.s3_half;
         // flops = EXECUTED bf16 MFMA work (six partial products per multiply); bytes = V + U (three bf16 terms each) + M'
         ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), (double)P * (6.0 * mt * cin + 6.0 * (double)cin * N + 4.0 * (double)mt * N), tag);
         prof_direct_form(ctx, 2.0 * B * H * W * 9.0 * cin * N,
                          4.0 * ((double)B * H * W * cin + 9.0 * cin * N + (io.out ? (double)B * H * W * N : 0.0) +
                                 (io.out2 ? (double)B * H * W * N / 4.0 : 0.0)));
+        if (ctx->prof && !ctx->capturing) ctx->prof_tab[wino_gemm_s3_half_chosen(g, 0) ? "s3_tile:128x2" : "s3_tile:256"].launches += 1;
         const int rc = launch_wino_gemm_s3(ctx->stream, g, 0);
         if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: split-bf16 Winograd GEMM launch failed (rc=%d)", tag, rc);
     } else {
@@ -745,6 +747,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
         GemmS3Args g;
         memset(&g, 0, sizeof(g));
         g.a = ho->buf; g.b = L.wt_s3; g.c = out; g.c_ps = 0; g.P = 1; g.Mt = (int)M; g.Mp = ho->mp; g.N = L.cout; g.Np = L.npad;
+        g.half = ctx->pol.s3_half;
         g.K = L.cin; g.ldc = out_ld; g.ones = ctx->s3_ones; g.bias_s3 = L.bias_s3; g.act = slope != 1.0f; g.slope = slope;
         char tag[32];
         snprintf(tag, sizeof(tag), "conv_%d", L.idx);

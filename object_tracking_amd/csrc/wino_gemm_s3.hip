@@ -31,8 +31,6 @@ typedef __attribute__((address_space(3))) void s3_lptr_t;
 typedef const __attribute__((address_space(1))) void s3_gptr_t;
 
 #define S3_THREADS 512
-#define S3_BM 256
-#define S3_STAGES 3
 #ifndef S3_DEFAULT_WAVES
 #define S3_DEFAULT_WAVES 8
 #endif
@@ -58,23 +56,26 @@ __device__ __forceinline__ void s3_mfma(s3_f16 &c, const s3_bf8 &a, const s3_bf8
 //                             and clock says the matrix pipe is being throttled (power), not starved
 //   ACT: LeakyReLU(p.slope) on the accumulators before the epilogue's stores (the 1x1 layers); a template parameter, so that
 //   the Winograd instances carry none of it
-template <int BN, int NW, bool ACT>
+//   BM rows of V per tile, NS LDS stages: 256 x 3 (one workgroup per CU, 144 KiB) or 128 x 2 with four waves (72 KiB: TWO workgroups
+//   per CU, each with one wave per SIMD -- the same two waves per SIMD in all, but one workgroup's epilogue and barriers overlap
+//   the other's main loop, and 128-row tiles fit short GEMMs better: the recurrent step's 588 rows are 5 x 128 instead of 3 x 256)
+template <int BN, int NW, bool ACT, int BM = 256, int NS = 3>
 __device__ __forceinline__ void s3_body(const GemmS3Args &p)
 {
     constexpr int WM = NW / 2;                        // waves along m (two along n)
-    constexpr int MB = S3_BM / (WM * 32);             // 32-high m blocks per wave
+    constexpr int MB = BM / (WM * 32);             // 32-high m blocks per wave
     constexpr int NBW = BN / 64;                      // 32-wide n blocks per wave (BN/2 columns)
-    constexpr int PV = 8 / NW;                        // 32-row DMA pieces of a 256-row V region per wave
+    constexpr int PV = (BM / 32) / NW;                // 32-row DMA pieces of a BM-row V region per wave
     constexpr int PU = (BN / 32) / NW > 0 ? (BN / 32) / NW : 1;   // ... of a BN-row U region (BN = 128, NW = 8: waves 0..3 only)
     constexpr bool U_HALF = (BN / 32) < NW;           // only the first BN / 32 waves move U rows
     constexpr int PT = 3 * (PU + PV);                 // DMA instructions per wave per stage
     constexpr int OP_A = 3 * BN * 32;                 // bytes of U terms per stage
-    constexpr int STAGE = OP_A + 3 * S3_BM * 32;      // + V terms
+    constexpr int STAGE = OP_A + 3 * BM * 32;      // + V terms
     extern __shared__ __attribute__((aligned(16))) unsigned char s3_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int KB = p.K >> 4;
-    const int MT = (p.Mt + S3_BM - 1) / S3_BM, NT = p.N / BN;
+    const int MT = (p.Mt + BM - 1) / BM, NT = p.N / BN;
     const int ntiles = p.P * MT * NT;              // < 2^31 (launcher)
     // XCD-aware order: workgroup w runs on XCD w % 8; each XCD walks a contiguous range of the n-fastest tile order, so
     // the 32 tiles resident on an XCD share their V / U panels through that XCD's L2
@@ -92,7 +93,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
         const int r = L / NT;
         const int mt = r % MT;
         t.pz = r / MT;
-        t.m0 = mt * S3_BM; t.n0 = nt * BN;
+        t.m0 = mt * BM; t.n0 = nt * BN;
         t.a0 = (long long)t.pz * 3 * a_term + (long long)t.m0 * 16;
         t.b0 = (long long)t.pz * 3 * b_term + (long long)t.n0 * 16;
         return t;
@@ -127,7 +128,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
             for (int sp = 0; sp < PV; ++sp, ++k)
                 if (k >= lo && k < hi)
                     __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_a + t3 * ta + sp * 512),
-                                                     (s3_lptr_t *)(dst + OP_A + t3 * S3_BM * 32 + (wave * PV + sp) * 1024), 16, 0, 0);
+                                                     (s3_lptr_t *)(dst + OP_A + t3 * BM * 32 + (wave * PV + sp) * 1024), 16, 0, 0);
         }
     };
     auto issue_done = [&]() {
@@ -154,7 +155,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     auto advance = [&](Cursor &c) {
         ++c.kb;
         if (c.kb == KB && KBX > KB) {          // next: the bias stage of this tile
-            src_a = p.ones + (long long)(32 * PV * wave + lrow) * 16 + dgran * 8; ta = S3_BM * 16;
+            src_a = p.ones + (long long)(32 * PV * wave + lrow) * 16 + dgran * 8; ta = 256 * 16;      // p.ones is [3][256][16] whatever the tile height
             src_b = p.bias_s3 + (long long)(c.t.n0 + 32 * PU * wave + lrow) * 16 + dgran * 8; tb = (long long)p.Np * 16;
         } else if (c.kb == KBX) {
             c.kb = 0; c.L += G;
@@ -173,7 +174,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
         if (!iss.valid) return;
         issue_pieces(buf_issue, 0, PT);
         issue_done();
-        buf_issue = buf_issue == S3_STAGES - 1 ? 0 : buf_issue + 1;
+        buf_issue = buf_issue == NS - 1 ? 0 : buf_issue + 1;
         ++n_ahead;
         advance(iss);
     };
@@ -204,7 +205,8 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     };
 
     // prologue: three stages in flight, the first one's leading fragments in registers
-    issue_next(); issue_next(); issue_next();
+#pragma unroll
+    for (int q = 0; q < NS; ++q) issue_next();
     wait_dma(n_ahead - 1);
     if (!(S3_ABLATE & 4)) __builtin_amdgcn_s_barrier();
     s3_bf8 v[MB][3], vn[MB][3], ua[3], ub[3];
@@ -213,7 +215,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = frag(sb, offV[i] + t3 * S3_BM * 32);
+            for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = frag(sb, offV[i] + t3 * BM * 32);
 #pragma unroll
         for (int t3 = 0; t3 < 3; ++t3) ua[t3] = frag(sb, offU[0] + t3 * BN * 32);
     }
@@ -235,7 +237,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
 #pragma unroll 1
         for (int kb = 0; kb < KBX; ++kb) {
             const unsigned char *sb = s3_lds + buf_use * STAGE;
-            buf_use = buf_use == S3_STAGES - 1 ? 0 : buf_use + 1;
+            buf_use = buf_use == NS - 1 ? 0 : buf_use + 1;
             const unsigned char *sn = s3_lds + buf_use * STAGE;          // the stage after this one
 #pragma unroll
             for (int j = 0; j < NBW; ++j) {
@@ -269,7 +271,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                 if (j == NBW - 1) {
                     iss_go = iss.valid;                                  // refill the buffer this stage occupied, piecewise from here on
                     iss_buf = buf_issue;
-                    if (iss_go) { buf_issue = buf_issue == S3_STAGES - 1 ? 0 : buf_issue + 1; ++n_ahead; }
+                    if (iss_go) { buf_issue = buf_issue == NS - 1 ? 0 : buf_issue + 1; ++n_ahead; }
                 }
                 // The group's other MFMAs -- six partial products per block, smallest first, consecutive MFMAs to DIFFERENT
                 // accumulators -- with the side work placed between them in source order and frozen there (sched_barrier): one
@@ -284,7 +286,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                 auto side = [&](int k) {
                     if (k < n_reads) {
                         if (j == NBW - 1) {
-                            if (k < 3 * MB) vn[k / 3][k % 3] = frag(sn, offV[k / 3] + (k % 3) * S3_BM * 32);
+                            if (k < 3 * MB) vn[k / 3][k % 3] = frag(sn, offV[k / 3] + (k % 3) * BM * 32);
                             else (j & 1 ? ua : ub)[k - 3 * MB] = frag(sn, offU[0] + (k - 3 * MB) * BN * 32);
                         } else
                             (j & 1 ? ua : ub)[k] = frag(sb, offU[j + 1] + k * BN * 32);
@@ -364,6 +366,12 @@ __global__ __launch_bounds__(NW * 64) void wino_gemm_s3_kernel(GemmS3Args p)
 {
     s3_body<BN, NW, ACT>(p);
 }
+// the two-workgroups-per-CU form: 128-row tiles, four waves, two LDS stages
+template <int BN, bool ACT>      // (two waves per SIMD: without the attribute the allocator spreads over all 512 registers and only one workgroup fits)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm_s3_half_kernel(GemmS3Args p)
+{
+    s3_body<BN, 4, ACT, 128, 2>(p);
+}
 #ifdef S3_WITH_4WAVES
 // the one-wave-per-SIMD form: told so, or the register allocator budgets for two waves and spills the accumulators
 template <int BN, bool ACT>
@@ -385,7 +393,7 @@ template <int BN, int NW, bool ACT>
 static int s3_launch(hipStream_t st, const GemmS3Args &a, long long grid)
 {
     static PerDeviceOnce attr;
-    const size_t lds = (size_t)S3_STAGES * (3 * BN * 32 + 3 * S3_BM * 32);
+    const size_t lds = (size_t)3 * (3 * BN * 32 + 3 * 256 * 32);
     if (attr.first()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_kernel<BN, NW, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
         attr.done();
@@ -393,26 +401,66 @@ static int s3_launch(hipStream_t st, const GemmS3Args &a, long long grid)
     hipLaunchKernelGGL((wino_gemm_s3_kernel<BN, NW, ACT>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
+template <int BN, bool ACT>
+static int s3_launch_half(hipStream_t st, const GemmS3Args &a, long long grid)
+{
+    static PerDeviceOnce attr;
+    const size_t lds = (size_t)2 * (3 * BN * 32 + 3 * 128 * 32);
+    if (attr.first()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_half_kernel<BN, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        attr.done();
+    }
+    hipLaunchKernelGGL((wino_gemm_s3_half_kernel<BN, ACT>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+static int s3_cus(int cus)
+{
+    if (cus > 0) return cus;
+    static int cu_of[64];
+    static PerDeviceOnce once;
+    if (once.first()) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, once.dev) != hipSuccess) return 0;
+        cu_of[once.dev] = prop.multiProcessorCount;
+        once.done();
+    }
+    return cu_of[once.dev];
+}
+
+// which tile form launch_wino_gemm_s3 takes for these arguments (the profile records it; tests assert it)
+bool wino_gemm_s3_half_chosen(const GemmS3Args &a, int cus)
+{
+    cus = s3_cus(cus);
+    const bool wide = a.N % 256 == 0 && a.Np % 256 == 0;
+    if (!wide || cus <= 0) return false;
+    const long long tiles = (long long)a.P * ((a.Mt + 255) / 256) * (a.N / 256), tiles_h = (long long)a.P * ((a.Mt + 127) / 128) * (a.N / 256);
+    const long long rounds = (tiles + cus - 1) / cus, rounds_h = (tiles_h + 2 * cus - 1) / (2 * cus);
+    return a.half > 0 || (a.half == 0 && rounds <= 8 && rounds_h < rounds);
+}
 
 int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
 {
-    if (!wino_gemm_s3_usable(a.Mt, a.K, a.N) || a.Mp % S3_BM || a.Mp < a.Mt || a.ldc % 4 || a.P <= 0) return 2;
+    if (!wino_gemm_s3_usable(a.Mt, a.K, a.N) || a.Mp % 256 || a.Mp < a.Mt || a.ldc % 4 || a.P <= 0) return 2;
     if ((a.bias_s3 != nullptr) != (a.ones != nullptr)) return 2;
     const bool wide = a.N % 256 == 0 && a.Np % 256 == 0;
     if (!wide && a.Np % 128) return 2;
     const int BN = wide ? 256 : 128;
-    const long long tiles = (long long)a.P * ((a.Mt + S3_BM - 1) / S3_BM) * (a.N / BN);
-    if (tiles >= (1ll << 31) - 65536) return 2;
-    if (cus <= 0) {
-        static int cu_of[64];
-        static PerDeviceOnce once;
-        if (once.first()) {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, once.dev) != hipSuccess) return 1;
-            cu_of[once.dev] = prop.multiProcessorCount;
-            once.done();
-        }
-        cus = cu_of[once.dev];
+    const long long tiles = (long long)a.P * ((a.Mt + 255) / 256) * (a.N / BN);
+    const long long tiles_h = (long long)a.P * ((a.Mt + 127) / 128) * (a.N / BN);
+    if (tiles_h >= (1ll << 31) - 65536) return 2;
+    cus = s3_cus(cus);
+    if (cus <= 0) return 1;
+    // 256-row tiles, one workgroup per CU -- or 128-row tiles, two per CU (a round of either takes about the same time): the half
+    // form when it needs fewer rounds, i.e. for short GEMMs whose rows fill 128-row tiles better (the recurrent step at 48 clips:
+    // 588 rows = 5 x 128 or 3 x 256 -> 3 rounds instead of 4: 0.352 -> 0.312 ms).  With many tiles it loses: a 128-row tile stages
+    // 1.5x the operand bytes per MFMA (K = 1024: 4.88 -> 5.20 ms; K = 256, where overlapping one workgroup's epilogue with the other's
+    // main loop was the hope: 3.09 -> 3.25 ms).  a.half: 1 / -1 force it on / off (Policy::s3_half).
+    const bool half = wino_gemm_s3_half_chosen(a, cus);
+    if (half && wide) {
+        long long grid = 2ll * cus;
+        if (grid > tiles_h) grid = tiles_h;
+        return a.act ? s3_launch_half<256, true>(st, a, grid) : s3_launch_half<256, false>(st, a, grid);
     }
     long long grid = cus;      // one workgroup per CU (108 / 144 KiB of LDS), persistent over the tiles
     if (grid > tiles) grid = tiles;
@@ -421,7 +469,7 @@ int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
 #ifdef S3_WITH_4WAVES      // the one-wave-per-SIMD form (micro-benchmark builds)
     if (nw == 4) {
         static PerDeviceOnce attr4[2];
-        const size_t lds = (size_t)S3_STAGES * (3 * BN * 32 + 3 * S3_BM * 32);
+        const size_t lds = (size_t)3 * (3 * BN * 32 + 3 * 256 * 32);
         const void *fn = wide ? reinterpret_cast<const void *>(wino_gemm_s3_kernel_w4<256, false>) : reinterpret_cast<const void *>(wino_gemm_s3_kernel_w4<128, false>);
         if (attr4[wide].first()) {
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;

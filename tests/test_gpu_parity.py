@@ -1279,11 +1279,13 @@ def _conv_case(rs, B, H, W, Cin, Cout, heavy_tail=False):
     (40, 26, 26, 32, 128, 1),    # several row tiles (Mt > 256), the shortest K the kernel takes (2 stages), pooled
     (7, 12, 18, 96, 384, 0),     # K = 6 stages, N = 3 x 128
 ])
-def test_conv2d_split_bf16_gemm_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool):
+@pytest.mark.parametrize("half", ["0", "1"], ids=["tile256", "tile128x2"])
+def test_conv2d_split_bf16_gemm_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool, half):
     """The split-operand GEMM (DT_S3=2: wherever the shape allows) against the oracle AND against the fp32 MFMA path of
     the same layer: the two differ by no more than the fp32 path differs from the oracle."""
     monkeypatch.setenv("DT_WINO", "2")
     monkeypatch.setenv("DT_WINO_TILE", "6")
+    monkeypatch.setenv("DT_S3_HALF", half)      # 1: the 128-row-tile / two-workgroups-per-CU form wherever N % 256 == 0
     x, w, b = _conv_case(np.random.RandomState(B * 7 + Cin + Cout), B, H, W, Cin, Cout)
     ref = orc.conv2d(x, w, b)
     ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
@@ -1295,6 +1297,8 @@ def test_conv2d_split_bf16_gemm_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, 
         ctx.profile_enable(False)
         assert ctx.profile_read("conv_gemm_s3")["launches"] == (1 if s3 == "2" else 0)
         assert ctx.profile_read("conv_igemm")["launches"] == (0 if s3 == "2" else 1)
+        if s3 == "2":
+            assert ctx.profile_read("s3_tile:128x2")["launches"] == (1 if (half == "1" and Cout % 256 == 0) else 0)
         outs[s3] = [g.cpu().numpy() for g in (got if pool == 2 else (got,))]
     refs = {0: [ref], 1: [orc.maxpool2(ref)], 2: [ref, orc.maxpool2(ref)]}[pool]
     for a, f, r in zip(outs["2"], outs["0"], refs):
@@ -1391,6 +1395,7 @@ def test_convlstm_step_split_bf16_gemm_vs_oracle(ctx, monkeypatch, B, H, W, Cx, 
     (wino_input_kernel<4,4,S3>, P = 36) -- the form the tracker's recurrence takes.  Against the oracle and against the fp32 MFMA
     form of the same step."""
     monkeypatch.setenv("DT_WINO", "2")
+    monkeypatch.setenv("DT_S3_HALF", "1" if tile else "0")      # the recurrent form also through the 128-row tiles
     if tile:
         monkeypatch.setenv("DT_WINO_TILE", tile)
     rs = np.random.RandomState(B + U)
@@ -1418,5 +1423,6 @@ def test_tracker_recurrence_on_split_bf16_gemm(ctx, monkeypatch):
     """A whole tracker forward (detector + ConvLSTM over T + 1x1 head) with every eligible GEMM forced onto the split kernel
     (DT_S3=2, thresholds off) against the oracle chain -- the path the bench takes at 48 clips, at a size the oracle finishes."""
     monkeypatch.setenv("DT_S3", "2")
+    monkeypatch.setenv("DT_S3_HALF", "1")
     test_track_forward_vs_oracle_small(ctx)
     test_track_clips_boxes_and_ids_vs_oracle(ctx)

@@ -47,6 +47,7 @@ static void run(int P, int Mt, int K, int N, int check_rows, int iters)
     a.a = dV; a.b = dU; a.c = dC; a.c_ps = (long long)Mt * N; a.P = P; a.Mt = Mt; a.Mp = Mp; a.N = N; a.Np = Np; a.K = K; a.ldc = N;
     a.dbg = nullptr;
     a.waves = getenv("S3_WAVES") ? atoi(getenv("S3_WAVES")) : 0;
+    a.half = getenv("S3_HALF") ? atoi(getenv("S3_HALF")) : 0;
     a.act = getenv("S3_ACT") ? 1 : 0; a.slope = 0.1f;      // timing only (the check below expects the plain product)
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
@@ -106,6 +107,7 @@ static void run(int P, int Mt, int K, int N, int check_rows, int iters)
 int main(int argc, char **argv)
 {
     if (argc > 1 && argv[1][0] == '2') { run(64, 7840, 1024, 1024, 1, 5); return 0; }      // PMC runs: one shape
+    if (argc > 1 && argv[1][0] == '3') { run(64, 30240, 256, 512, 8, 5); run(36, 588, 512, 2048, 32, 20); run(64, 7840, 1024, 1024, 4, 5); return 0; }   // half-tile A/B
     if (argc > 1) { run(64, 7840, 1024, 1024, 1, 5); run(64, 30240, 256, 512, 1, 5); run(64, 116640, 128, 256, 1, 3); return 0; }   // probes: timing only
     run(4, 300, 64, 256, 64, 3);          // ragged Mt, short K
     run(3, 700, 128, 128, 64, 3);         // BN = 128
@@ -113,5 +115,6 @@ int main(int argc, char **argv)
     run(64, 7840, 512, 1024, 8, 5);       // conv_14 / 16 / 18
     run(64, 30240, 256, 512, 8, 5);       // conv_9 / 11 / 13   (26x26: 21 tiles per frame)
     run(64, 116640, 128, 256, 4, 3);      // conv_6 / conv_8   (52x52: 81 tiles per frame)
+    run(36, 588, 512, 2048, 32, 20);      // the ConvLSTM recurrent step at 48 clips (F(4x4): 36 positions)
     return 0;
 }
