@@ -57,7 +57,7 @@ def main():
     out["traffic_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
     # the whole conv family of ONE step (the probe runs the path twice: head calibration + the measured step):
     # MFMA GEMMs + Winograd transforms + the fused conv_2 / conv_3 / conv_5 kernels (conv_1 is listed separately: it was never part of this sum)
-    fam2 = lambda k: any(t in k for t in ("wino_gemm_s3_kernel", "conv_igemm_f32", "wino_input", "wino_output", "wino2_fused", "wino4_fused", "wino4s_fused", "splitk_reduce"))
+    fam2 = lambda k: any(t in k for t in ("wino_gemm_s3", "conv_igemm_f32", "wino_input", "wino_output", "wino2_fused", "wino4_fused", "wino4s_fused", "splitk_reduce"))
     passes = 2.0
     out["conv_family_fetch_bytes_per_step"] = sum(v for _, k, v in fetch if fam2(k)) * 1024.0 * f_read / passes
     out["conv_family_write_bytes_per_step"] = sum(v for _, k, v in write if fam2(k)) * 1024.0 * f_write / passes
