@@ -1,26 +1,31 @@
-// wino_gemm_s3.hip -- the P batched GEMMs  M'[p] = V[p] (Mt x K)  *  U[p]^T (N x K)  of the F(6x6,3x3) layers on the
-// BF16 matrix pipe at fp32 accuracy (the arithmetic of nn/yolo.py:conv_6..conv_22 and of nn/tracker.py's input
-// convolution once they are in Winograd form).
+// wino_gemm_s3.hip -- the batched GEMMs  M'[p] = V[p] (Mt x K)  *  U[p]^T (N x K)  of the Winograd-form layers on the BF16
+// matrix pipe at fp32 accuracy: the arithmetic of the reference's Conv2D layers conv_9 .. conv_22
+// (models_detection/KerasYOLO.py:326-393), of ConvLSTM2D's input and recurrent convolutions
+// (models_tracking/MultiObjDetTracker.py:160-189) once they are in F(6x6,3x3) / F(4x4,3x3) form, and of four 1x1 Conv2D layers
+// (conv_10 / 12 / 15 / 17) as plain GEMMs (P = 1).  DESIGN.md section 4.2f.
 //
 // gfx950 has no fp32-rate shortcut (v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate, no xf32), so each fp32
 // operand is carried as THREE bf16 terms   x = x1 + x2 + x3   (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2):
 // 3 x 8 significand bits cover fp32's 24, the split is exact up to the last term's rounding, |x - x1 - x2 - x3| <= 2^-25 |x|)
 // and a product is the six partial products of weight 2^0, 2^-8, 2^-16
 //      u*v ~= u1 v1 + (u1 v2 + u2 v1) + (u1 v3 + u2 v2 + u3 v1)            (dropped: u2 v3, u3 v2, u3 v3 <= 2^-24 |u v|)
-// accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest terms first.  Six bf16 MFMAs do the work of sixteen fp32
-// MFMAs' cycles (2.67x), with errors at the level of fp32's own product rounding (tests/test_gpu_parity.py:
-// the error against float64 is no larger than the fp32 MFMA path's).
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest terms first.  Per 32x32 block and 16 k: six bf16 MFMAs of 32
+// cycles instead of eight fp32 MFMAs of 64 (2.67x fewer matrix-pipe cycles), with errors at the level of fp32's own product
+// rounding (tests/test_gpu_parity.py::test_split_bf16_gemm_error_against_float64: not above the fp32 MFMA path's).
 //
-// Operands arrive ALREADY split, from the producers: V from the input transform (winograd.hip, split form), U packed at
-// load time (wino_s3_pack_weights).  Both are K-blocked so that the 16-deep stage of a 256-row tile is ONE contiguous
-// 8 KiB run per term:     [p][term 3][K/16][rows][16] bf16.
+// Operands arrive ALREADY split, from their producers: V from the input transforms (winograd.hip: wino_input_s3_kernel,
+// wino_input_kernel<4,4,S3>), the 1x1 layers' activations from the producing layer's output transform
+// (wino_output_s3_kernel), U split on the device at load time (wino_s3_pack_kernel).  All are K-blocked so that the 16-deep
+// stage of a 256-row tile is ONE contiguous 8 KiB run per term:     [p][term 3][K/16][rows][16] bf16.
 //
-// Kernel: persistent, one 512-thread workgroup per CU; tile = 256 rows of V x BN (256 | 128) rows of U; k in stages of 16
-// through a 3-deep LDS ring filled by global_load_lds_dwordx4 (6 x 1 KiB pieces per wave per stage) -- the next tile's
-// first two stages are in flight during a tile's epilogue.  Wave (wm, wn) owns 64 rows of V x BN/2 rows of U; the MFMA
-// takes U as its A operand, so a lane holds 4 consecutive n of one m and the epilogue stores 16 B.
+// Kernel: persistent; tile = BM rows of V x BN (256 | 128) rows of U; k in stages of 16 through an LDS ring filled by
+// global_load_lds_dwordx4 in 1 KiB pieces, the next tile's first stages in flight during a tile's epilogue.  Two forms:
+// BM = 256, eight waves, three stages (144 KiB, one workgroup per CU) -- or BM = 128, four waves, two stages (72 KiB, two
+// workgroups per CU) where that saves a round of tiles.  Wave (wm, wn) owns 64 rows of V x BN/2 rows of U; the MFMA takes U
+// as its A operand, so a lane holds 4 consecutive n of one m and the epilogue stores 16 B.
 // LDS image of one (operand, term, stage): [row][2 granules of 8 bf16], granule index XOR (row >> 3) & 1 -- with the
-// ds_read_b128 lane groups of gfx950 ({0-3,12-15,20-27}, ...) every group then covers all 64 banks once.
+// ds_read_b128 lane groups of gfx950 ({0-3,12-15,20-27}, ...) every group then covers all 64 banks once
+// (SQ_LDS_BANK_CONFLICT = 0 measured).
 #include "dt_internal.h"
 #include <cstring>
 
@@ -30,7 +35,6 @@ typedef float s3_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void s3_lptr_t;
 typedef const __attribute__((address_space(1))) void s3_gptr_t;
 
-#define S3_THREADS 512
 #ifndef S3_DEFAULT_WAVES
 #define S3_DEFAULT_WAVES 8
 #endif
