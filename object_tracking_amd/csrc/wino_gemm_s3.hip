@@ -1,6 +1,6 @@
 // wino_gemm_s3.hip -- the batched GEMMs  M'[p] = V[p] (Mt x K)  *  U[p]^T (N x K)  of the Winograd-form layers on the BF16
 // matrix pipe at fp32 accuracy: the arithmetic of the reference's Conv2D layers conv_9 .. conv_22
-// (models_detection/KerasYOLO.py:326-393), of ConvLSTM2D's input and recurrent convolutions
+// (models_detection/KerasYOLO.py:323-396), of ConvLSTM2D's input and recurrent convolutions
 // (models_tracking/MultiObjDetTracker.py:160-189) once they are in F(6x6,3x3) / F(4x4,3x3) form, and of four 1x1 Conv2D layers
 // (conv_10 / 12 / 15 / 17) as plain GEMMs (P = 1).  DESIGN.md section 4.2f.
 //
