@@ -185,19 +185,29 @@ def _time_steps(step, warmup, steps):
     return (time.perf_counter() - t0) / steps
 
 
-def track_extra(device, size, clips, T, boxes, steps=3):
+def track_extra(device, size, clips, T, boxes, steps=3, env=None, what=None):
     """BASELINE.json configs[4]'s single-GPU shard under the same clock: MultiObjDetTracker at size x size with
-    ~`boxes` candidate boxes per frame, `clips` clips x T frames per step, its own context."""
+    ~`boxes` candidate boxes per frame, `clips` clips x T frames per step, its own context.  `env`: policy knobs the
+    context is created under (read once in dt_create), e.g. {"DT_S3": "0"} = every GEMM on the fp32 MFMA instruction."""
     frames = make_frames(clips, T, size, size, device, seed0=7000)
-    trk, _, _ = build_tracker(size, size, T, boxes, frames)
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        trk, _, _ = build_tracker(size, size, T, boxes, frames)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     cap = max(128, 2 * boxes)
     res = {}
 
     def step():
         res["r"] = trk.track_clips(frames, cap=cap)
     sec = _time_steps(step, 2, steps)
-    return {"workload": "BASELINE.json configs[4] on one GPU: MultiObjDetTracker %dx%d, %d clips x %d frames per step, "
-                        "head calibrated to %d candidate boxes per frame" % (size, size, clips, T, boxes),
+    return {"workload": what or "BASELINE.json configs[4] on one GPU: MultiObjDetTracker %dx%d, %d clips x %d frames per step, "
+                                "head calibrated to %d candidate boxes per frame" % (size, size, clips, T, boxes),
             "ms_per_step": 1e3 * sec, "frames_per_s": clips * T / sec,
             "boxes_per_frame": float(res["r"]["counts"].float().mean().item())}
 
@@ -582,7 +592,13 @@ def _run():
             out["extra"] = {}
             for key, fn in (("detect_batch8", lambda: detect_batch8_extra(device, H, W, seed0=4242)),
                             ("track_608_128boxes", lambda: track_extra(device, 608, 24, args.T, 128)),
-                            ("tiny_T64", lambda: tiny_extra(device, H, W, 32))):
+                            ("tiny_T64", lambda: tiny_extra(device, H, W, 32)),
+                            # the headline workload with the split-bf16 GEMMs switched off (DT_S3=0: v_mfma_f32_32x32x2_f32
+                            # everywhere), same run, same clock: what the bf16-pipe arithmetic buys
+                            ("track_fp32_mfma_only", lambda: track_extra(
+                                device, args.size, args.clips, args.T, args.boxes, env={"DT_S3": "0"},
+                                what="the headline workload (BASELINE.json configs[2], %d clips x %d frames) with DT_S3=0: every GEMM on "
+                                     "the fp32 MFMA instruction" % (args.clips, args.T)))):
                 out["extra"][key] = fn()
                 gc.collect()                      # each extra owns a context with its own workspaces: release them
                 torch.cuda.empty_cache()
