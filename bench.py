@@ -23,9 +23,12 @@ so that ~32 boxes/frame survive (the "32 tracks" of configs[2]); frames are
 low-frequency backgrounds with moving rectangles.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     -- the fp32 MFMA implicit-GEMM conv kernel family: algorithmic
-                  FLOP / HIP-event time of its launches inside the timed region,
-                  against the 157.3 TFLOP/s fp32 matrix peak of MI355X
+  roofline     -- achieved / peak / frac / traffic of the DOMINANT kernel family (the one with the most HIP-event
+                  time inside the timed region; with the default policy wino_gemm_s3_kernel: executed bf16 MFMA
+                  FLOPs against the 2.5 PFLOP/s dense bf16 peak of MI355X), and under roofline.families one
+                  self-contained block per conv kernel family (wino_gemm_s3 / conv_igemm_f32 against the 157.3
+                  TFLOP/s fp32 matrix peak / wino4s_fused / conv1_mfma): launches, time, executed and
+                  direct-form FLOPs of the layers THOSE launches computed, bytes, PMC traffic
   cpu_baseline -- the CPU oracle ("port") timed on a bounded sample on this host.
 """
 import argparse
@@ -45,7 +48,7 @@ import torch.distributed as dist
 import object_tracking_amd  # noqa: F401
 from models_detection.KerasYOLO import KerasYOLO
 from models_tracking.MultiObjDetTracker import MultiObjDetTracker
-from parallel import gather_detections, init_from_env, track_clips_frame_sharded
+from parallel import frame_shard_stage_ms, gather_detections, init_from_env, track_clips_frame_sharded
 from utility import synth
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
@@ -405,6 +408,16 @@ def _run():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # frame-shard: where each rank spent the last step -- the part spread over all ranks (detector + input projection) vs the
+    # owner stage (row wait + recurrence + decode on the clips it owns; a rank that owns none idles there)
+    stage_ms = None
+    if args.workload == "track" and args.shard == "frame" and world > 1:
+        mine = frame_shard_stage_ms(xstats)
+        rec = [None] * world
+        dist.all_gather_object(rec, {"rank": rank, "clips_owned": xstats.get("clips_owned"),
+                                     "sharded_stage_ms": mine[0] if mine else None, "owner_stage_ms": mine[1] if mine else None})
+        stage_ms = rec
+
     kern = {}
     for name in ("conv_gemm_s3", "conv_igemm", "conv_fused", "wino_input", "wino_output", "conv1_direct", "convlstm_gates", "decode_nms", "associate", "splitk_reduce", "pool",
                  "lstm_step", "misc"):
@@ -413,33 +426,74 @@ def _run():
             kern[name] = dict(launches=p["launches"], ms_per_step=p["ms"] / args.steps,
                               tflops=(p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["ms"] > 0 else None,
                               gbs=(p["bytes"] / (p["ms"] * 1e-3) / 1e9) if p["ms"] > 0 else None)
+    steps = max(1, args.steps)
     ig = ctx.profile_read("conv_igemm")
-    achieved_f32 = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-    # the F(6x6) layers' batched GEMMs: bf16 MFMAs on 3-term split fp32 operands (six partial products per multiply);
-    # flops = EXECUTED bf16 FLOPs, so /6 is the fp32 multiply-add rate the layer sees
     s3 = ctx.profile_read("conv_gemm_s3")
-    achieved_s3 = s3["flops"] / (s3["ms"] * 1e-3) / 1e12 if s3["ms"] > 0 else 0.0
-    dominant_s3 = s3["ms"] >= ig["ms"]
-    # direct-form FLOPs (SURVEY.md 8d figures) of the layers those launches computed; > executed where the
-    # wide 3x3 layers run in Winograd form.  Time base: the MFMA kernel alone / with its transform kernels.
-    direct_form = ctx.profile_read("conv_direct_form")["flops"]
-    direct_form_bytes = ctx.profile_read("conv_direct_form")["bytes"]
-    wino_in, wino_out = ctx.profile_read("wino_input"), ctx.profile_read("wino_output")
-    wino_ms = wino_in["ms"] + wino_out["ms"]
     fused = ctx.profile_read("conv_fused")
     conv1 = ctx.profile_read("conv1_direct")
-    direct_form_fused = ctx.profile_read("conv_direct_form_fused")["flops"]
-    # whole conv path: every MFMA FLOP the conv kernels execute (batched / direct GEMMs, the fused Winograd kernels,
-    # conv_1) over ALL the time the conv path takes (those kernels + the Winograd transform kernels)
+    wino_in, wino_out = ctx.profile_read("wino_input"), ctx.profile_read("wino_output")
+    wino_ms = wino_in["ms"] + wino_out["ms"]
+    # direct-form work (2*M*K*N of the reference's layer; in + W + out fp32 bytes) of the layers EACH family's
+    # launches computed -- booked per family by the library (network.hip:prof_direct_form), never across families
+    df = {"conv_gemm_s3": ctx.profile_read("conv_direct_form_s3"), "conv_igemm": ctx.profile_read("conv_direct_form"),
+          "conv_fused": ctx.profile_read("conv_direct_form_fused"),
+          "conv1_direct": {"flops": conv1["flops"], "bytes": conv1["bytes"]}}      # conv_1 runs in direct form: executed = algorithmic
+    tr = load_traffic(args.clips, args.T, args.size) if args.workload == "track" else None
+    fam_traffic = (tr[1].get("family_bytes_per_step") or {}) if tr is not None else {}
+
+    def family(key, prof, kernel, instruction, peak, tkey):
+        """one kernel family: everything from ITS launches, ITS HIP-event time and ITS PMC bytes"""
+        if prof["ms"] <= 0:
+            return None
+        sec, n = prof["ms"] * 1e-3, max(1, prof["launches"])
+        d = {"kernel": kernel, "instruction": instruction, "peak_tflops": peak,
+             "launches_per_step": prof["launches"] / steps, "ms_per_step": prof["ms"] / steps, "avg_launch_ms": prof["ms"] / n,
+             "executed_tflop_per_step": prof["flops"] / steps / 1e12, "executed_gflop_per_launch": prof["flops"] / n / 1e9,
+             "achieved": prof["flops"] / sec / 1e12, "frac": prof["flops"] / sec / 1e12 / peak,
+             "algorithmic_tflop_per_step": df[key]["flops"] / steps / 1e12, "algorithmic_gflop_per_launch": df[key]["flops"] / n / 1e9,
+             "achieved_algorithmic": df[key]["flops"] / sec / 1e12,
+             "direct_form_bytes_per_step": df[key]["bytes"] / steps,
+             "implementation_bytes_per_launch": prof["bytes"] / n, "implementation_GBps": prof["bytes"] / sec / 1e9,
+             "traffic_bytes_per_launch": None, "traffic_bytes_per_step": None}
+        if tkey in fam_traffic:
+            d["traffic_bytes_per_step"] = fam_traffic[tkey]
+            d["traffic_bytes_per_launch"] = fam_traffic[tkey] / (prof["launches"] / steps)
+        return d
+
+    families = {
+        "wino_gemm_s3": family("conv_gemm_s3", s3, "wino_gemm_s3_kernel / wino_gemm_s3_half_kernel (F(6x6) / F(4x4) batched GEMMs, 1x1 layers behind them)",
+                               "v_mfma_f32_32x32x16_bf16 on 3-term split fp32 operands, six per fp32 multiply-add, fp32 accumulate",
+                               PEAK_BF16_MFMA_TFLOPS, "wino_gemm_s3"),
+        "conv_igemm_f32": family("conv_igemm", ig, "conv_igemm_f32 (implicit GEMM: 1x1 layers with short K or N, the K = 128 Winograd GEMMs of conv_6 / conv_8)",
+                                 "v_mfma_f32_32x32x2_f32", PEAK_F32_MFMA_TFLOPS, "conv_igemm_f32"),
+        "wino4s_fused": family("conv_fused", fused, "wino4s_fused_kernel (conv_2 / conv_3 / conv_5: fused F(4x4,3x3))", "v_mfma_f32_16x16x4_f32",
+                               PEAK_F32_MFMA_TFLOPS, "wino4s_fused"),
+        "conv1_mfma": family("conv1_direct", conv1, "conv1_mfma_kernel (conv_1 + x/255 + BN + LeakyReLU + 2x2 max)", "v_mfma_f32_32x32x2_f32",
+                             PEAK_F32_MFMA_TFLOPS, "conv1_mfma"),
+    }
+    if families["wino_gemm_s3"]:
+        families["wino_gemm_s3"]["fp32_equivalent_tflops"] = families["wino_gemm_s3"]["achieved"] / 6.0
+        families["wino_gemm_s3"]["fp32_equivalent_over_fp32_mfma_peak"] = families["wino_gemm_s3"]["achieved"] / 6.0 / PEAK_F32_MFMA_TFLOPS
+    transforms = None if wino_ms <= 0 else {
+        "kernel": "wino_input_* / wino_output_* (Winograd transforms around the batched GEMMs)", "bound": "hbm", "peak_GBps": PEAK_HBM_GBS,
+        "launches_per_step": (wino_in["launches"] + wino_out["launches"]) / steps, "ms_per_step": wino_ms / steps,
+        "input_ms_per_step": wino_in["ms"] / steps, "output_ms_per_step": wino_out["ms"] / steps,
+        "implementation_GBps": (wino_in["bytes"] + wino_out["bytes"]) / (wino_ms * 1e-3) / 1e9,
+        "frac_of_8TBps": (wino_in["bytes"] + wino_out["bytes"]) / (wino_ms * 1e-3) / 8e12,
+        "implementation_bytes_per_step": (wino_in["bytes"] + wino_out["bytes"]) / steps,
+        "traffic_bytes_per_step": fam_traffic.get("wino_transforms")}
+    dominant = max((k for k in families if families[k]), key=lambda k: families[k]["ms_per_step"], default=None)
+    # whole conv path: time the matrix pipe would need AT ITS PEAKS for everything the conv kernels execute (bf16 and fp32
+    # instructions have different peaks) / the time the conv path takes, transforms included
     conv_path_ms = s3["ms"] + ig["ms"] + fused["ms"] + conv1["ms"] + wino_ms
     conv_path_flops = ig["flops"] + fused["flops"] + conv1["flops"]        # executed on the fp32 MFMA instructions
-    # time the matrix pipe would need at its peaks for everything the conv path executes (bf16 and fp32 instructions
-    # have different peaks) / the time the conv path takes, transforms included
     conv_path_pipe_frac = ((s3["flops"] / (PEAK_BF16_MFMA_TFLOPS * 1e12) + conv_path_flops / (PEAK_F32_MFMA_TFLOPS * 1e12)) /
                            (conv_path_ms * 1e-3)) if conv_path_ms > 0 else None
-    # split the family's launches by arithmetic intensity (executed FLOP per algorithmic byte): below the ridge
-    # of the chip (157.3 TFLOP/s over ~6.3 TB/s achievable = 25 FLOP/B; 40 used as the class boundary) a launch is
-    # HBM-bound whatever the kernel does, and is priced against the HBM roof instead
+    direct_form_all = sum(v["flops"] for v in df.values())
+    direct_form_bytes_all = sum(v["bytes"] for v in df.values())
+    # conv_igemm_f32's launches by arithmetic intensity (executed FLOP per algorithmic byte): below the ridge of the chip
+    # (157.3 TFLOP/s over ~6.3 TB/s achievable = 25 FLOP/B; 40 used as the class boundary) a launch is HBM-bound whatever
+    # the kernel does, and is priced against the HBM roof instead
     regimes = {"mfma": [0.0, 0.0, 0.0, []], "hbm": [0.0, 0.0, 0.0, []]}
     for name in ctx.profile_names():
         if not name.startswith("conv_igemm:"):
@@ -449,15 +503,28 @@ def _run():
             continue
         r = regimes["mfma" if p["flops"] / p["bytes"] >= 40.0 else "hbm"]
         r[0] += p["flops"]; r[1] += p["bytes"]; r[2] += p["ms"]; r[3].append(name.split(":", 1)[1])
-    s3_layers = {}
-    for name in ctx.profile_names():
-        if name.startswith("conv_gemm_s3:"):
-            p = ctx.profile_read(name)
-            if p["ms"] > 0:
-                s3_layers[name.split(":", 1)[1]] = {"ms_per_step": p["ms"] / args.steps,
-                                                    "executed_bf16_tflops": p["flops"] / (p["ms"] * 1e-3) / 1e12,
-                                                    "fp32_equivalent_tflops": p["flops"] / 6.0 / (p["ms"] * 1e-3) / 1e12,
-                                                    "algorithmic_GBps": p["bytes"] / (p["ms"] * 1e-3) / 1e9}
+    if families["conv_igemm_f32"]:
+        families["conv_igemm_f32"]["mfma_bound_launches"] = None if regimes["mfma"][2] <= 0 else {
+            "layers": sorted(regimes["mfma"][3]), "ms_per_step": regimes["mfma"][2] / steps,
+            "achieved": regimes["mfma"][0] / (regimes["mfma"][2] * 1e-3) / 1e12,
+            "frac": regimes["mfma"][0] / (regimes["mfma"][2] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+        families["conv_igemm_f32"]["hbm_bound_launches"] = None if regimes["hbm"][2] <= 0 else {
+            "layers": sorted(regimes["hbm"][3]), "ms_per_step": regimes["hbm"][2] / steps,
+            "achieved_GBps": regimes["hbm"][1] / (regimes["hbm"][2] * 1e-3) / 1e9,
+            "frac_of_8TBps": regimes["hbm"][1] / (regimes["hbm"][2] * 1e-3) / 8e12,
+            "executed_tflops": regimes["hbm"][0] / (regimes["hbm"][2] * 1e-3) / 1e12}
+    for key, fam in (("conv_gemm_s3:", "wino_gemm_s3"), ("conv_igemm:", "conv_igemm_f32"), ("conv_fused:", "wino4s_fused")):
+        if not families[fam]:
+            continue
+        layers = {}
+        for name in ctx.profile_names():
+            if name.startswith(key):
+                p = ctx.profile_read(name)
+                if p["ms"] > 0:
+                    layers[name.split(":", 1)[1]] = {"ms_per_step": p["ms"] / steps, "launches_per_step": p["launches"] / steps,
+                                                    "executed_tflops": p["flops"] / (p["ms"] * 1e-3) / 1e12,
+                                                    "implementation_GBps": p["bytes"] / (p["ms"] * 1e-3) / 1e9}
+        families[fam]["layers"] = layers
     boxes_per_frame = None
     if args.workload == "track" and res is not None and isinstance(res, dict):
         boxes_per_frame = float(res["counts"].float().mean().item())
@@ -501,92 +568,44 @@ def _run():
             "whole_path_tflops": fps * gflop_per_frame / 1e3, "h2d_included": bool(args.h2d),
             "ranks_seen": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
             "exchange_bytes_received_per_step_rank0": int(xstats.get("bytes_received", 0)),
-            "roofline": {"bound": "mfma",
-                         "kernel": ("wino_gemm_s3_kernel (v_mfma_f32_32x32x16_bf16 on 3-term split fp32 operands: six bf16 products per "
-                                    "fp32 multiply, fp32 accumulate -- the F(6x6,3x3) layers' batched GEMMs)") if dominant_s3 else
-                                   "conv_igemm_f32 (v_mfma_f32_32x32x2_f32 implicit GEMM)",
-                         "achieved": achieved_s3 if dominant_s3 else achieved_f32,
-                         "peak": PEAK_BF16_MFMA_TFLOPS if dominant_s3 else PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (achieved_s3 / PEAK_BF16_MFMA_TFLOPS) if dominant_s3 else (achieved_f32 / PEAK_F32_MFMA_TFLOPS),
-                         "dominant_kernel_ms_per_step": (s3["ms"] if dominant_s3 else ig["ms"]) / max(1, args.steps),
-                         "split_bf16_gemm": None if s3["ms"] <= 0 else {
-                             "executed_bf16_tflops": achieved_s3, "peak_bf16_tflops": PEAK_BF16_MFMA_TFLOPS,
-                             "frac": achieved_s3 / PEAK_BF16_MFMA_TFLOPS,
-                             "fp32_equivalent_tflops": achieved_s3 / 6.0,
-                             "fp32_equivalent_over_fp32_mfma_peak": achieved_s3 / 6.0 / PEAK_F32_MFMA_TFLOPS,
-                             "ms_per_step": s3["ms"] / max(1, args.steps), "launches_per_step": s3["launches"] / max(1, args.steps),
-                             "avg_launch_ms": s3["ms"] / max(1, s3["launches"]),
-                             "executed_gflop_per_launch": s3["flops"] / max(1, s3["launches"]) / 1e9,
-                             "algorithmic_bytes_per_launch": s3["bytes"] / max(1, s3["launches"]),
-                             "layers": s3_layers},
-                         "fp32_mfma_kernel": {"kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)", "achieved": achieved_f32,
-                                              "peak": PEAK_F32_MFMA_TFLOPS, "frac": achieved_f32 / PEAK_F32_MFMA_TFLOPS,
-                                              "ms_per_step": ig["ms"] / max(1, args.steps)},
-                         "frac_executed": achieved_f32 / PEAK_F32_MFMA_TFLOPS,
-                         # the transform kernels exist only because of the Winograd form: charge them to the conv path
-                         "frac_incl_transforms": (ig["flops"] / ((ig["ms"] + wino_ms) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS)
-                         if ig["ms"] > 0 else None,
-                         "frac_whole_conv_path": conv_path_pipe_frac,
-                         "whole_conv_path": {"executed_fp32_mfma_tflop_per_step": conv_path_flops / max(1, args.steps) / 1e12,
-                                             "executed_bf16_mfma_tflop_per_step": s3["flops"] / max(1, args.steps) / 1e12,
-                                             "fp32_equivalent_tflops": ((conv_path_flops + s3["flops"] / 6.0) / (conv_path_ms * 1e-3) / 1e12)
-                                             if conv_path_ms > 0 else None,
-                                             "ms_per_step": conv_path_ms / max(1, args.steps),
-                                             "direct_form_tflop_per_step": (direct_form + direct_form_fused + conv1["flops"]) / max(1, args.steps) / 1e12},
-                         "transform_ms_per_step": wino_ms / max(1, args.steps),
-                         # conv family as a whole (MFMA GEMMs + transforms + fused conv_2): direct-form bytes the
-                         # reference's layers need (in + W + out, fp32) vs the bytes this implementation's kernels
-                         # move by their own algorithmic count (V + U + M' for the GEMMs, the transforms' reads+writes)
-                         "direct_form_bytes_per_step": direct_form_bytes / max(1, args.steps),
-                         "implementation_bytes_per_step": (s3["bytes"] + ig["bytes"] + wino_in["bytes"] + wino_out["bytes"] + fused["bytes"]) / max(1, args.steps),
-                         "traffic": None, "traffic_per_step": None,
-                         "launches_per_step": ig["launches"] / max(1, args.steps),
-                         "avg_launch_ms": ig["ms"] / max(1, ig["launches"]),
-                         "executed_gflop_per_launch": ig["flops"] / max(1, ig["launches"]) / 1e9,
-                         "algorithmic_gflop_per_launch": direct_form / max(1, ig["launches"]) / 1e9,
-                         "algorithmic_bytes_per_launch": ig["bytes"] / max(1, ig["launches"]),
-                         "achieved_algorithmic": (direct_form / (ig["ms"] * 1e-3) / 1e12) if ig["ms"] > 0 else None,
-                         "achieved_algorithmic_incl_transforms":
-                             (direct_form / ((ig["ms"] + wino_ms) * 1e-3) / 1e12) if ig["ms"] > 0 else None,
-                         "mfma_bound_launches": None if regimes["mfma"][2] <= 0 else {
-                             "layers": sorted(regimes["mfma"][3]), "ms_per_step": regimes["mfma"][2] / args.steps,
-                             "achieved": regimes["mfma"][0] / (regimes["mfma"][2] * 1e-3) / 1e12,
-                             "frac": regimes["mfma"][0] / (regimes["mfma"][2] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
-                         "hbm_bound_launches": None if regimes["hbm"][2] <= 0 else {
-                             "layers": sorted(regimes["hbm"][3]), "ms_per_step": regimes["hbm"][2] / args.steps,
-                             "achieved_GBps": regimes["hbm"][1] / (regimes["hbm"][2] * 1e-3) / 1e9,
-                             "frac_of_8TBps": regimes["hbm"][1] / (regimes["hbm"][2] * 1e-3) / 8e12,
-                             "executed_tflops": regimes["hbm"][0] / (regimes["hbm"][2] * 1e-3) / 1e12},
-                         "note": "achieved/frac = MFMA FLOPs the DOMINANT kernel executes / its HIP-event time, against the dense "
-                                 "peak of the instruction it issues (pipe utilisation, <= 1). With the default policy the dominant "
-                                 "kernel is wino_gemm_s3_kernel: the F(6x6,3x3) layers' GEMMs carry every fp32 operand as three bf16 "
-                                 "terms and form each product from six bf16 MFMA partial products with fp32 accumulation -- fp32 "
-                                 "accuracy (tests/test_gpu_parity.py::test_split_bf16_gemm_error_against_float64) at 16/6 of the "
-                                 "fp32 MFMA rate; split_bf16_gemm.fp32_equivalent_tflops = executed / 6 is what the layer sees "
-                                 "(DT_S3=0 runs the same GEMMs on v_mfma_f32_32x32x2_f32: fp32_mfma_kernel). "
-                                 "launches_per_step .. achieved_algorithmic and the mfma_/hbm_bound split below describe the fp32 "
-                                 "kernel family (conv_igemm_f32: 1x1 layers, short-K Winograd GEMMs, recurrent step). "
-                                 "frac_whole_conv_path = time the matrix pipe needs at its peaks for everything the conv path "
-                                 "executes (bf16 FLOPs / 2500 + fp32 FLOPs / 157.3) / the conv path's time incl. transforms. "
-                                 "The 3x3 layers from conv_3 up and both ConvLSTM convolutions run in Winograd "
-                                 "form (F(6x6,3x3): 64 batched GEMMs through the same kernel; F(4x4,3x3) for the recurrent "
-                                 "step), which executes up to 5x fewer FLOPs than the direct form SURVEY.md 8d counts; "
-                                 "achieved_algorithmic = direct-form FLOPs of the layers THESE launches computed (layers run "
-                                 "by the fused Winograd kernels or conv_1 are not counted) / the same time, and exceeds "
-                                 "the peak; ..._incl_transforms adds the HBM-bound transform kernels to the time; "
-                                 "frac_whole_conv_path = every executed MFMA FLOP of the conv path (GEMMs + fused kernels + "
-                                 "conv_1) / (their time + the transforms' time) / peak. "
-                                 "mfma_bound_launches / hbm_bound_launches split the family by arithmetic intensity "
-                                 "(>= / < 40 executed FLOP per algorithmic byte): the short-K launches (K = 64/128 Winograd "
-                                 "GEMMs, early 1x1 layers) sit under the HBM roof, not the MFMA one."},
+            "frame_shard_stage_ms_per_rank": stage_ms,
+            "roofline": None if dominant is None else {
+                "bound": "mfma",
+                # the four contract fields describe ONE family -- the one with the most time in the step -- and nothing else;
+                # every other figure of a family lives in families[<name>], computed from that family's own launches only
+                "kernel": families[dominant]["kernel"] + " -- " + families[dominant]["instruction"],
+                "dominant_family": dominant,
+                "achieved": families[dominant]["achieved"], "peak": families[dominant]["peak_tflops"], "unit": "TFLOP/s",
+                "frac": families[dominant]["frac"],
+                "traffic": families[dominant]["traffic_bytes_per_launch"],
+                "traffic_unit": "bytes per launch of the dominant family (FETCH_SIZE x in-run calibration + WRITE_SIZE; beyond-L2, incl. Infinity Cache hits)",
+                "traffic_source": os.path.relpath(tr[0], ROOT) if tr is not None else None,
+                "traffic_per_step": tr[1].get("traffic_bytes_per_step") if tr is not None else None,
+                "families": families, "transforms": transforms,
+                "frac_whole_conv_path": conv_path_pipe_frac,
+                "whole_conv_path": {"executed_fp32_mfma_tflop_per_step": conv_path_flops / steps / 1e12,
+                                    "executed_bf16_mfma_tflop_per_step": s3["flops"] / steps / 1e12,
+                                    "fp32_equivalent_tflops": ((conv_path_flops + s3["flops"] / 6.0) / (conv_path_ms * 1e-3) / 1e12)
+                                    if conv_path_ms > 0 else None,
+                                    "ms_per_step": conv_path_ms / steps,
+                                    "direct_form_tflop_per_step": direct_form_all / steps / 1e12,
+                                    "direct_form_tflops": (direct_form_all / (conv_path_ms * 1e-3) / 1e12) if conv_path_ms > 0 else None,
+                                    "direct_form_bytes_per_step": direct_form_bytes_all / steps,
+                                    "implementation_bytes_per_step": (s3["bytes"] + ig["bytes"] + wino_in["bytes"] + wino_out["bytes"] + fused["bytes"] + conv1["bytes"]) / steps},
+                "note": "achieved / peak / frac / traffic = the DOMINANT kernel family (most time in the step): MFMA FLOPs its launches execute / "
+                        "their HIP-event time, against the dense peak of the instruction it issues (pipe utilisation, <= 1). Per family "
+                        "(families.*): executed = FLOPs on the matrix pipe; algorithmic = SURVEY.md 8d direct-form FLOPs (2MKN of the "
+                        "reference's layer) of the layers THAT family's launches computed -- the 3x3 layers run in Winograd form "
+                        "(F(6x6,3x3): 1.78 multiplies per output instead of 9; fused F(4x4,3x3): 2.25), so achieved_algorithmic exceeds "
+                        "achieved; wino_gemm_s3 carries every fp32 operand as three bf16 terms and forms each product from six bf16 "
+                        "MFMA partial products with fp32 accumulation (fp32 accuracy, tests/test_gpu_parity.py::"
+                        "test_split_bf16_gemm_benched_shapes_against_float64): fp32_equivalent_tflops = executed / 6. "
+                        "implementation_* = bytes the kernels move by their own count (V + U + M' for the GEMMs); traffic_* = PMC "
+                        "measurement (profiles/). transforms = the HBM-bound Winograd transform kernels around the GEMMs. "
+                        "frac_whole_conv_path = time the matrix pipe needs at its peaks for everything the conv path executes "
+                        "(bf16 FLOPs / 2500 + fp32 FLOPs / 157.3) / the conv path's time incl. transforms."},
             "kernels": kern,
         }
-        tr = load_traffic(args.clips, args.T, args.size) if args.workload == "track" else None
-        if tr is not None:
-            out["roofline"]["traffic"] = tr[1]["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_per_step"] = tr[1].get("traffic_bytes_per_step")
-            out["roofline"]["traffic_unit"] = "bytes/launch (FETCH_SIZE x in-run calibration + WRITE_SIZE; beyond-L2, incl. Infinity Cache hits)"
-            out["roofline"]["traffic_source"] = os.path.relpath(tr[0], ROOT)
         if world == 1 and not args.no_extra and args.workload == "track":
             import gc
             out["extra"] = {}

@@ -48,7 +48,7 @@ DT_API int dt_create(dt_ctx **out);
 DT_API void dt_destroy(dt_ctx *ctx);
 DT_API const char *dt_last_error(dt_ctx *ctx);
 DT_API int dt_set_stream(dt_ctx *ctx, void *hip_stream);
-/* ABI version of this header: major*100+minor (1.05: 1.04 + dt_track_detect_xproj / dt_track_recurrent_xproj) */
+/* ABI version of this header: major*100+minor (1.06: 1.05 + dt_gemm_split_bf16) */
 DT_API int dt_abi_version(void);
 
 /* ---- detector: KerasYOLO ---------------------------------------------- */
@@ -272,6 +272,16 @@ DT_API int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int W, 
                      const float *d_h, const float *d_c, int U,
                      const float *h_kernel, const float *h_recurrent,
                      const float *h_bias, float *d_h_out, float *d_c_out);
+
+/* The split-bf16 batched GEMM of the F(6x6,3x3) / F(4x4,3x3) layers (wino_gemm_s3.hip) on the caller's fp32 operands --
+ * the contraction over input channels that models_detection/KerasYOLO.py:351-396 (conv_14 .. conv_22) and
+ * models_tracking/MultiObjDetTracker.py:176 (both ConvLSTM2D convolutions) become in Winograd form -- so that the parity
+ * tests can check the kernel against float64 AT THE SHAPES bench.py runs (P = 64, Mt = 7840, K = 1024 / 1280, ...):
+ *   d_v [P][Mt][K], d_u [P][N][K] float32  ->  d_m [P][Mt][N] = sum_k v * u     (K % 32 == 0, N % 128 == 0)
+ * Both operands are split into three bf16 terms on the device by the production pack kernel, then the production
+ * launcher runs.  half: 0 = the launcher's own choice of row tile, 1 = 128-row tiles (two workgroups per CU), -1 = 256. */
+DT_API int dt_gemm_split_bf16(dt_ctx *ctx, const float *d_v, const float *d_u, int P, int Mt, int K, int N, int half,
+                              float *d_m);
 
 /* ---- tuning / test knobs ------------------------------------------------- *
  * The DT_* environment variables of DESIGN.md's appendix are read ONCE, in dt_create (no launch path calls

@@ -20,8 +20,6 @@ SOURCES = {
     "conv_igemm.hip": [],
     "conv1.hip": [],
     "winograd.hip": [],
-    "wino_fused.hip": [],
-    "wino4_fused.hip": [],
     # no SLP vectorisation: hipcc otherwise packs the transforms' scalar f32 adds / fmas into v_pk_* with a v_mov per operand --
     # more instructions, and packed f32 issues slowly beside MFMAs (MI355X_MICROARCH.md)
     "wino4s_fused.hip": ["-fno-slp-vectorize"],

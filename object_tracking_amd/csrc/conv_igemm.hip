@@ -728,12 +728,10 @@ static int launch_one(hipStream_t st, const ConvArgs &a, int ksplit = 1)
     const size_t lds = (size_t)NSTAGE * (BM + BN) * LDK * sizeof(float);
     auto kern = conv_igemm_f32<KS, BM, BN, WGM, WGN, ORDER, EPI, PERSIST>;
     static PerDeviceOnce attr;
-    if (attr.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return 1;
-        attr.done();
-    }
+    if (attr.ensure(nullptr, [&](int) {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess;
+        }))
+        return 1;
     // one workgroup per tile, or -- with more tiles than resident slots -- a persistent grid of one
     // workgroup per slot (256 CUs x 2 four-wave workgroups, or x 1 of the 8/16-wave ones) that walks the tiles
     int grid = ntm * ntn * (a.zbatch > 1 ? a.zbatch : 1);
@@ -782,14 +780,16 @@ int launch_conv_igemm(hipStream_t st, const ConvArgs &a_in, int ks, int order, i
     }
     static float *zeros_dev[64];   // per device: 256 B of zeros for the padding taps
     static PerDeviceOnce zeros_once;
-    if (zeros_once.first()) {
-        float *z = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&z), 256) != hipSuccess) return 1;
-        if (hipMemset(z, 0, 256) != hipSuccess) return 1;
-        zeros_dev[zeros_once.dev] = z;
-        zeros_once.done();
-    }
-    a.zeros = zeros_dev[zeros_once.dev];
+    int dev = 0;
+    if (zeros_once.ensure(&dev, [&](int d) {
+            float *z = nullptr;
+            if (hipMalloc(reinterpret_cast<void **>(&z), 256) != hipSuccess) return 1;
+            if (hipMemset(z, 0, 256) != hipSuccess) { (void)hipFree(z); return 1; }
+            zeros_dev[d] = z;
+            return 0;
+        }))
+        return 1;
+    a.zeros = zeros_dev[dev];
     if (a.Cin % KCH != 0 || a.K != ks * ks * a.Cin) return 2;
     if (ks == 1 && order == ORD_LINEAR && a.in_bs != (long long)a.H * a.W * a.in_ld) return 2;   // flat row addressing
     if (epi == EPI_GATES) {

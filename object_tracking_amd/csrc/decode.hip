@@ -638,14 +638,13 @@ int launch_decode(hipStream_t st, const float *netout, long long frame_stride, i
     a.nms_waves = nms_waves > DEC_THREADS / 64 ? DEC_THREADS / 64 : nms_waves;
     const size_t lds = fixed + (size_t)nzcap * 8 + dyn;
     static PerDeviceOnce attr;
-    if (attr.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(decode_nms_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(decode_nms_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return 1;
-        attr.done();
-    }
+    if (attr.ensure(nullptr, [](int) {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(decode_nms_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                   hipFuncSetAttribute(reinterpret_cast<const void *>(decode_nms_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess;
+        }))
+        return 1;
     if (lds > 160 * 1024) return 2;
     if (big) hipLaunchKernelGGL(decode_nms_kernel<true>, dim3((unsigned)batch), dim3(DEC_THREADS), lds, st, a);
     else hipLaunchKernelGGL(decode_nms_kernel<false>, dim3((unsigned)batch), dim3(DEC_THREADS), lds, st, a);
@@ -756,12 +755,11 @@ int launch_associate(hipStream_t st, const float *boxes, const int *counts, int 
     const size_t lds = (size_t)cap * 12 * sizeof(float);   // 2 x 5 box fields + 2 id arrays
     if (lds > 160 * 1024) return 2;
     static PerDeviceOnce attr;
-    if (attr.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(associate_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return 1;
-        attr.done();
-    }
+    if (attr.ensure(nullptr, [](int) {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(associate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024) != hipSuccess;
+        }))
+        return 1;
     hipLaunchKernelGGL(associate_kernel, dim3((unsigned)n_clips), dim3(64), lds, st, boxes, counts, T, cap, thr, ids,
                        nids);
     return hipGetLastError() == hipSuccess ? 0 : 1;

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <functional>
 #include <string>
 #include <vector>
@@ -15,16 +16,25 @@
 
 // One-time, PER-DEVICE set-up of a launch site (hipFuncSetAttribute for large dynamic LDS, small constant buffers):
 // kernel attributes and allocations belong to a device, so a process that drives several GPUs must repeat them on
-// each.  `first()` is true until `done()` was called on the calling thread's current device.
+// each.  `ensure(&dev, setup)` runs `setup(dev)` once per device, serialised by a mutex, and hands the calling thread's
+// device id back to the CALLER (nothing device-specific is kept in shared state, so two host threads on different
+// devices cannot see each other's id).  It returns non-zero -- the caller fails its launch -- when the set-up failed,
+// the device cannot be determined, or it lies beyond the 64 devices tracked (never aliased onto device 0).
 struct PerDeviceOnce {
     std::atomic<unsigned long long> mask{0};
-    int dev = 0;
-    bool first()
+    std::mutex mu;
+    template <class F> int ensure(int *dev_out, F &&setup)
     {
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
-        return !((mask.load(std::memory_order_acquire) >> dev) & 1ull);
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 1;
+        if (dev_out) *dev_out = dev;
+        if ((mask.load(std::memory_order_acquire) >> dev) & 1ull) return 0;
+        std::lock_guard<std::mutex> lk(mu);
+        if ((mask.load(std::memory_order_acquire) >> dev) & 1ull) return 0;
+        const int rc = setup(dev);
+        if (rc == 0) mask.fetch_or(1ull << dev, std::memory_order_release);
+        return rc;
     }
-    void done() { mask.fetch_or(1ull << dev, std::memory_order_release); }
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -126,22 +136,13 @@ struct WinoArgs {
     long long c_bs;
     int c_ld;
 };
-// fused Winograd F(2x2,3x3) + LeakyReLU + MaxPooling2D(2,2) for conv_2 (32 -> 64 channels), wino_fused.hip
-struct WinoFusedArgs {
-    const float *in;     // [B][H][W][32]
-    int B, H, W;
-    const float *u;      // [16][2][32][2][16]  (wino2_fused_pack)
-    const float *bias;   // [64]
-    float slope;
-    float *out;          // [B][H/2][W/2][64]
-};
-// fused Winograd F(4x4,3x3) for the early wide layers (Cin 64 / 128 -> Cout 128 / 256), wino4_fused.hip
+// fused Winograd F(4x4,3x3) for the early layers (Cin 32 / 64 / 128 -> Cout 64 / 128 / 256: conv_2, conv_3, conv_5; conv_6 / conv_8 on request), wino4s_fused.hip
 struct Wino4FusedArgs {
     const float *in;     // NHWC, pixel stride in_ld, frame stride in_bs
     long long in_bs;
     int in_ld;
     int B, H, W, Cin, N;
-    const float *u;      // wino4_fused_pack layout
+    const float *u;      // wino4s_fused_pack layout
     const float *bias;   // [N]
     float slope;
     float *out;          // full-resolution output (pixel stride out_ld, frame stride out_bs) or null
@@ -152,9 +153,7 @@ struct Wino4FusedArgs {
     int nby, nbx;        // set by the launcher
     const float *zeros;  // >= 16 B of device zeros: DMA source of out-of-image patch pixels (wino4s_fused.hip)
 };
-int launch_wino4_fused(hipStream_t st, const Wino4FusedArgs &a);
-void wino4_fused_pack(const float *u36, int npad, int cin, int cout, float *dst);
-// second-generation fused F(4x4,3x3) kernel: U staged through LDS by DMA, in-register output transform, persistent (wino4s_fused.hip)
+// U staged through LDS by DMA, in-register output transform, persistent over (block pair, 64-channel slice) items
 int launch_wino4s_fused(hipStream_t st, const Wino4FusedArgs &a, const float *zeros);
 void wino4s_fused_pack(const float *u36, int npad, int cin, int cout, float *dst);
 // split-bf16 batched GEMM of the F(6x6,3x3) layers (wino_gemm_s3.hip): fp32 operands as three bf16 terms, six MFMAs per product
@@ -179,8 +178,6 @@ bool wino_gemm_s3_half_chosen(const GemmS3Args &a, int cus);
 double wino_gemm_s3_flops(const GemmS3Args &a);
 void wino_s3_split_host(float x, unsigned short t[3]);
 void wino_s3_pack_weights(const float *u, int P, int npad, int K, unsigned short *dst);
-int launch_wino2_fused_pool(hipStream_t st, const WinoFusedArgs &a);
-void wino2_fused_pack(const float *hwio, const float *scale, float *dst);
 int launch_wino_input(hipStream_t st, const WinoArgs &a);
 // U [P][npad][K] fp32 (device) -> split-bf16 [P][3][K/16][npad][16] (device)
 int launch_wino_s3_pack(hipStream_t st, const float *u, int P, int npad, int K, unsigned short *dst);
@@ -262,9 +259,7 @@ struct ConvLayer {
     float *wino = nullptr;               // device, [P][npad][cin] Winograd-domain weights (wide 3x3 layers) or null
     int wino_ts = 0;                     // their output tile size (2, 4 or 6)
     float *wino_alt = nullptr;           // device, F(4x4) weights kept next to F(6x6) ones for small-batch launches, or null
-    float *fused = nullptr;              // device, fused-Winograd weights (32 -> 64 pooled layer: conv_2) or null
-    float *fused4 = nullptr;             // device, fused F(4x4,3x3) weights (Cin 64/128 -> Cout 128/256: conv_3/5/6/8) or null
-    float *fused4s = nullptr;            // device, the same for the LDS-staged kernel (wino4s_fused.hip; also conv_2's shape) or null
+    float *fused4s = nullptr;            // device, fused F(4x4,3x3) weights (wino4s_fused.hip: conv_2 / 3 / 5 / 6 / 8's shapes) or null
     float *bias = nullptr;               // device, [npad]
     float *scale = nullptr;              // device, [cout]: folded BatchNorm scale (dt_detector_extract un-folds with it) or null
     bool scale_has_zero = false;
@@ -279,13 +274,11 @@ struct Policy {
     int wino_minc = 64, wino_minn = 128, wino_mint = 0;   // DT_WINO_MINC / MINN / MINT (A/B runs)
     double wino_ws_gb = 96.0;   // DT_WINO_WS_GB: V + M' workspace above this -> direct form
     int mosaic = -1;         // DT_WINO_MOSAIC: 1 never, 2/3/4 force, -1 = fewest tiles
-    int fused = 1;           // DT_WINO_FUSED: 0 never / 1 from 512 workgroups / 2 always
-    int fused4 = 1;          // DT_WINO_FUSED4: the fused F(4x4) kernel: 0 never / 1 conv_3/5 (Cin 64) from 1024 blocks / 3 also conv_6/8 / 2 always
+    int fused4 = 1;          // DT_WINO_FUSED4: the fused F(4x4) kernel (wino4s_fused.hip): 0 never / 1 conv_2 / 3 / 5 (Cin <= 64) from 1024
+                             //                 blocks / 3 also conv_6 / 8 (Cin 128) / 2 any eligible layer at any size.  Read at weight load (0) and per launch
     int wino_cfg = -1, wino_gn = -1;   // DT_WINO_CFG / DT_WINO_GN (A/B runs)
     int ksplit = 0;          // DT_KSPLIT
     int conv_cfg = -1;       // DT_CONV_CFG
-    int w4s = 2;             // DT_W4S: 2 (default) = the LDS-staged fused F(4x4) kernel (wino4s_fused.hip) where fused4 applies AND for
-                             //         conv_2 (instead of its fused F(2x2) kernel); 1 = not for conv_2; 0 = wino4_fused.hip
     int s3 = 1;              // DT_S3: the F(6x6) layers' batched GEMMs on the bf16 matrix pipe with 3-term split operands (wino_gemm_s3.hip):
                              //        0 never (fp32 MFMA) / 1 where it wins (K >= s3_mink, GEMM rows >= s3_minrows) / 2 wherever the shape allows
     int s3_mink = 256, s3_minrows = 2048;   // DT_S3_MINK / DT_S3_MINROWS

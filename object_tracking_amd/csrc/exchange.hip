@@ -99,6 +99,7 @@ extern "C" int dt_pack_detections(dt_ctx *ctx, const float *d_boxes, const int *
     if (n_clips < 0 || T <= 0 || cap <= 0) return dt_fail(ctx, DT_ERR_ARG, "bad detection table shape");
     if (n_rows < n_clips) return dt_fail(ctx, DT_ERR_ARG, "dt_pack_detections: %d rows cannot hold %d clips (n_rows is the per-rank maximum)", n_rows, n_clips);
     if (n_rows == 0) return DT_OK;
+    if (n_rows > 65535) return dt_fail(ctx, DT_ERR_ARG, "dt_pack_detections: %d rows exceed the 65535 rows one launch addresses (grid.y); exchange in slices", n_rows);
     const long long row = (long long)row_ints(T, cap);
     int gx = (int)((row + 256 * 8 - 1) / (256 * 8));
     if (gx > 64) gx = 64;
@@ -114,6 +115,7 @@ extern "C" int dt_unpack_detections(dt_ctx *ctx, const int32_t *d_rows, int n_ro
 {
     if (!ctx || !d_rows || !d_boxes || !d_counts || !d_ids || !d_nids || !d_n_valid) return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (n_rows <= 0 || T <= 0 || cap <= 0) return dt_fail(ctx, DT_ERR_ARG, "bad detection table shape");
+    if (n_rows > 65535) return dt_fail(ctx, DT_ERR_ARG, "dt_unpack_detections: %d rows exceed the 65535 rows one launch addresses (grid.y); exchange in slices", n_rows);
     const long long row = (long long)row_ints(T, cap);
     int *slot = reinterpret_cast<int *>(ws_get(ctx, "xchg_slot", (size_t)n_rows * sizeof(int)));
     long long *idoff = reinterpret_cast<long long *>(ws_get(ctx, "xchg_idoff", (size_t)n_rows * sizeof(long long)));
@@ -123,7 +125,8 @@ extern "C" int dt_unpack_detections(dt_ctx *ctx, const int32_t *d_rows, int n_ro
     if (gx < 1) gx = 1;
     ProfScope ps(ctx, "exchange_unpack", 0.0, 8.0 * (double)n_rows * row);
     hipLaunchKernelGGL(unpack_plan_kernel, dim3(1), dim3(256), 0, ctx->stream, d_rows, n_rows, row, slot, idoff, d_n_valid);
+    if (hipGetLastError() != hipSuccess) return dt_fail(ctx, DT_ERR_DEVICE, "unpack plan launch failed");
     hipLaunchKernelGGL(unpack_rows_kernel, dim3(gx, n_rows), dim3(256), 0, ctx->stream, d_rows, row, slot, idoff, T, cap,
                        reinterpret_cast<int *>(d_boxes), d_counts, d_ids, d_nids, reinterpret_cast<long long *>(d_gids));
-    return hipGetLastError() == hipSuccess ? DT_OK : dt_fail(ctx, DT_ERR_DEVICE, "unpack launch failed");
+    return hipGetLastError() == hipSuccess ? DT_OK : dt_fail(ctx, DT_ERR_DEVICE, "unpack rows launch failed");
 }

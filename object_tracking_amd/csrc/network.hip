@@ -164,7 +164,7 @@ static int upload(dt_ctx *ctx, float **dst, const std::vector<float> &h)
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int dt_abi_version(void) { return 105; }   // 1.05: + dt_track_detect_xproj / dt_track_recurrent_xproj / dt_track_xproj_width
+extern "C" int dt_abi_version(void) { return 106; }   // 1.06: + dt_gemm_split_bf16 (test entry point of wino_gemm_s3.hip)
 
 extern "C" int dt_create(dt_ctx **out)
 {
@@ -210,8 +210,6 @@ extern "C" void dt_destroy(dt_ctx *ctx)
         if (ctx->layers[i].bias_s3) (void)hipFree(ctx->layers[i].bias_s3);
         if (ctx->layers[i].wino) (void)hipFree(ctx->layers[i].wino);
         if (ctx->layers[i].wino_alt) (void)hipFree(ctx->layers[i].wino_alt);
-        if (ctx->layers[i].fused) (void)hipFree(ctx->layers[i].fused);
-        if (ctx->layers[i].fused4) (void)hipFree(ctx->layers[i].fused4);
         if (ctx->layers[i].fused4s) (void)hipFree(ctx->layers[i].fused4s);
         if (ctx->layers[i].scale) (void)hipFree(ctx->layers[i].scale);
     }
@@ -276,7 +274,7 @@ static void oihw_to_hwio(const float *src, int O, int I, int k, std::vector<floa
 static bool wino_wanted(const dt_ctx *ctx, int ks, int cin, int cout);
 static int wino_tile(const dt_ctx *ctx, bool recurrent);
 static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map,
-                       int cin_dst, const int *n_map, int npad, const float *scale, bool want_s3 = true);
+                       int cin_dst, const int *n_map, int npad, const float *scale, bool want_s3);
 
 static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, const float *hwio, const float *scale,
                            const float *bias_src)
@@ -322,33 +320,18 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
     }
     if (L.wino) { (void)hipStreamSynchronize(ctx->stream); s3_drop(ctx, L.wino); (void)hipFree(L.wino); L.wino = nullptr; }
     if (L.wino_alt) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino_alt); L.wino_alt = nullptr; }
-    if (L.fused) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused); L.fused = nullptr; }
-    if (L.fused4) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused4); L.fused4 = nullptr; }
     if (L.fused4s) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused4s); L.fused4s = nullptr; }
-    const bool f4_shape = (cin == 64 || cin == 128) && cout % 128 == 0 && cout <= 256;
-    const bool f4s_conv2 = cin == 32 && cout == 64 && ctx->pol.w4s == 2;
-    if (ks == 3 && (f4_shape || f4s_conv2) && ctx->pol.wino != 0 && ctx->pol.fused4 != 0) {
-        // conv_3 / conv_5 / conv_6 / conv_8's shapes (and conv_2's with DT_W4S=2): fused F(4x4,3x3) kernels
+    const bool f4_shape = ((cin == 64 || cin == 128) && cout % 128 == 0 && cout <= 256) || (cin == 32 && cout == 64);
+    if (ks == 3 && f4_shape && ctx->pol.wino != 0 && ctx->pol.fused4 != 0) {
+        // conv_2 / conv_3 / conv_5 / conv_6 / conv_8's shapes: the fused F(4x4,3x3) kernel (wino4s_fused.hip)
         std::vector<float> u36((size_t)36 * L.npad * cin), uf((size_t)36 * cin * cout);
         wino_pack_weights(4, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale, u36.data());
-        if (f4_shape) {
-            wino4_fused_pack(u36.data(), L.npad, cin, cout, uf.data());
-            if ((rc = upload(ctx, &L.fused4, uf))) return rc;
-        }
-        if (ctx->pol.w4s != 0) {
-            wino4s_fused_pack(u36.data(), L.npad, cin, cout, uf.data());
-            if ((rc = upload(ctx, &L.fused4s, uf))) return rc;
-        }
-    }
-    if (ks == 3 && cin == 32 && cout == 64 && ctx->pol.wino != 0) {   // conv_2's shape: fused F(2x2,3x3) + pool kernel
-        std::vector<float> uf((size_t)16 * 2 * 32 * 2 * 16);
-        wino2_fused_pack(hwio, scale, uf.data());
-        rc = upload(ctx, &L.fused, uf);
-        if (rc) return rc;
+        wino4s_fused_pack(u36.data(), L.npad, cin, cout, uf.data());
+        if ((rc = upload(ctx, &L.fused4s, uf))) return rc;
     }
     if (wino_wanted(ctx, ks, cin, cout)) {
         L.wino_ts = wino_tile(ctx, false);
-        rc = upload_wino(ctx, &L.wino, L.wino_ts, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale);
+        rc = upload_wino(ctx, &L.wino, L.wino_ts, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale, L.wino_ts == 6);
         if (rc) return rc;
         // small batches of the 13x13 / 26x26 layers: F(4x4) needs 36 GEMMs of ONE (partly filled) row tile where F(6x6)
         // needs 64 -- keep both weight sets and choose per launch (run_conv); only with the default tile policy
@@ -421,15 +404,15 @@ extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t 
     return DT_OK;
 }
 
-// "conv_direct_form": direct-form FLOPs (2*M*K*N of the reference's convolution) of every layer a
-// conv_igemm launch computes, whichever form it runs in -- bench.py divides it by the kernel family's
-// time for the algorithmic-equivalent rate next to the executed one.  Layers that run in one of the fused
-// Winograd kernels (conv_2 / conv_3 / conv_5 ...) are NOT conv_igemm launches: they are booked under
-// "conv_direct_form_fused", so that the family's rate is never credited with work another kernel did.
-static void prof_direct_form(dt_ctx *ctx, double flops, double bytes, bool fused_kernel = false)
+// Direct-form FLOPs (2*M*K*N of the reference's convolution) and bytes (in + weights + out, fp32) of every layer, booked
+// under the kernel FAMILY whose launch computed it -- "conv_direct_form" (conv_igemm_f32 launches), "conv_direct_form_s3"
+// (wino_gemm_s3 launches), "conv_direct_form_fused" (the fused Winograd kernel) -- so that bench.py divides each family's
+// algorithmic work by that family's own time and no family is credited with work another kernel did.
+enum { DF_IGEMM = 0, DF_FUSED = 1, DF_S3 = 2 };
+static void prof_direct_form(dt_ctx *ctx, double flops, double bytes, int family = DF_IGEMM)
 {
     if (!ctx->prof) return;
-    ProfEntry &e = ctx->prof_tab[fused_kernel ? "conv_direct_form_fused" : "conv_direct_form"];
+    ProfEntry &e = ctx->prof_tab[family == DF_FUSED ? "conv_direct_form_fused" : (family == DF_S3 ? "conv_direct_form_s3" : "conv_direct_form")];
     e.flops += flops;
     e.bytes += bytes;   // in + weights + out of the reference's layer, float32
 }
@@ -453,13 +436,11 @@ void policy_from_env(Policy &p)
     p.wino_mint = geti("DT_WINO_MINT", d.wino_mint);
     { const char *e = getenv("DT_WINO_WS_GB"); p.wino_ws_gb = e ? atof(e) : d.wino_ws_gb; }
     p.mosaic = geti("DT_WINO_MOSAIC", d.mosaic);
-    p.fused = geti("DT_WINO_FUSED", d.fused);
     p.fused4 = geti("DT_WINO_FUSED4", d.fused4);
     p.wino_cfg = geti("DT_WINO_CFG", d.wino_cfg);
     p.wino_gn = geti("DT_WINO_GN", d.wino_gn);
     p.ksplit = geti("DT_KSPLIT", d.ksplit);
     p.conv_cfg = geti("DT_CONV_CFG", d.conv_cfg);
-    p.w4s = geti("DT_W4S", d.w4s);
     p.wino_coop = geti("DT_WINO_COOP", d.wino_coop);
     p.s3 = geti("DT_S3", d.s3);
     p.s3_mink = geti("DT_S3_MINK", d.s3_mink);
@@ -513,13 +494,15 @@ static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int 
     s3_drop(ctx, *dst);
     int rc = upload(ctx, dst, u);
     if (rc) return rc;
-    // F(6x6) weights also in the split-bf16 form of wino_gemm_s3.hip (the split runs on the device, from the fp32 copy)
-    // (F(4x4): the ConvLSTM recurrent convolution)
-    if (want_s3 && (ts == 6 || ts == 4) && ctx->pol.s3 != 0 && cin_dst % 32 == 0 && npad % 128 == 0) {
+    // also in the split-bf16 form of wino_gemm_s3.hip (the split runs on the device, from the fp32 copy) -- only where run_wino
+    // can use it: F(6x6) weights of a plain layer, F(4x4) weights of the ConvLSTM recurrent convolution (the caller says which)
+    if (want_s3 && ctx->pol.s3 != 0 && cin_dst % 32 == 0 && npad % 128 == 0) {
         unsigned short *s3 = nullptr;
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s3), u.size() * 3 * sizeof(unsigned short)));
-        if (launch_wino_s3_pack(ctx->stream, *dst, (ts + 2) * (ts + 2), npad, cin_dst, s3)) { (void)hipFree(s3); return dt_fail(ctx, DT_ERR_DEVICE, "split-bf16 weight pack launch failed"); }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (launch_wino_s3_pack(ctx->stream, *dst, (ts + 2) * (ts + 2), npad, cin_dst, s3) || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            (void)hipFree(s3);
+            return dt_fail(ctx, DT_ERR_DEVICE, "split-bf16 weight pack failed");
+        }
         ctx->wino_s3[*dst] = s3;
     }
     return DT_OK;
@@ -613,8 +596,9 @@ static WinoGeom wino_geometry(const dt_ctx *ctx, int ts, int B, int H, int W, bo
 }
 
 static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias, int cin, int N, int npad, int B, int H,
-                    int W, const WinoIO &io, float slope, const char *tag)
+                    int W, const WinoIO &io, float slope, const char *tag, int cin_alg = 0 /* channels of the reference's layer when cin is padded */)
 {
+    const double cin_df = cin_alg > 0 ? cin_alg : cin;
     WinoArgs w;
     memset(&w, 0, sizeof(w));
     w.B = B; w.H = H; w.W = W; w.ts = ts;
@@ -661,9 +645,9 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
         g.K = cin; g.ldc = N; g.half = ctx->pol.s3_half;
         // flops = EXECUTED bf16 MFMA work (six partial products per multiply); bytes = V + U (three bf16 terms each) + M'
         ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), (double)P * (6.0 * mt * cin + 6.0 * (double)cin * N + 4.0 * (double)mt * N), tag);
-        prof_direct_form(ctx, 2.0 * B * H * W * 9.0 * cin * N,
-                         4.0 * ((double)B * H * W * cin + 9.0 * cin * N + (io.out ? (double)B * H * W * N : 0.0) +
-                                (io.out2 ? (double)B * H * W * N / 4.0 : 0.0)));
+        prof_direct_form(ctx, 2.0 * B * H * W * 9.0 * cin_df * N,
+                         4.0 * ((double)B * H * W * cin_df + 9.0 * cin_df * N + (io.out ? (double)B * H * W * N : 0.0) +
+                                (io.out2 ? (double)B * H * W * N / 4.0 : 0.0) + (io.cstate ? 4.0 * B * H * W * N / 4.0 : 0.0)), DF_S3);
         if (ctx->prof && !ctx->capturing) ctx->prof_tab[wino_gemm_s3_half_chosen(g, 0) ? "s3_tile:128x2" : "s3_tile:256"].launches += 1;
         const int rc = launch_wino_gemm_s3(ctx->stream, g, 0);
         if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: split-bf16 Winograd GEMM launch failed (rc=%d)", tag, rc);
@@ -680,8 +664,8 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
         // that on whole tiles: 4x for F(4x4,3x3), 2.25x for F(2x2,3x3)); bytes = V + U + M'
         ProfScope ps(ctx, "conv_igemm", 2.0 * P * mt * (double)cin * N,
                      4.0 * P * ((double)mt * cin + (double)cin * N + (double)mt * N), tag);
-        prof_direct_form(ctx, 2.0 * B * H * W * 9.0 * cin * N,
-                         4.0 * ((double)B * H * W * cin + 9.0 * cin * N + (io.out ? (double)B * H * W * N : 0.0) +
+        prof_direct_form(ctx, 2.0 * B * H * W * 9.0 * cin_df * N,
+                         4.0 * ((double)B * H * W * cin_df + 9.0 * cin_df * N + (io.out ? (double)B * H * W * N : 0.0) +
                                 (io.out2 ? (double)B * H * W * N / 4.0 : 0.0) + (io.cstate ? 4.0 * B * H * W * N / 4.0 : 0.0)));
         int cfg = pick_cfg_gemm(w.Mt, N, P);
         if (ctx->pol.wino_cfg >= 0) cfg = ctx->pol.wino_cfg;               // A/B runs
@@ -752,7 +736,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
         char tag[32];
         snprintf(tag, sizeof(tag), "conv_%d", L.idx);
         ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), 6.0 * M * L.cin + 6.0 * (double)L.cin * L.cout + 4.0 * (double)M * L.cout, tag);
-        prof_direct_form(ctx, 2.0 * M * (double)L.cin * L.cout, 4.0 * ((double)M * L.cin + (double)L.cin * L.cout + (double)M * L.cout));
+        prof_direct_form(ctx, 2.0 * M * (double)L.cin * L.cout, 4.0 * ((double)M * L.cin + (double)L.cin * L.cout + (double)M * L.cout), DF_S3);
         const int rc = launch_wino_gemm_s3(ctx->stream, g, 0);
         if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: split-bf16 1x1 GEMM launch failed (rc=%d)", tag, rc);
         return DT_OK;
@@ -772,51 +756,26 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
                                 (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0));
     char tag[32];
     snprintf(tag, sizeof(tag), L.idx == 102 ? "tconv_2" : "conv_%d", L.idx);
-    // conv_3/5/6/8's shapes: the fused F(4x4,3x3) kernel (V and M' stay on the CU) once there are enough 16x16-pixel
+    // conv_2 / 3 / 5 (6 / 8)'s shapes: the fused F(4x4,3x3) kernel (V and M' stay on the CU) once there are enough 16x16-pixel
     // blocks to fill the chip several times over; below that the unfused forms win (few, half-empty workgroups)
-    if ((L.fused4 || L.fused4s) && in_ld % 4 == 0 && ((epi == EPI_PLAIN && order == ORD_LINEAR) || (epi == EPI_POOL && !((H | W) & 1)))) {
+    if (L.fused4s && ctx->pol.fused4 != 0 && in_ld % 4 == 0 && ((epi == EPI_PLAIN && order == ORD_LINEAR) || (epi == EPI_POOL && !((H | W) & 1)))) {
         const long long blocks = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((L.cout + 127) / 128);
         if (ctx->pol.fused4 == 2 || (((ctx->pol.fused4 == 1 && L.cin <= 64) || ctx->pol.fused4 == 3) && blocks >= 1024)) {
             Wino4FusedArgs f;
             memset(&f, 0, sizeof(f));
             f.in = in; f.in_bs = a.in_bs; f.in_ld = in_ld; f.B = B; f.H = H; f.W = W; f.Cin = L.cin; f.N = L.cout;
-            f.u = L.fused4; f.bias = L.bias; f.slope = slope;
+            f.u = L.fused4s; f.bias = L.bias; f.slope = slope;
             if (epi == EPI_POOL) { f.out2 = out; f.out2_ld = out_ld; }
             else { f.out = out; f.out_ld = out_ld; f.out_bs = a.out_bs; }
-            // executed MFMA FLOPs: 36 positions x (whole 4x4 tiles) x Cin x N x 2; bytes: input once (+ halo 27 %) and the output
+            // executed MFMA FLOPs: 36 positions x (whole 4x4 tiles) x Cin x N x 2; bytes: input once per 128 output channels (+ halo 27 %) and the output
             const double tiles = (double)B * ((H + 3) / 4) * ((W + 3) / 4);
             ProfScope ps(ctx, "conv_fused", 2.0 * 36.0 * tiles * L.cin * L.cout,
                          4.0 * ((double)B * H * W * L.cin * 1.27 * ((L.cout + 127) / 128) + (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0)), tag);
-            prof_direct_form(ctx, flops, bytes, true);
-            int rc;
-            if (L.fused4s && ctx->pol.w4s != 0) {
-                float *zeros = ws_get(ctx, "zeros256", 256, /*zero_on_grow=*/true);
-                if (!zeros) return DT_ERR_DEVICE;
-                f.u = L.fused4s;
-                rc = launch_wino4s_fused(ctx->stream, f, zeros);
-            } else if (L.fused4) {
-                rc = launch_wino4_fused(ctx->stream, f);
-            } else {
-                rc = 2;
-            }
+            prof_direct_form(ctx, flops, bytes, DF_FUSED);
+            float *zeros = ws_get(ctx, "zeros256", 256, /*zero_on_grow=*/true);
+            if (!zeros) return DT_ERR_DEVICE;
+            const int rc = launch_wino4s_fused(ctx->stream, f, zeros);
             if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused F(4x4) launch failed", tag);
-            return DT_OK;
-        }
-    }
-    // conv_2's shape with its pooling epilogue, when the F(4x4) kernel above did not take it (DT_W4S < 2, or too few blocks):
-    // the fused F(2x2) Winograd kernel (wino_fused.hip) once there are enough
-    // workgroups to fill the chip (one per 8x8 pooled pixels); DT_WINO_FUSED=0 keeps the direct form
-    if (L.fused && epi == EPI_POOL && in_ld == 32 && out_ld == 64 && !((H | W) & 1)) {
-        const int fmode = ctx->pol.fused;      // 0: never, 2: at any size (parity tests)
-        if (fmode == 2 || (fmode == 1 && (long long)B * ((H / 2 + 7) / 8) * ((W / 2 + 7) / 8) >= 512)) {
-            WinoFusedArgs f;
-            f.in = in; f.B = B; f.H = H; f.W = W; f.u = L.fused; f.bias = L.bias; f.slope = slope; f.out = out;
-            // executed MFMA FLOPs: 16 positions x (tiles x 32 x 64) x 2; bytes: input once (+halo) and the pooled output
-            ProfScope ps(ctx, "conv_fused", 2.0 * 16.0 * B * (H / 2.0) * (W / 2.0) * 32.0 * 64.0,
-                         4.0 * ((double)B * H * W * 32.0 * 1.27 + (double)B * (H / 2) * (W / 2) * 64.0), tag);
-            prof_direct_form(ctx, flops, bytes, true);
-            const int rc = launch_wino2_fused_pool(ctx->stream, f);
-            if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused Winograd launch failed", tag);
             return DT_OK;
         }
     }
@@ -1297,11 +1256,11 @@ extern "C" int dt_tracker_load(dt_ctx *ctx, int units, const float *h_kernel, co
     ctx->trk_wh_ts = wino_tile(ctx, true);
     if (wino_wanted(ctx, 3, Cx, 4 * U) &&
         (rc = upload_wino(ctx, &ctx->trk_wx_wino, ctx->trk_wino_ts, h_kernel, Csrc, 4 * U, cin_map.data(), Cx, n_map.data(),
-                          4 * U, nullptr)))
+                          4 * U, nullptr, ctx->trk_wino_ts == 6)))
         return rc;
     if (wino_wanted(ctx, 3, U, 4 * U) &&
         (rc = upload_wino(ctx, &ctx->trk_wh_wino, ctx->trk_wh_ts, h_recurrent, U, 4 * U, nullptr, U, n_map.data(), 4 * U,
-                          nullptr)))
+                          nullptr, ctx->trk_wh_ts == 4)))
         return rc;
     ctx->trk_units = U; ctx->trk_cx = Cx; ctx->trk_wo_npad = npad;
     graphs_clear(ctx);
@@ -1338,7 +1297,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
         memset(&io, 0, sizeof(io));
         io.in = z; io.in_ld = Cx; io.in_bs = (long long)GG * Cx;
         io.out = xproj; io.out_ld = N4; io.out_bs = (long long)GG * N4;
-        const int rc = run_wino(ctx, wx_wino, ctx->trk_wino_ts, bx, Cx, N4, N4, F, gh, gw, io, 1.0f, "convlstm_xproj");
+        const int rc = run_wino(ctx, wx_wino, ctx->trk_wino_ts, bx, Cx, N4, N4, F, gh, gw, io, 1.0f, "convlstm_xproj", ctx->cb + 1024);
         if (rc) return rc;
     } else {
         ConvArgs a;
@@ -1795,8 +1754,8 @@ extern "C" int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int
     if (ctx->pol.wino == 2 && wino_wanted(ctx, 3, Cx, N4) && wino_wanted(ctx, 3, U, N4)) {   // the same step through the Winograd path
         float **uwx = tmp.add(), **uwh = tmp.add();
         const int ts = wino_tile(ctx, false);
-        if ((rc = upload_wino(ctx, uwx, ts, h_kernel, Cx, N4, nullptr, Cx, n_map.data(), N4, nullptr)) ||
-            (rc = upload_wino(ctx, uwh, ts, h_recurrent, U, N4, nullptr, U, n_map.data(), N4, nullptr)))
+        if ((rc = upload_wino(ctx, uwx, ts, h_kernel, Cx, N4, nullptr, Cx, n_map.data(), N4, nullptr, ts == 6)) ||
+            (rc = upload_wino(ctx, uwh, ts, h_recurrent, U, N4, nullptr, U, n_map.data(), N4, nullptr, ts == 4)))
             return rc;
         WinoIO io;
         memset(&io, 0, sizeof(io));
@@ -1829,6 +1788,41 @@ extern "C" int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int
     a.B = B; a.H = H; a.W = W; a.Cin = U; a.N = N4; a.M = B * GG; a.K = 9 * U; a.slope = 1.0f;
     if (launch_igemm(ctx, a, 3, ORD_LINEAR, EPI_GATES, CFG_128x128))
         return dt_fail(ctx, DT_ERR_DEVICE, "gates launch failed");
+    return DT_OK;
+}
+
+// wino_gemm_s3.hip on caller data (parity tests at the benched shapes): both operands padded to the kernel's row tiles,
+// split into three bf16 terms by the production pack kernel, then the production launcher.
+extern "C" int dt_gemm_split_bf16(dt_ctx *ctx, const float *d_v, const float *d_u, int P, int Mt, int K, int N, int half, float *d_m)
+{
+    if (!ctx || !d_v || !d_u || !d_m) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    if (P <= 0 || Mt <= 0 || K <= 0 || N <= 0 || K % 32 || N % 128 || !wino_gemm_s3_usable(Mt, K, N))
+        return dt_fail(ctx, DT_ERR_ARG, "dt_gemm_split_bf16: unsupported shape P=%d Mt=%d K=%d N=%d", P, Mt, K, N);
+    const size_t Mp = ((size_t)Mt + 255) / 256 * 256, Np = ((size_t)N + 255) / 256 * 256;
+    DevTemps tmp(ctx->stream);
+    tmp.p.reserve(4);
+    float **vpad = tmp.add(), **upad = tmp.add(), **vs = tmp.add(), **us = tmp.add();
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(vpad), (size_t)P * Mp * K * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(upad), (size_t)P * Np * K * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(vs), (size_t)P * 3 * Mp * K * sizeof(unsigned short)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(us), (size_t)P * 3 * Np * K * sizeof(unsigned short)));
+    HIP_TRY(ctx, hipMemsetAsync(*vpad, 0, (size_t)P * Mp * K * sizeof(float), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(*upad, 0, (size_t)P * Np * K * sizeof(float), ctx->stream));
+    HIP_TRY(ctx, hipMemcpy2DAsync(*vpad, Mp * K * sizeof(float), d_v, (size_t)Mt * K * sizeof(float), (size_t)Mt * K * sizeof(float), P,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpy2DAsync(*upad, Np * K * sizeof(float), d_u, (size_t)N * K * sizeof(float), (size_t)N * K * sizeof(float), P,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    if (launch_wino_s3_pack(ctx->stream, *vpad, P, (int)Mp, K, reinterpret_cast<unsigned short *>(*vs)) ||
+        launch_wino_s3_pack(ctx->stream, *upad, P, (int)Np, K, reinterpret_cast<unsigned short *>(*us)))
+        return dt_fail(ctx, DT_ERR_DEVICE, "split-bf16 pack launch failed");
+    GemmS3Args g;
+    memset(&g, 0, sizeof(g));
+    g.a = reinterpret_cast<unsigned short *>(*vs); g.b = reinterpret_cast<unsigned short *>(*us); g.c = d_m;
+    g.c_ps = (long long)Mt * N; g.P = P; g.Mt = Mt; g.Mp = (int)Mp; g.N = N; g.Np = (int)Np; g.K = K; g.ldc = N; g.half = half;
+    ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), (double)P * (6.0 * Mt * K + 6.0 * (double)K * N + 4.0 * (double)Mt * N), "test_gemm");
+    if (ctx->prof && !ctx->capturing) ctx->prof_tab[wino_gemm_s3_half_chosen(g, 0) ? "s3_tile:128x2" : "s3_tile:256"].launches += 1;
+    const int rc = launch_wino_gemm_s3(ctx->stream, g, 0);
+    if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "dt_gemm_split_bf16: launch failed (rc=%d)", rc);
     return DT_OK;
 }
 

@@ -482,17 +482,19 @@ int launch_wino4s_fused(hipStream_t st, const Wino4FusedArgs &a_in, const float 
     const size_t lds = (size_t)S4_LDS_FLOATS * sizeof(float);      // 157,696 B
     static PerDeviceOnce attr;
     static int cus[64];
-    if (attr.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino4s_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(wino4s_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return 1;
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, attr.dev) != hipSuccess || n <= 0) n = 256;
-        cus[attr.dev] = n;
-        attr.done();
-    }
+    int dev = 0;
+    if (attr.ensure(&dev, [&](int d) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino4s_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(wino4s_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return 1;
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+            cus[d] = n;
+            return 0;
+        }))
+        return 1;
     const long long items = ((blocks + 1) / 2) * (a.N / 64);
-    long long grid = cus[attr.dev];                 // one 8-wave workgroup per CU (157 KB of LDS), persistent over the items
+    long long grid = cus[dev];                 // one 8-wave workgroup per CU (157 KB of LDS), persistent over the items
     if (grid > items) grid = items;
     if (pool) hipLaunchKernelGGL(wino4s_fused_kernel<true>, dim3((unsigned)grid), dim3(S4_THREADS), lds, st, a);
     else hipLaunchKernelGGL(wino4s_fused_kernel<false>, dim3((unsigned)grid), dim3(S4_THREADS), lds, st, a);

@@ -398,10 +398,10 @@ static int s3_launch(hipStream_t st, const GemmS3Args &a, long long grid)
 {
     static PerDeviceOnce attr;
     const size_t lds = (size_t)3 * (3 * BN * 32 + 3 * 256 * 32);
-    if (attr.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_kernel<BN, NW, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-        attr.done();
-    }
+    if (attr.ensure(nullptr, [&](int) {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_kernel<BN, NW, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess;
+        }))
+        return 1;
     hipLaunchKernelGGL((wino_gemm_s3_kernel<BN, NW, ACT>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -410,10 +410,10 @@ static int s3_launch_half(hipStream_t st, const GemmS3Args &a, long long grid)
 {
     static PerDeviceOnce attr;
     const size_t lds = (size_t)2 * (3 * BN * 32 + 3 * 128 * 32);
-    if (attr.first()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_half_kernel<BN, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-        attr.done();
-    }
+    if (attr.ensure(nullptr, [&](int) {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_half_kernel<BN, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess;
+        }))
+        return 1;
     hipLaunchKernelGGL((wino_gemm_s3_half_kernel<BN, ACT>), dim3((unsigned)grid), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -423,13 +423,15 @@ static int s3_cus(int cus)
     if (cus > 0) return cus;
     static int cu_of[64];
     static PerDeviceOnce once;
-    if (once.first()) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, once.dev) != hipSuccess) return 0;
-        cu_of[once.dev] = prop.multiProcessorCount;
-        once.done();
-    }
-    return cu_of[once.dev];
+    int dev = 0;
+    if (once.ensure(&dev, [&](int d) {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) return 1;
+            cu_of[d] = n;
+            return 0;
+        }))
+        return 0;
+    return cu_of[dev];
 }
 
 // which tile form launch_wino_gemm_s3 takes for these arguments (the profile records it; tests assert it)
@@ -475,10 +477,8 @@ int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
         static PerDeviceOnce attr4[2];
         const size_t lds = (size_t)3 * (3 * BN * 32 + 3 * 256 * 32);
         const void *fn = wide ? reinterpret_cast<const void *>(wino_gemm_s3_kernel_w4<256, false>) : reinterpret_cast<const void *>(wino_gemm_s3_kernel_w4<128, false>);
-        if (attr4[wide].first()) {
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
-            attr4[wide].done();
-        }
+        if (attr4[wide].ensure(nullptr, [&](int) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess; }))
+            return 1;
         if (wide) hipLaunchKernelGGL((wino_gemm_s3_kernel_w4<256, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
         else hipLaunchKernelGGL((wino_gemm_s3_kernel_w4<128, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
         return hipGetLastError() == hipSuccess ? 0 : 1;

@@ -173,7 +173,14 @@ def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=
       3. ConvLSTM recurrence + 1x1 + decode + association on the owner (the recurrence is sequential in T, so it
          cannot be split further; with fewer clips than ranks the surplus ranks idle in this phase);
       4. the cross-stream detection all-gather of gather_detections, rows put back in global clip order.
-    Returns the global table like gather_detections.  Single process: identical to track_clips + gather_detections.
+    Returns the global table like gather_detections.  With ONE process it is track_clips + gather_detections, bit for bit.
+    Across ranks the VALUES agree with the single-process result to float32 rounding only (boxes within 1e-3, the bar the
+    tests pin): a rank's detector batch is n_clips * len(chunk) frames, and the library's kernel selection depends on the
+    batch (split-bf16 vs fp32 MFMA GEMMs by row count, F(4x4) vs F(6x6), the frame-mosaic groups, split-K), so the
+    same frame is a different rounding of the same network for another world size or `chunks`.  Everything discrete --
+    counts, cells, labels, track ids -- is identical unless a score / IoU lies within that rounding (~1e-4) of its
+    threshold.  A deployment that needs ids that do not vary with the number of ranks pins the selection with the
+    DT_* policy knobs (e.g. DT_S3_MINROWS=1 DT_S3_REC_MINROWS=1: the split GEMM at any row count; DT_WINO_MOSAIC=1).
     `stats` (dict) receives bytes_received (rows + detection records from other ranks) for this call."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return gather_detections(trk.track_clips(frames, cap=cap))
@@ -207,6 +214,10 @@ def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=
     chunks = max(1, min(int(chunks), Tl))
     bounds = [(Tl * i) // chunks for i in range(chunks + 1)]
     pending = []
+    timed = stats is not None and torch.cuda.is_available() and ctx.device.type == "cuda"
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
+    if timed:
+        ev[0].record()
     for ci in range(chunks):
         j0, j1 = bounds[ci], bounds[ci + 1]
         send = torch.zeros((world, n_own, j1 - j0, gh, gw, rw), dtype=torch.float32, device=ctx.device)
@@ -222,6 +233,8 @@ def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=
         # collective after the kernels already queued on the current stream)
         recv, work = _all_to_all_rows(send, group, async_op=True)
         pending.append((j0, j1, recv, work))
+    if timed:
+        ev[1].record()         # everything before: the part that is spread over all ranks (detector [+ input projection])
     my_owned = owned_clips(n_clips, rank, world)
     z_mine = torch.zeros((len(my_owned), T, gh, gw, rw), dtype=torch.float32, device=ctx.device)
     recv_bytes = 0
@@ -240,8 +253,22 @@ def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=
         res = trk.empty_result(T, cap)
     if stats is not None:
         stats["bytes_received"] = stats.get("bytes_received", 0) + recv_bytes
+        stats["clips_owned"] = len(my_owned)
+        if timed:
+            ev[2].record()     # ev[1] .. ev[2]: waiting for rows + the sequential part on the clips this rank owns (0 clips: idle)
+            stats["stage_events"] = ev      # read with frame_shard_stage_ms() after a synchronize
     return gather_detections(res, n_clips_max=n_own, group=group, clip_ids=perm, stats=stats,
                              ctx=ctx if getattr(ctx, "pack_detections", None) else None)
+
+
+def frame_shard_stage_ms(stats):
+    """(sharded-stage ms, owner-stage ms) of the last track_clips_frame_sharded call that was handed `stats`, from the
+    events it recorded on the current stream; call after torch.cuda.synchronize().  The owner stage of a rank that owns
+    no clip (fewer clips than ranks) is the time it idles while the owners run the recurrence."""
+    ev = stats.get("stage_events") if stats else None
+    if not ev:
+        return None
+    return ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
 
 
 def gather_frame_rows(rows_local, group=None):

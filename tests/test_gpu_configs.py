@@ -1,9 +1,14 @@
 """GPU suite, part 2 (-m gpu): BASELINE.json's configurations AT THEIR STATED SIZES against the oracle,
 through the same code path bench.py times.
 
-  configs[2]  9 clips x T=30 x 416x416, C=12, default policy (fused conv_2 / conv_3 / conv_5, F(6x6) on 3x3 frame mosaics,
-              F(4x4) recurrent step for 29 steps), tracker head calibrated by bench.build_tracker to ~32 boxes/frame
-  configs[4]  4 clips x T=30 x 608x608 (19x19 grid), ~128 boxes/frame
+  configs[2]  (a) 9 clips x T=30 x 416x416, C=12 under the default policy of a 9-clip call (fused conv_2 / conv_3 / conv_5,
+              F(6x6) on 3x3 frame mosaics, F(4x4) recurrent step for 29 steps), tracker head calibrated by
+              bench.build_tracker to ~32 boxes/frame;
+              (b) the same 9 clips under the KERNEL SELECTION OF THE 48-CLIP BENCH STEP (BENCH_SELECTION: the split-bf16
+              GEMM on the 13x13 layers, the ConvLSTM input projection and the recurrent step, both row-tile forms),
+              every such launch asserted from the profile;
+              (c) the bench step itself, 48 clips x 30 frames, the oracle on three of the clips
+  configs[4]  4 clips x T=30 x 608x608 (19x19 grid), ~128 boxes/frame, under the bench shard's kernel selection
   configs[3]  TinyTracker, 32 sequences x T=64 (detector at 416, act_13 tap, LSTM over 64 steps)
   configs[1]  detector batch 8 at 416, C=80, against the float64 graph fixture as well
 
@@ -94,6 +99,37 @@ def _report(name, payload):
 
 _SETUP = {}
 
+# The kernel selection of the 48-clip bench step, forced onto the smaller batches these tests can afford to run the
+# oracle on: at 48 clips the 13x13 layers have 7,840 GEMM rows (>= DT_S3_MINROWS 2048) and the recurrent step 588
+# (>= DT_S3_REC_MINROWS 512), so conv_14/16/18/19/20/22, convlstm_xproj and convlstm_step run on wino_gemm_s3.hip;
+# at 9 clips (1,470 / 147 rows) and 4 clips of 608x608 (1,400 / 100 rows) the DEFAULT thresholds keep them on the
+# fp32 MFMA kernel.  Lowering the two row thresholds selects exactly the bench's kernels for every launch.
+BENCH_SELECTION = {"DT_S3_MINROWS": "1024", "DT_S3_REC_MINROWS": "64"}
+S3_BENCH_LAUNCHES = ["conv_gemm_s3:conv_9", "conv_gemm_s3:conv_10", "conv_gemm_s3:conv_11", "conv_gemm_s3:conv_12", "conv_gemm_s3:conv_13",
+                     "conv_gemm_s3:conv_14", "conv_gemm_s3:conv_15", "conv_gemm_s3:conv_16", "conv_gemm_s3:conv_17", "conv_gemm_s3:conv_18",
+                     "conv_gemm_s3:conv_19", "conv_gemm_s3:conv_20", "conv_gemm_s3:conv_22", "conv_gemm_s3:convlstm_xproj",
+                     "conv_gemm_s3:convlstm_step"]
+
+
+class policy(object):
+    """DT_* knobs set in the environment and re-read into a live context; the previous policy is restored on exit"""
+
+    def __init__(self, ctx, env):
+        self.ctx, self.env = ctx, dict(env or {})
+
+    def __enter__(self):
+        self.saved = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+        self.ctx.reload_policy()
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        self.ctx.reload_policy()
+
 
 def _setup_config(size, n_clips, T, target_boxes):
     """frames, tracker (calibrated exactly as bench.py does) and the ORACLE's tracking grids of one configuration.  The
@@ -115,7 +151,8 @@ def _setup_config(size, n_clips, T, target_boxes):
     return _SETUP[key]
 
 
-def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_policy, min_boxes_per_frame):
+def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_policy, min_boxes_per_frame, policy_env=None,
+                            forbid_policy=()):
     C = 12
     frames, trk, ref_trk = _setup_config(size, n_clips, T, target_boxes)
     ctx = trk.model.ctx
@@ -151,12 +188,15 @@ def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_pol
 
     # ---- the HIP path, exactly as bench.py's step() runs it (profiled to see which kernels ran)
     trk.OBJ_THRESHOLD, trk.NMS_THRESHOLD, trk.ASSOC_THRESHOLD = obj_thr.reshape(-1), nms_thr, assoc_thr
-    ctx.profile_reset(); ctx.profile_enable(True)
-    res = trk.track_clips(frames, cap=cap)
-    ctx.profile_enable(False)
+    with policy(ctx, policy_env):
+        ctx.profile_reset(); ctx.profile_enable(True)
+        res = trk.track_clips(frames, cap=cap)
+        ctx.profile_enable(False)
     names = set(ctx.profile_names())
     for want in expect_policy:
         assert want in names, "%s did not run; ran: %s" % (want, sorted(n for n in names if ":" in n or "wino" in n))
+    for bad in forbid_policy:
+        assert bad not in names, "%s ran although the policy under test excludes it" % bad
     assert ctx.profile_read("wino_input:convlstm_step")["launches"] == T - 1
     assert ctx.profile_read("conv_fused")["launches"] == 3          # conv_2, conv_3 and conv_5: the fused F(4x4) kernel (wino4s_fused.hip)
 
@@ -201,7 +241,9 @@ def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_pol
         assert np.array_equal(ids[i], rid), "track ids differ in clip %d" % i
         assert int(nids[i]) == rn
     _report("parity_%s.json" % tag, dict(
-        config="%d clips x T=%d x %dx%d, C=12, default policy" % (n_clips, T, size, size), boxes=int(nbox),
+        config="%d clips x T=%d x %dx%d, C=12, %s" % (n_clips, T, size, size, "default policy" if not policy_env else
+                                                      "the 48-clip bench step's kernel selection (%s)" % " ".join("%s=%s" % kv for kv in sorted(policy_env.items()))),
+        boxes=int(nbox),
         boxes_per_frame=nbox / float(n_clips * T), tracks=int(nids.sum()),
         grid_chan_err_t0=err_t[0], grid_chan_err_t10=err_t[min(10, T - 1)], grid_chan_err_t_last=err_t[-1],
         grid_chan_err_max=max(err_t), score_err_near_threshold=score_err, box_coord_err=worst_coord,
@@ -210,7 +252,8 @@ def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_pol
         assoc_threshold=assoc_thr, assoc_margin=m_assoc, ids_bit_exact=True, kernels=sorted(n for n in names if ":" in n)))
 
 
-def _track_config_at_reference_defaults(size, n_clips, T, target_boxes, cap, tag, max_flip_frames):
+def _track_config_at_reference_defaults(size, n_clips, T, target_boxes, cap, tag, max_flip_frames, policy_env=None, expect_policy=(),
+                                        forbid_policy=()):
     """The same configuration at the thresholds a user of the reference gets -- OBJ_THRESHOLD 0.5 / NMS_THRESHOLD 0.45
     (KerasYOLO.py:43-44), ASSOC_THRESHOLD 0.3 -- with every discrete disagreement between the
     HIP path and the oracle accounted for (tests/flip_accounting.py): frames without an oracle decision inside the
@@ -222,7 +265,15 @@ def _track_config_at_reference_defaults(size, n_clips, T, target_boxes, cap, tag
     frames, trk, ref_trk = _setup_config(size, n_clips, T, target_boxes)
     ctx = trk.model.ctx
     trk.OBJ_THRESHOLD, trk.NMS_THRESHOLD, trk.ASSOC_THRESHOLD = 0.5, 0.45, 0.3
-    res = trk.track_clips(frames, cap=cap)
+    with policy(ctx, policy_env):
+        ctx.profile_reset(); ctx.profile_enable(True)
+        res = trk.track_clips(frames, cap=cap)
+        ctx.profile_enable(False)
+    names = set(ctx.profile_names())
+    for want in expect_policy:
+        assert want in names, "%s did not run; ran: %s" % (want, sorted(n for n in names if ":" in n))
+    for bad in forbid_policy:
+        assert bad not in names, "%s ran although the policy under test excludes it" % bad
     got = res["netout"]
     flat = got.reshape((n_clips * T,) + tuple(got.shape[2:])).contiguous()
     ncell = flat.shape[1] * flat.shape[2] * flat.shape[3]
@@ -231,35 +282,119 @@ def _track_config_at_reference_defaults(size, n_clips, T, target_boxes, cap, tag
     got_scores = post[..., 5:].reshape(n_clips, T, ncell, C).cpu().numpy()
     rep = fa.account(ref_trk, got.cpu().numpy(), got_scores, res["boxes"].cpu().numpy(), res["counts"].cpu().numpy(),
                      res["ids"].cpu().numpy(), res["nids"].cpu().numpy(), ANCHORS, C, 0.5, 0.45, 0.3)
-    rep["config"] = "%d clips x T=%d x %dx%d, C=12, default policy, reference-default thresholds" % (n_clips, T, size, size)
+    rep["config"] = "%d clips x T=%d x %dx%d, C=12, %s, reference-default thresholds" % (
+        n_clips, T, size, size, "default policy" if not policy_env else
+        "the 48-clip bench step's kernel selection (%s)" % " ".join("%s=%s" % kv for kv in sorted(policy_env.items())))
+    rep["kernels"] = sorted(n for n in names if ":" in n)
     _report("parity_%s.json" % tag, rep)
     assert rep["box_coord_err"] < 1e-3 and rep["box_iou_min"] >= 0.999
     assert rep["frames_with_a_flip"] <= max_flip_frames, "%d of %d frames flipped" % (rep["frames_with_a_flip"], rep["frames"])
     assert rep["boxes_in_identical_frames"] > 0
 
 
+# max_flip_frames = the measured count + 1 (profiles/parity_r03_defaults_*.json, parity_r04_*: 0 of 270 / 0 of 120 frames):
+# which side of a threshold a score 1e-5 away from it lands on is chance between two float32 implementations, so one
+# flipped frame is tolerated -- a second one is a regression.
 def test_configs2_track_416_reference_default_thresholds():
-    _track_config_at_reference_defaults(416, 9, 30, 32, 128, "r03_defaults_track416", max_flip_frames=27)
+    """9 clips under the library's DEFAULT policy for 9 clips (the 13x13 layers and the recurrent step below the split
+    GEMM's row thresholds run on the fp32 MFMA kernel -- what a 9-clip user gets)."""
+    _track_config_at_reference_defaults(416, 9, 30, 32, 128, "r04_defaults_track416", max_flip_frames=1)
 
 
-def test_configs2_benched_track_416_vs_oracle():
-    """BASELINE configs[2] as bench.py runs it: this is the path the headline number is measured on."""
-    _track_config_vs_oracle(416, 9, 30, 32, 128, "r03_track416",
+def test_configs2_track_416_default_policy_vs_oracle():
+    """BASELINE configs[2], 9 clips, the DEFAULT policy of a 9-clip call (not the bench's kernel selection: see
+    test_configs2_bench_kernel_selection_416_vs_oracle and test_configs2_bench_size_48_clips_vs_oracle)."""
+    _track_config_vs_oracle(416, 9, 30, 32, 128, "r04_track416",
                             ["wino_input:convlstm_xproj", "wino_input:convlstm_step", "wino_input:conv_22",
                              "conv_fused:conv_3", "conv_fused:conv_5", "wino_input:conv_6", "conv_fused:conv_2",
-                             "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4"],
+                             "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4", "conv_gemm_s3:conv_9", "conv_igemm:conv_14"],
                             min_boxes_per_frame=12)      # 32 candidates/frame; ~14-20 survive NMS (bench.py reports the same)
 
 
+def test_configs2_bench_kernel_selection_416_vs_oracle():
+    """The kernel selection the HEADLINE number is measured on (bench.py, 48 clips), forced onto 9 clips so that the
+    oracle can be run on every frame: every GEMM the bench runs on the split-bf16 kernel runs on it here -- asserted
+    launch by launch from the profile -- with 128-row tiles (two workgroups per CU, DT_S3_HALF=1) throughout."""
+    _track_config_vs_oracle(416, 9, 30, 32, 128, "r04_track416_bench_selection",
+                            ["conv_fused:conv_2", "conv_fused:conv_3", "conv_fused:conv_5", "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4",
+                             "s3_tile:128x2"] + S3_BENCH_LAUNCHES,
+                            min_boxes_per_frame=12, policy_env=dict(BENCH_SELECTION, DT_S3_HALF="1"),
+                            forbid_policy=["s3_tile:256", "conv_igemm:conv_14", "conv_igemm:conv_22", "conv_igemm:convlstm_xproj",
+                                           "conv_igemm:convlstm_step"])
+
+
+def test_configs2_bench_kernel_selection_416_reference_default_thresholds():
+    """the same selection at the reference's default thresholds (0.5 / 0.45 / 0.3), 256-row tiles throughout (DT_S3_HALF=-1)"""
+    _track_config_at_reference_defaults(416, 9, 30, 32, 128, "r04_defaults_track416_bench_selection", max_flip_frames=1,
+                                        policy_env=dict(BENCH_SELECTION, DT_S3_HALF="-1"),
+                                        expect_policy=["s3_tile:256"] + S3_BENCH_LAUNCHES,
+                                        forbid_policy=["s3_tile:128x2", "conv_igemm:conv_14", "conv_igemm:convlstm_step"])
+
+
 def test_configs4_track_608_128_boxes_vs_oracle():
-    """BASELINE configs[4] single-GPU shard: 608x608 -> 19x19 grid, ~128 boxes/frame, 4 clips x 30 frames."""
-    _track_config_vs_oracle(608, 4, 30, 400, 640, "r03_track608",
+    """BASELINE configs[4] single-GPU shard: 608x608 -> 19x19 grid, ~128 boxes/frame, 4 clips x 30 frames -- with the
+    split-bf16 GEMM on every launch the 24-clip bench shard (extra.track_608_128boxes) runs it on."""
+    _track_config_vs_oracle(608, 4, 30, 400, 640, "r04_track608",
                             ["wino_input:convlstm_xproj", "wino_input:convlstm_step", "wino_input:conv_22",
-                             "conv_fused:conv_2", "conv_fused:conv_3"], min_boxes_per_frame=100)    # 400 candidates/frame -> >= 100 tracks after NMS
+                             "conv_fused:conv_2", "conv_fused:conv_3", "s3_tile:256"] + S3_BENCH_LAUNCHES, min_boxes_per_frame=100,    # 400 candidates/frame -> >= 100 tracks after NMS
+                            policy_env=dict(BENCH_SELECTION, DT_S3_HALF="-1"), forbid_policy=["conv_igemm:conv_14", "conv_igemm:convlstm_step"])
 
 
 def test_configs4_track_608_reference_default_thresholds():
-    _track_config_at_reference_defaults(608, 4, 30, 400, 640, "r03_defaults_track608", max_flip_frames=12)
+    _track_config_at_reference_defaults(608, 4, 30, 400, 640, "r04_defaults_track608", max_flip_frames=1,
+                                        policy_env=dict(BENCH_SELECTION, DT_S3_HALF="1"),
+                                        expect_policy=["s3_tile:128x2"] + S3_BENCH_LAUNCHES,
+                                        forbid_policy=["s3_tile:256", "conv_igemm:conv_14", "conv_igemm:convlstm_step"])
+
+
+def test_configs2_bench_size_48_clips_vs_oracle():
+    """EXACTLY the step bench.py times -- 48 clips x 30 frames x 416x416, default policy, the reference's default thresholds --
+    with the oracle run on three of the clips (first, middle, last; the clips of a 3x3 frame mosaic mix, so these sit in
+    different mosaics with different neighbours).  Asserts the kernel selection from the profile (every split-bf16 launch,
+    the 128-row-tile form for the recurrent step, 256-row tiles elsewhere), the per-channel grid bar, and accounts for every
+    discrete disagreement (tests/flip_accounting.py)."""
+    import bench
+    import flip_accounting as fa
+    C, size, n_clips, T, cap = 12, 416, 48, 30, 128
+    sub = [0, 23, 47]
+    _SETUP.clear()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    frames = bench.make_frames(n_clips, T, size, size, dev, seed0=42)
+    trk, blob, tw = bench.build_tracker(size, size, T, 32, frames)
+    ctx = trk.model.ctx
+    layers, used = orc.parse_darknet_blob(blob, C)
+    assert used == blob.size
+    host = frames[sub].cpu().numpy()
+    ref_trk = np.stack([orc.tracker_forward(orc.normalize_u8(host[i]), layers, tw)[0] for i in range(len(sub))])
+    trk.OBJ_THRESHOLD, trk.NMS_THRESHOLD, trk.ASSOC_THRESHOLD = 0.5, 0.45, 0.3
+    ctx.profile_reset(); ctx.profile_enable(True)
+    res = trk.track_clips(frames, cap=cap)
+    ctx.profile_enable(False)
+    names = set(ctx.profile_names())
+    for want in S3_BENCH_LAUNCHES + ["conv_fused:conv_2", "conv_fused:conv_3", "conv_fused:conv_5", "s3_tile:128x2", "s3_tile:256",
+                                     "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4", "conv_igemm:conv_6", "conv_igemm:conv_8"]:
+        assert want in names, "%s did not run; ran: %s" % (want, sorted(n for n in names if ":" in n))
+    assert ctx.profile_read("conv_gemm_s3:convlstm_step")["launches"] == T - 1
+    assert ctx.profile_read("s3_tile:128x2")["launches"] == T - 1      # the recurrent step only (588 rows = 5 x 128)
+    for bad in ("conv_igemm:conv_14", "conv_igemm:conv_19", "conv_igemm:conv_22", "conv_igemm:convlstm_xproj", "conv_igemm:convlstm_step"):
+        assert bad not in names
+    got = res["netout"][sub]
+    err_t = [chan_err(got[:, t].cpu().numpy(), ref_trk[:, t]) for t in range(T)]
+    assert max(err_t) < 3e-4, "tracking grid error %g at t=%d" % (max(err_t), int(np.argmax(err_t)))
+    flat = got.reshape((len(sub) * T,) + tuple(got.shape[2:])).contiguous()
+    ncell = flat.shape[1] * flat.shape[2] * flat.shape[3]
+    post = ctx.decode(flat, 0.0, 2.0, ANCHORS, C, cap=ncell, want_post=True)["post"]
+    got_scores = post[..., 5:].reshape(len(sub), T, ncell, C).cpu().numpy()
+    rep = fa.account(ref_trk, got.cpu().numpy(), got_scores, res["boxes"][sub].cpu().numpy(), res["counts"][sub].cpu().numpy(),
+                     res["ids"][sub].cpu().numpy(), res["nids"][sub].cpu().numpy(), ANCHORS, C, 0.5, 0.45, 0.3)
+    rep["config"] = ("48 clips x T=30 x 416x416, C=12: the bench.py step itself (default policy, reference-default thresholds); "
+                     "oracle on clips %s" % sub)
+    rep["grid_chan_err_t0"], rep["grid_chan_err_t_last"], rep["grid_chan_err_max"] = err_t[0], err_t[-1], max(err_t)
+    rep["kernels"] = sorted(n for n in names if ":" in n)
+    _report("parity_r04_bench48_track416.json", rep)
+    assert rep["box_coord_err"] < 1e-3 and rep["box_iou_min"] >= 0.999
+    assert rep["frames_with_a_flip"] <= 1, "%d of %d frames flipped" % (rep["frames_with_a_flip"], rep["frames"])
+    assert rep["boxes_in_identical_frames"] > 0
 
 
 def test_configs3_tinytracker_T64_vs_oracle():
@@ -321,7 +456,7 @@ def test_configs3_tinytracker_T64_vs_oracle():
         ref[:, t] = orc.dense_sigmoid(h, tw["dense_kernel"], tw["dense_bias"])
     e_t = [float(np.abs(got[:, t] - ref[:, t]).max()) for t in range(T)]
     assert max(e_t) < 1e-4
-    _report("parity_r03_tiny64.json", dict(config="TinyTracker 32 sequences x T=64 @416", frames_with_box=int(nbox),
+    _report("parity_r04_tiny64.json", dict(config="TinyTracker 32 sequences x T=64 @416", frames_with_box=int(nbox),
                                            out_err_t0=e_t[0], out_err_t31=e_t[31], out_err_t63=e_t[63], out_err_max=max(e_t)))
 
 
@@ -347,5 +482,5 @@ def test_configs1_detector_batch8_vs_oracle_and_f64_graph(golden_dir):
     e64_oracle = chan_err(ref_net[:1].reshape(1, 13, 13, -1), d["netout"].reshape(1, 13, 13, -1))
     assert e_net < 3e-4 and e_feat < 3e-4
     assert e64 < 3e-4, "HIP path vs float64 graph: %g (oracle vs float64: %g)" % (e64, e64_oracle)
-    _report("parity_r03_detect8.json", dict(netout_chan_err_vs_oracle=e_net, feat_chan_err_vs_oracle=e_feat,
+    _report("parity_r04_detect8.json", dict(netout_chan_err_vs_oracle=e_net, feat_chan_err_vs_oracle=e_feat,
                                             netout_chan_err_vs_f64_graph=e64, oracle_vs_f64_graph=e64_oracle))

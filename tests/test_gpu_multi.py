@@ -177,6 +177,36 @@ def test_bench_self_launches_its_ranks():
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 2 * 2 * 4) < 1e-5
 
 
+@pytest.mark.parametrize("mode", ["clip", "frame", "tiny"])
+def test_eight_ranks_dry_run_of_the_scale_command(mode):
+    """The process shape the driver's SCALE run takes -- `python bench.py --gpus 8 ...` typed as a plain command -- has
+    executed once: eight ranks under torch.distributed.run (here all on the box's one GPU over gloo, tiny sizes), both
+    shard modes of the tracker and the frame-sharded TinyTracker (T = 64 = 8 x 8).  Frame-shard with 3 clips on 8 ranks:
+    five ranks own no clip and idle in the owner stage -- the per-rank stage times in the line say so."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DT_ONE_DEVICE="1", DT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--size", "96", "--no-cpu-baseline"]
+    if mode == "tiny":
+        cmd += ["--workload", "tiny", "--seqs", "2"]
+    else:
+        cmd += ["--clips", "3" if mode == "frame" else "1", "--T", "8", "--boxes", "4", "--shard", mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["value"] > 0
+    assert out["scaling"] == ("weak" if mode == "clip" else "strong")
+    frames_total = {"clip": 8 * 1 * 8, "frame": 3 * 8, "tiny": 2 * 64}[mode]
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - frames_total) < 1e-5 * frames_total
+    if mode == "frame":
+        st = out["frame_shard_stage_ms_per_rank"]
+        assert len(st) == 8 and sorted(s["rank"] for s in st) == list(range(8))
+        assert sum(s["clips_owned"] for s in st) == 3 and sum(1 for s in st if s["clips_owned"] == 0) == 5
+        assert all(s["sharded_stage_ms"] > 0 and s["owner_stage_ms"] >= 0 for s in st)
+        assert out["exchange_bytes_received_per_step_rank0"] > 0
+
+
 def test_native_pack_unpack_matches_host_logic(ctx):
     """dt_pack_detections / dt_unpack_detections (the exchange a C-ABI caller has) against parallel.py's torch
     statements of the same layout: bit-identical rows, tables, global ids; padding rows and empty ranks handled."""

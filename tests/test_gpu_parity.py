@@ -1109,13 +1109,12 @@ def test_graph_replay_lstm_sequence(ctx):
     c.close()
 
 
-# ---- conv_2 as one fused Winograd F(2x2,3x3) + LeakyReLU + max-pool kernel (csrc/wino_fused.hip) -----------
+# ---- conv_2's shape (32 -> 64 channels, pooled) through the fused F(4x4,3x3) kernel (csrc/wino4s_fused.hip) ---------
 @pytest.mark.parametrize("B,H,W", [(2, 16, 16), (3, 32, 48), (1, 18, 34), (2, 2, 2), (5, 104, 104)])
 def test_conv2_fused_winograd_vs_oracle(ctx, monkeypatch, B, H, W):
     """32 -> 64 channels with the 2x2 pooling epilogue through the fused kernel (forced at any size): whole and
-    partial 8x8-tile workgroups, image borders, several frames; F(2x2,3x3) rounds like the direct form."""
-    monkeypatch.setenv("DT_WINO_FUSED", "2")
-    monkeypatch.setenv("DT_W4S", "1")          # the default (2) hands conv_2's shape to the F(4x4) kernel when there are enough blocks
+    partial 16x16-pixel blocks, image borders, several frames; against the oracle and against the direct form."""
+    monkeypatch.setenv("DT_WINO_FUSED4", "2")
     rs = np.random.RandomState(B * 100 + H + W)
     x = rs.randn(B, H, W, 32).astype(np.float32)
     w = (rs.randn(3, 3, 32, 64) * np.sqrt(2.0 / (9 * 32))).astype(np.float32)
@@ -1126,32 +1125,34 @@ def test_conv2_fused_winograd_vs_oracle(ctx, monkeypatch, B, H, W):
     got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=1)
     ctx.profile_enable(False)
     assert ctx.profile_read("conv_fused")["launches"] == 1
-    assert relerr(got.cpu().numpy(), ref) < 2e-5
-    monkeypatch.setenv("DT_WINO_FUSED", "0")
+    assert relerr(got.cpu().numpy(), ref) < 1e-4            # F(4x4,3x3): ~15x the direct form's rounding error
+    monkeypatch.setenv("DT_WINO_FUSED4", "0")
+    ctx.profile_reset(); ctx.profile_enable(True)
     direct = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=1)
-    assert relerr(got.cpu().numpy(), direct.cpu().numpy()) < 2e-5
+    ctx.profile_enable(False)
+    assert ctx.profile_read("conv_fused")["launches"] == 0
+    assert relerr(got.cpu().numpy(), direct.cpu().numpy()) < 1e-4
 
 
 def test_conv2_fused_winograd_one_hot(ctx, monkeypatch):
-    """one-hot taps on integer data: exact, and any misplaced tile / channel / position is off by >= 1"""
-    monkeypatch.setenv("DT_WINO_FUSED", "2")
-    monkeypatch.setenv("DT_W4S", "1")
+    """one-hot taps on small integers: any misplaced tile / channel / position is off by >= 1"""
+    monkeypatch.setenv("DT_WINO_FUSED4", "2")
     B, H, W = 2, 20, 12
     x = (np.arange(B * H * W * 32, dtype=np.float32).reshape(B, H, W, 32) % 251)
     w = np.zeros((3, 3, 32, 64), dtype=np.float32)
     for n in range(64):
         w[n % 3, (n // 3) % 3, (n * 7) % 32, n] = 1.0
     got = ctx.conv2d(dev(x, ctx), w, None, leaky_slope=1.0, pool=1).cpu().numpy()
-    assert np.array_equal(got, orc.maxpool2(orc.conv2d(x, w)))
+    assert np.abs(got - orc.maxpool2(orc.conv2d(x, w))).max() < 0.05
 
 
 @pytest.mark.parametrize("mode", ["default", "all_winograd"])
 def test_detector_non_square_odd_grid_vs_oracle(ctx, monkeypatch, mode):
     """352x288 frames (grid 11x9: odd, non-square, not a multiple of any Winograd tile), 5 frames (ragged mosaic
-    groups, partial 8x8 workgroups of the fused conv_2 kernel at 88x72 pooled pixels): whole detector vs oracle."""
+    groups, partial 16x16-pixel blocks of the fused kernel at 176x144 / 88x72 pixels): whole detector vs oracle."""
     if mode == "all_winograd":
         monkeypatch.setenv("DT_WINO", "2")
-        monkeypatch.setenv("DT_WINO_FUSED", "2")
+        monkeypatch.setenv("DT_WINO_FUSED4", "2")
     det, layers, _ = _detector(ctx, 352, 288, 12)
     frames = synth.synth_clip(5, 352, 288, 3, seed=21)
     ref_net, ref_feat, _ = orc.yolov2_forward(orc.normalize_u8(frames), layers)
@@ -1196,7 +1197,7 @@ def test_winograd_randomized_shapes_vs_oracle(ctx, monkeypatch):
         assert e < {2: 2e-5, 4: 1e-4, 6: 3e-4}[ts], (it, ts, B, H, W, Cin, Cout, pool, mos, e)
 
 
-# ---- conv_3/5/6/8 as one fused Winograd F(4x4,3x3) kernel (csrc/wino4_fused.hip) ---------------------------
+# ---- conv_3/5/6/8 as one fused Winograd F(4x4,3x3) kernel (csrc/wino4s_fused.hip) --------------------------
 @pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [
     (2, 16, 16, 64, 128, 0),      # exactly one 16x16-pixel block per frame
     (3, 32, 48, 64, 128, 1),      # pooled output only (conv_5's epilogue), several blocks
@@ -1205,10 +1206,8 @@ def test_winograd_randomized_shapes_vs_oracle(ctx, monkeypatch):
     (1, 13, 13, 128, 256, 0),     # odd size, smaller than a block
     (5, 104, 104, 64, 128, 0),    # conv_3's real geometry (6.5 blocks per side)
 ])
-@pytest.mark.parametrize("w4s", [1, 0])      # 1: the LDS-staged persistent kernel (wino4s_fused.hip), 0: wino4_fused.hip
-def test_conv_fused_f4x4_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool, w4s):
+def test_conv_fused_f4x4_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool):
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
-    monkeypatch.setenv("DT_W4S", str(w4s))
     rs = np.random.RandomState(B * 100 + H + W + Cin)
     x = rs.randn(B, H, W, Cin).astype(np.float32)
     w = (rs.randn(3, 3, Cin, Cout) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
@@ -1229,9 +1228,8 @@ def test_conv_fused_f4x4_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool, w
 
 @pytest.mark.parametrize("B,H,W,pool", [(3, 32, 48, 1), (2, 208, 208, 1), (1, 26, 22, 0)])
 def test_conv2_shape_through_staged_f4x4_kernel(ctx, monkeypatch, B, H, W, pool):
-    """DT_W4S=2: conv_2's shape (32 -> 64 channels, pooled) through the LDS-staged F(4x4) kernel instead of its F(2x2) one"""
+    """conv_2's shape (32 -> 64 channels) through the fused F(4x4) kernel: pooled and plain epilogue, the real 208x208 geometry"""
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
-    monkeypatch.setenv("DT_W4S", "2")
     rs = np.random.RandomState(B + H + W)
     x = rs.randn(B, H, W, 32).astype(np.float32)
     w = (rs.randn(3, 3, 32, 64) * np.sqrt(2.0 / (9 * 32))).astype(np.float32)
@@ -1247,11 +1245,9 @@ def test_conv2_shape_through_staged_f4x4_kernel(ctx, monkeypatch, B, H, W, pool)
     assert relerr(got.cpu().numpy(), ref) < 1e-4
 
 
-@pytest.mark.parametrize("w4s", [1, 0])
-def test_conv_fused_f4x4_one_hot(ctx, monkeypatch, w4s):
+def test_conv_fused_f4x4_one_hot(ctx, monkeypatch):
     """one-hot taps on small integers: every position / tile offset / channel slot of the fused kernel must line up"""
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
-    monkeypatch.setenv("DT_W4S", str(w4s))
     B, H, W, Cin, Cout = 2, 20, 36, 64, 128
     x = (np.arange(B * H * W * Cin, dtype=np.float32).reshape(B, H, W, Cin) % 251)
     w = np.zeros((3, 3, Cin, Cout), dtype=np.float32)
@@ -1328,6 +1324,55 @@ def test_split_bf16_gemm_error_against_float64(ctx, monkeypatch):
         err[s3] = np.sqrt(np.mean((got - ref64) ** 2)) / np.sqrt(np.mean(ref64 ** 2))
     assert err["2"] < 1.1 * err["0"] + 1e-8, err
     assert err["2"] < 5e-5, err
+
+
+@pytest.mark.parametrize("P,Mt,K,N,half,what", [
+    (64, 7840, 1024, 1024, -1, "conv_19 / conv_20 at 48 clips (160 3x3 mosaics x 49 tiles), 256-row tiles"),
+    (64, 7840, 1280, 1024, -1, "conv_22"),
+    (64, 7840, 512, 1024, -1, "conv_14 / 16 / 18"),
+    (64, 7840, 1120, 2048, -1, "convlstm_xproj (K = 1109 padded to 1120)"),
+    (64, 29160, 256, 512, -1, "conv_9 / conv_11 (26x26 on 2x2 mosaics)"),
+    (36, 588, 512, 2048, 1, "convlstm_step at 48 clips: F(4x4), 128-row tiles, two workgroups per CU"),
+    (36, 588, 512, 2048, -1, "convlstm_step, 256-row tiles"),
+    (1, 243360, 1024, 512, -1, "conv_15 / conv_17 as one split GEMM over 1440 x 169 pixels"),
+])
+def test_split_bf16_gemm_benched_shapes_against_float64(ctx, P, Mt, K, N, half, what):
+    """wino_gemm_s3.hip AT THE SHAPES THE BENCH STEP LAUNCHES (48 clips x 30 frames x 416x416), through the production
+    pack kernel and launcher (dt_gemm_split_bf16), against float64 products of the same fp32 operands.  Operands spread
+    over 13 binades.  Error relative to sum_k |v||u| (the scale fp32 rounding is relative to): the split form must stay at
+    the level of an fp32 accumulation -- rms below 2^-24 x 0.75 (measured 3.7e-8; an fp32 fmaf chain on such data: 4.4e-8)
+    and not above 1.25 x the error of the fp32 library GEMM (torch.bmm, fp32 MFMA) on the same data; max below 3e-7."""
+    t = torch
+    g = t.Generator(device=ctx.device)
+    g.manual_seed(1000 + K + N)
+    v = t.randn((P, Mt, K), generator=g, device=ctx.device) * t.exp2(t.randint(-6, 7, (P, Mt, K), generator=g, device=ctx.device).float())
+    u = t.randn((P, N, K), generator=g, device=ctx.device) * t.exp2(t.randint(-3, 4, (P, N, K), generator=g, device=ctx.device).float()) / float(np.sqrt(K))
+    ctx.profile_reset(); ctx.profile_enable(True)
+    got = ctx.gemm_split_bf16(v, u, half=half)
+    ctx.profile_enable(False)
+    assert ctx.profile_read("s3_tile:128x2" if half > 0 else "s3_tile:256")["launches"] == 1
+    se = sf = 0.0
+    me = mf = 0.0
+    n = 0
+    step = max(1, int(2.5e8 // (Mt * max(K, N))))          # positions per float64 chunk (<= 2 GB per operand)
+    for p0 in range(0, P, step):
+        for m0 in range(0, Mt, 65536):
+            vv = v[p0:p0 + step, m0:m0 + 65536]
+            uu = u[p0:p0 + step]
+            ref = t.bmm(vv.double(), uu.double().transpose(1, 2))
+            scale = t.bmm(vv.double().abs(), uu.double().abs().transpose(1, 2))
+            e = (got[p0:p0 + step, m0:m0 + 65536].double() - ref).abs() / scale
+            f = (t.bmm(vv, uu.transpose(1, 2)).double() - ref).abs() / scale
+            se += float((e * e).sum()); sf += float((f * f).sum()); n += e.numel()
+            me = max(me, float(e.max())); mf = max(mf, float(f.max()))
+    rms_e, rms_f = float(np.sqrt(se / n)), float(np.sqrt(sf / n))
+    print("gemm_s3 P=%d Mt=%d K=%d N=%d half=%d: rms %.3g max %.3g | fp32 library GEMM rms %.3g max %.3g  (%s)" % (P, Mt, K, N, half, rms_e, me, rms_f, mf, what))
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "parity_r04_gemm_s3_f64.txt"), "a") as fh:
+        fh.write("P=%d Mt=%d K=%d N=%d half=%d  split-bf16: rms %.4g max %.4g   fp32 library GEMM: rms %.4g max %.4g   # %s\n" % (P, Mt, K, N, half, rms_e, me, rms_f, mf, what))
+    assert rms_e < 4.5e-8 and me < 3e-7, (rms_e, me)
+    assert rms_e < 1.25 * rms_f + 2e-9, (rms_e, rms_f)
 
 
 def test_split_bf16_gemm_one_hot_taps(ctx, monkeypatch):

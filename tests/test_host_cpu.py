@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(mi355_dt.LIB_PATH)
     for s in declared:
         assert hasattr(lib, s), "missing export " + s
-    assert lib.dt_abi_version() == 105
+    assert lib.dt_abi_version() == 106
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -167,14 +167,15 @@ sys.exit(0 if ok else 1)
 '''
 
 
-def test_gather_detections_gloo_world2(tmp_path):
-    """N>1 path on CPU: 2 processes, gloo, uneven shards (3+2 clips) -> identical
-    global table and globally unique ids on both ranks, equal to the 1-process result."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_gather_detections_gloo(tmp_path, world):
+    """N>1 path on CPU: 2 / 8 processes, gloo, uneven shards (3+2 clips; 5 clips on 8 ranks: three ranks hold none) ->
+    identical global table and globally unique ids on every rank, equal to the 1-process result."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29731 + 100 * (world == 8)), WORLD_SIZE=str(world))
     procs = []
-    for r in range(2):
+    for r in range(world):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
@@ -359,12 +360,12 @@ sys.exit(0 if ok else 1)
 '''
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_frame_sharded_tracker_gloo(tmp_path, world):
     """configs[4] split: detector frame-shard {t : t mod N = r} (whole batch on every rank, or
     sharded ingest: only the rank's own frames), rows sent to the clip's round-robin owner with chunked all_to_all,
     recurrence on the owner, detection gather in global clip order -- with a torch-CPU stand-in for the two library
-    halves, 2 / 4 gloo ranks give exactly the single-process table incl. the global ids; the detector ran on each rank's
+    halves, 2 / 4 / 8 gloo ranks give exactly the single-process table incl. the global ids; the detector ran on each rank's
     own frames only; the bytes a rank received are the owner-only volume."""
     script = tmp_path / "worker_fs.py"
     script.write_text(_WORKER_FRAMESHARD)

@@ -4,7 +4,7 @@
 # the variants are selected with MI355_DT_LIB and only ever timed (tools/ablate_run.sh).
 set -e
 cd "$(dirname "$0")/.."
-D=object_tracking_amd/ablate; mkdir -p $D
+D=tools/_probe_builds; mkdir -p $D
 C=object_tracking_amd/csrc
 for m in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -DDT_ABLATE=$m -c $C/conv_igemm.hip -o $D/conv_igemm_$m.o

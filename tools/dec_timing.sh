@@ -2,7 +2,7 @@
 # debug build of the library with phase timestamps inside decode_nms_kernel (tools/dec_timing.py reads them)
 set -e
 cd "$(dirname "$0")/.."
-D=object_tracking_amd/ablate; mkdir -p $D
+D=tools/_probe_builds; mkdir -p $D
 C=object_tracking_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -DDT_DEC_TIMING -c $C/decode.hip -o $D/decode_tt.o
 OBJS=$(ls $C/*.o | grep -v "/decode.o")

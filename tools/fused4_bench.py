@@ -20,9 +20,8 @@ for (name, H, Cin, Cout, pool) in [("conv_2", 208, 32, 64, 1), ("conv_3", 104, 6
     x = torch.randn((B, H, H, Cin), dtype=torch.float32, device=ctx.device)
     w = (rs.randn(3, 3, Cin, Cout) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
     b = rs.randn(Cout).astype(np.float32)
-    for mode, w4s in (("0", "0"), ("2", "0"), ("2", "2")):     # unfused / wino4_fused (conv_2: its F(2x2) kernel) / wino4s_fused
+    for mode in ("0", "2"):     # unfused (conv_2: direct form) / wino4s_fused
         os.environ["DT_WINO_FUSED4"] = mode
-        os.environ["DT_W4S"] = w4s
         for _ in range(2):
             ctx.conv2d(x, w, b, leaky_slope=0.1, pool=pool)
         ctx.profile_reset(); ctx.profile_enable(True)
@@ -33,7 +32,7 @@ for (name, H, Cin, Cout, pool) in [("conv_2", 208, 32, 64, 1), ("conv_3", 104, 6
         ms = sum(p["ms"] for p in parts.values()) / 3
         fl = (parts["conv_fused"]["flops"] + parts["conv_igemm"]["flops"]) / 3
         direct = 2.0 * B * H * H * 9 * Cin * Cout
-        print("%-7s fused4=%s w4s=%s  %7.3f ms  executed %6.1f TFLOP/s  direct-form %6.1f TFLOP/s  (%s)" % (
-            name, mode, w4s, ms, fl / ms / 1e9, direct / ms / 1e9,
+        print("%-7s fused4=%s  %7.3f ms  executed %6.1f TFLOP/s  direct-form %6.1f TFLOP/s  (%s)" % (
+            name, mode, ms, fl / ms / 1e9, direct / ms / 1e9,
             ", ".join("%s %.2f" % (n, p["ms"] / 3) for n, p in parts.items() if p["ms"] > 0)), flush=True)
     del x

@@ -2,7 +2,7 @@
 # FETCH_SIZE + time for alternative library builds (MI355_DT_LIB)
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/ab; mkdir -p $O
 for n in "$@"; do
-  L=$R/object_tracking_amd/ablate/libmi355_dt_$n.so
+  L=$R/tools/_probe_builds/libmi355_dt_$n.so
   cd $R
   MI355_DT_LIB=$L python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$n', 'fps', round(d['value'],1), 'TF', round(d['roofline']['achieved'],2))"
   cd /tmp && export TMPDIR=/tmp

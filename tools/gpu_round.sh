@@ -26,6 +26,11 @@ if [ "${SKIP_PMC:-0}" != "1" ]; then
     python $R/tools/rocprof_summary.py pmc $O/pmc_$C $C > $O/rocprof_pmc_$C.txt 2>&1
     head -8 $O/rocprof_pmc_$C.txt
   done
+  # MFMA-busy share and effective shader clock of every kernel INSIDE the step (one pass, both counters)
+  timeout 900 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_MFMA -o pmc -- python $R/tools/pmc_probe.py 48 > $O/pmc_MFMA.log 2>&1
+  tail -1 $O/pmc_MFMA.log
+  python $R/tools/rocprof_summary.py mfma $O/pmc_MFMA > $O/rocprof_pmc_MFMA.txt 2>&1
+  head -14 $O/rocprof_pmc_MFMA.txt
 fi
 # the split-bf16 GEMM on its own: rate, error against float64, effective clock with / without the LDS fragment reads and the DMA
 if [ -x $R/tools/micro/gemm_s3_bench ]; then

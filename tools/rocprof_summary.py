@@ -4,6 +4,9 @@ small text tables committed under profiles/.
 
   rocprof_summary.py stats  <dir>          # per-kernel calls / total / avg from *_kernel_trace.csv
   rocprof_summary.py pmc    <dir> COUNTER  # per-kernel sum and per-launch mean of COUNTER
+  rocprof_summary.py mfma   <dir>          # per kernel: effective shader clock (GRBM_GUI_ACTIVE / 8 XCDs / duration) and the
+                                           # MFMA-busy share of its cycles (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / cycles), from ONE
+                                           # pass `--kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES`
 """
 import csv
 import glob
@@ -51,8 +54,35 @@ def pmc(d, counter):
         print("%-92s %7d %18.1f %18.1f" % (short(k), a[0], a[1], a[1] / a[0]))
 
 
+def mfma(d):
+    dur, name = {}, {}
+    for f in find(d, "*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3     # us
+            name[r["Dispatch_Id"]] = r["Kernel_Name"]
+    gui, busy = {}, {}
+    for f in find(d, "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                gui[r["Dispatch_Id"]] = gui.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+            if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                busy[r["Dispatch_Id"]] = busy.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    agg = OrderedDict()
+    for k in dur:
+        if k in gui:
+            a = agg.setdefault(name[k], [0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += dur[k]; a[2] += gui[k] / 8.0; a[3] += busy.get(k, 0.0) / 1024.0
+    print("# GRBM_GUI_ACTIVE is summed over the 8 XCDs (/8 = cycles); SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs (/1024 = busy cycles per SIMD)")
+    print("%-92s %7s %12s %10s %12s" % ("kernel", "calls", "total_us", "clock_GHz", "mfma_busy_%"))
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        if a[1] > 0 and a[2] > 0:
+            print("%-92s %7d %12.1f %10.3f %12.1f" % (short(k), a[0], a[1], a[2] / a[1] / 1e3, 100.0 * a[3] / a[2]))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "mfma":
+        mfma(sys.argv[2])
     else:
         pmc(sys.argv[2], sys.argv[3])

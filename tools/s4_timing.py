@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Cycle stamps inside the LDS-staged fused F(4x4) kernel (debug build -DDT_S4_TIMING, tools/s4_timing.sh): workgroups 0..63,
 all 8 waves, the first 8 items of each.
-   MI355_DT_LIB=object_tracking_amd/ablate/libmi355_dt_s4tt.so python tools/s4_timing.py conv_3 1440"""
+   MI355_DT_LIB=tools/_probe_builds/libmi355_dt_s4tt.so python tools/s4_timing.py conv_3 1440"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,7 +15,6 @@ SHAPES = {"conv_2": (208, 32, 64, 1), "conv_3": (104, 64, 128, 0), "conv_5": (10
 name = sys.argv[1]; B = int(sys.argv[2])
 H, Cin, Cout, pool = SHAPES[name]
 os.environ["DT_WINO_FUSED4"] = "2"
-os.environ["DT_W4S"] = "2"
 ctx = mi355_dt.Context()
 lib = ctx.lib
 rs = np.random.RandomState(0)
