@@ -190,7 +190,9 @@ void wino_pack_weights(int ts, const float *hwio, int cin_src, int cout_src, con
 // ---------------------------------------------------------------------------
 int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, int H, int W,
                         const float *w_packed /*[27][32]*/, const float *bias /*[32]*/,
-                        const float *lut /*[256] or null*/, float slope, float *out /*[B,H/2,W/2,32]*/);
+                        const float *lut /*[256] or null*/, float slope, float *out /*[B,H/2,W/2,32]*/,
+                        const unsigned *lut3 = nullptr /*[256][2]*/, const unsigned *w3 = nullptr /*[2][3][64][4]: both set -> conv1_s3_kernel*/);
+void conv1_split_tables(const float *w /*[27][32]*/, unsigned *lut3 /*[512]*/, unsigned *w3 /*[1536]*/);
 
 int launch_decode(hipStream_t st, const float *netout, long long frame_stride, int batch, int GH, int GW, int NB,
                   int NC, float obj_thr, float nms_thr, const float *anchors_dev, int cap, float *boxes,
@@ -279,6 +281,7 @@ struct Policy {
     int wino_cfg = -1, wino_gn = -1;   // DT_WINO_CFG / DT_WINO_GN (A/B runs)
     int ksplit = 0;          // DT_KSPLIT
     int conv_cfg = -1;       // DT_CONV_CFG
+    int s3_conv1 = 1;        // DT_S3_CONV1: conv_1 on the bf16 pipe with split operands (conv1_s3_kernel); 0 = conv1_mfma_kernel (fp32 MFMA)
     int s3 = 1;              // DT_S3: the F(6x6) layers' batched GEMMs on the bf16 matrix pipe with 3-term split operands (wino_gemm_s3.hip):
                              //        0 never (fp32 MFMA) / 1 where it wins (K >= s3_mink, GEMM rows >= s3_minrows) / 2 wherever the shape allows
     int s3_mink = 256, s3_minrows = 2048;   // DT_S3_MINK / DT_S3_MINROWS
@@ -312,6 +315,7 @@ struct dt_ctx {
     unsigned short *s3_ones = nullptr;   // device, [3][256][16]: split terms of the A rows (1, 0, .., 0) that carry a 1x1 layer's bias through wino_gemm_s3.hip
     std::map<const void *, unsigned short *> wino_s3;   // F(6x6) Winograd weights (device pointer) -> their split-bf16 form (wino_gemm_s3.hip), when built
     float *conv1_w = nullptr, *conv1_b = nullptr, *lut255 = nullptr;
+    unsigned *conv1_lut3 = nullptr, *conv1_w3 = nullptr;   // device: split-bf16 tables of conv1_s3_kernel (conv1.hip:conv1_split_tables)
     std::vector<float> conv1_hwio32, conv1_scale, conv1_shift;   // host copy of conv_1 as a Cin = 32 layer (dt_detector_extract)
     // tracker head
     bool trk_loaded = false;

@@ -219,6 +219,8 @@ extern "C" void dt_destroy(dt_ctx *ctx)
     s3_drop(ctx, ctx->trk_wx_wino);
     s3_drop(ctx, ctx->trk_wh_wino);
     if (ctx->s3_ones) (void)hipFree(ctx->s3_ones);
+    if (ctx->conv1_lut3) (void)hipFree(ctx->conv1_lut3);
+    if (ctx->conv1_w3) (void)hipFree(ctx->conv1_w3);
     for (float *p : singles)
         if (p) (void)hipFree(p);
     for (auto &e : ctx->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -378,6 +380,15 @@ extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t 
             if (rc) return rc;
             rc = upload(ctx, &ctx->conv1_b, shift);
             if (rc) return rc;
+            {   // the same weights and the x/255 table as three bf16 terms (conv1_s3_kernel)
+                std::vector<unsigned> lut3(512), w3(1536);
+                conv1_split_tables(w.data(), lut3.data(), w3.data());
+                for (auto pr : {std::make_pair(&ctx->conv1_lut3, &lut3), std::make_pair(&ctx->conv1_w3, &w3)}) {
+                    if (*pr.first) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(*pr.first); *pr.first = nullptr; }
+                    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(pr.first), pr.second->size() * sizeof(unsigned)));
+                    HIP_TRY(ctx, hipMemcpy(*pr.first, pr.second->data(), pr.second->size() * sizeof(unsigned), hipMemcpyHostToDevice));
+                }
+            }
             ctx->conv1_hwio32.assign((size_t)9 * 32 * 32, 0.0f);   // [3][3][32 (3 used)][32]
             for (int t = 0; t < 9; ++t)
                 for (int ci = 0; ci < 3; ++ci)
@@ -443,6 +454,7 @@ void policy_from_env(Policy &p)
     p.conv_cfg = geti("DT_CONV_CFG", d.conv_cfg);
     p.wino_coop = geti("DT_WINO_COOP", d.wino_coop);
     p.s3 = geti("DT_S3", d.s3);
+    p.s3_conv1 = geti("DT_S3_CONV1", d.s3_conv1);
     p.s3_mink = geti("DT_S3_MINK", d.s3_mink);
     p.s3_minrows = geti("DT_S3_MINROWS", d.s3_minrows);
     p.s3_1x1 = geti("DT_S3_1X1", d.s3_1x1);
@@ -963,8 +975,9 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
     {   // conv_1 + norm_1 + leaky + pool, with x/255 fused
         ProfScope ps(ctx, "conv1_direct", 2.0 * B * H * W * 27.0 * 32.0,
                      (double)B * H * W * 3.0 * (dtype == DT_FRAMES_U8 ? 1 : 4) + 4.0 * B * (H / 2) * (W / 2) * 32.0);
+        const bool c1s3 = ctx->pol.s3 != 0 && ctx->pol.s3_conv1 != 0;
         if (launch_conv1_direct(ctx->stream, frames, dtype, B, H, W, ctx->conv1_w, ctx->conv1_b, ctx->lut255, LEAKY,
-                                bufA))
+                                bufA, c1s3 ? ctx->conv1_lut3 : nullptr, c1s3 ? ctx->conv1_w3 : nullptr))
             return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");
     }
     const int h = H / 32, w = W / 32;
@@ -1087,7 +1100,9 @@ extern "C" int dt_detector_extract(dt_ctx *ctx, const void *d_frames, int frames
         if (!bufA || !bufB || !skip || !cat) return DT_ERR_DEVICE;
         ctx->last_batch = 0;            // the tap workspaces no longer hold a complete forward
         ctx->tap_feat = ctx->tap_netout = false;
-        if (launch_conv1_direct(ctx->stream, d_frames, frames_dtype, B, H, W, ctx->conv1_w, ctx->conv1_b, ctx->lut255, LEAKY, bufA))
+        const bool c1s3 = ctx->pol.s3 != 0 && ctx->pol.s3_conv1 != 0;
+        if (launch_conv1_direct(ctx->stream, d_frames, frames_dtype, B, H, W, ctx->conv1_w, ctx->conv1_b, ctx->lut255, LEAKY, bufA,
+                                c1s3 ? ctx->conv1_lut3 : nullptr, c1s3 ? ctx->conv1_w3 : nullptr))
             return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");
         if (idx == 1) {   // max_pooling2d_1
             HIP_TRY(ctx, hipMemcpyAsync(d_out, bufA, need * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));

@@ -38,6 +38,9 @@ typedef const __attribute__((address_space(1))) void s3_gptr_t;
 #ifndef S3_DEFAULT_WAVES
 #define S3_DEFAULT_WAVES 8
 #endif
+#ifndef S3_EPI_ROWS
+#define S3_EPI_ROWS 0    // A/B: 1 = V is the MFMA's A operand: a lane then holds ONE column n and 16 rows of a block, and a store instruction
+#endif                   //      writes 4 bytes per lane = two whole 128-byte lines (32 consecutive n of rows m, m + 4) instead of 64 16-byte pieces
 #ifndef S3_ABLATE
 #define S3_ABLATE 0      // probes (tools/micro/gemm_s3_bench.hip): 1 no DMA, 2 no operand reads, 4 no barrier, 8 DMA from one tile's panels only
 #endif
@@ -46,9 +49,13 @@ typedef const __attribute__((address_space(1))) void s3_gptr_t;
 template <int N>
 __device__ __forceinline__ void s3_wait_vm() { __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14)); }
 
-__device__ __forceinline__ void s3_mfma(s3_f16 &c, const s3_bf8 &a, const s3_bf8 &b)
+__device__ __forceinline__ void s3_mfma(s3_f16 &c, const s3_bf8 &a, const s3_bf8 &b)      // a: U fragment (rows n), b: V fragment (rows m)
 {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#if S3_EPI_ROWS
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0);      // D[i = m][j = n]
+#else
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);      // D[i = n][j = m]
+#endif
 }
 
 // NW waves per workgroup: 8 = 4 (m) x 2 (n) waves of 64 x BN/2 at two waves per SIMD (<= 256 registers each);
@@ -331,6 +338,23 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                     for (int e = 0; e < 16; ++e) acc[j][i][e] = acc[j][i][e] > 0.0f ? acc[j][i][e] : acc[j][i][e] * p.slope;
             __builtin_amdgcn_sched_barrier(0);
         }
+#if S3_EPI_ROWS
+        // ---- epilogue: lane holds, per block, column n = n0 + (lane & 31) of rows m = m0 + 8 (r / 4) + 4 (lane >> 5) + r % 4 ----
+        float *cz = p.c + (long long)cur.pz * p.c_ps + cur.n0 + wn * (BN / 2) + rl;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int mb = cur.m0 + wm * (MB * 32) + 32 * i + 4 * gl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + 8 * (r >> 2) + (r & 3);
+                if (m < p.Mt) {
+                    float *row = cz + (long long)m * p.ldc;
+#pragma unroll
+                    for (int j = 0; j < NBW; ++j) __builtin_nontemporal_store(acc[j][i][r], row + 32 * j);
+                }
+            }
+        }
+#else
         // ---- epilogue: lane holds, per block, n = n0 + 8q + 4*(lane>>5) + (0..3) of row m = m0 + (lane & 31) ----
         float *cz = p.c + (long long)cur.pz * p.c_ps;
 #pragma unroll
@@ -352,6 +376,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                     }
             }
         }
+#endif
         Lcur += G;
 #ifdef S3_TIMING
         if (Lcur >= ntiles && lane == 0 && p.dbg) {

@@ -152,7 +152,7 @@ def _setup_config(size, n_clips, T, target_boxes):
 
 
 def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_policy, min_boxes_per_frame, policy_env=None,
-                            forbid_policy=()):
+                            forbid_policy=(), max_order_flips=1):
     C = 12
     frames, trk, ref_trk = _setup_config(size, n_clips, T, target_boxes)
     ctx = trk.model.ctx
@@ -212,34 +212,56 @@ def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_pol
     score_err = float(np.abs(gsc - scores)[near].max()) if near.any() else 0.0
     assert m_obj > 2.0 * score_err, "objectness margin %g vs observed score error %g" % (m_obj, score_err)
 
-    # ---- boxes: set, order, labels exact; coordinates; IoU per matched box
+    # ---- boxes: set, order, labels exact; coordinates; IoU per matched box.  The gap thresholds take every score-vs-threshold
+    # and IoU-vs-threshold decision out of rounding's reach, but not the ORDER in which NMS visits two overlapping boxes of one
+    # class whose scores nearly tie (utils.py:240: the higher score suppresses the other): a frame may differ from the oracle's
+    # only if the oracle has such a near-tie (|s_a - s_b| within twice the MEASURED score error, IoU at the NMS threshold or
+    # above) and every differing box traces to it (tests/flip_accounting.py); at most `max_order_flips` frames may.
+    import flip_accounting as fa
     counts = res["counts"].cpu().numpy()
-    assert np.array_equal(counts, rc), "box counts differ in %d of %d frames" % (int((counts != rc).sum()), rc.size)
     gb = res["boxes"].cpu().numpy()
     worst_coord, worst_iou, nbox = 0.0, 1.0, 0
+    order_flips = []
+    first_flip_t = {}
     for i in range(n_clips):
         for t in range(T):
             n = rc[i, t]
-            g, r = gb[i, t, :n], rb[i, t, :n]
-            assert np.array_equal(g[:, 7], r[:, 7]), "cell order differs (clip %d t %d)" % (i, t)
-            assert np.array_equal(g[:, 5], r[:, 5]), "labels differ (clip %d t %d)" % (i, t)
+            g, r = gb[i, t, :counts[i, t]], rb[i, t, :n]
+            if not (counts[i, t] == n and np.array_equal(g[:, 7], r[:, 7]) and np.array_equal(g[:, 5], r[:, 5])):
+                sc_r = fa.oracle_scores(ref_trk[i, t], ANCHORS, C)
+                bx_r, bx_g = fa.boxes_of_grid(ref_trk[i, t], ANCHORS), fa.boxes_of_grid(got[i, t], ANCHORS)
+                _, e_iou, _, _ = fa.measure_eps(sc_r, fa.oracle_scores(got[i, t], ANCHORS, C), bx_r, bx_g, float(obj_thr[i, t]), (nms_thr,))
+                dec, band_cells = fa.decode_decisions(sc_r, bx_r, score_err + 1e-7, e_iou + 1e-6, float(obj_thr[i, t]), nms_thr)
+                key = lambda rr: set((int(c), int(l)) for c, l in zip(rr[:, 7], rr[:, 5]))
+                diff = key(g) ^ key(r)
+                unexplained = fa.explain_diff(set(c for c, _ in diff), band_cells, sc_r, bx_r, score_err + 1e-7, e_iou + 1e-6,
+                                              float(obj_thr[i, t]), nms_thr)
+                assert dec and all(d["kind"] == "nms_order" for d in dec) and not unexplained, \
+                    "clip %d t %d: boxes differ (%d vs %d) without a near-tie in NMS order behind it: in band %s, unexplained cells %s" % (
+                        i, t, len(g), n, dec, sorted(unexplained))
+                order_flips.append(dict(clip=i, t=t, differing=sorted([int(c), int(l)] for c, l in diff), near_ties=dec))
+                first_flip_t.setdefault(i, t)
+                continue
             if n:
                 exy = np.abs(g[:, :2] - r[:, :2]).max()
                 ewh = (np.abs(g[:, 2:4] - r[:, 2:4]) / np.maximum(1.0, np.abs(r[:, 2:4]))).max()
                 worst_coord = max(worst_coord, float(exy), float(ewh))
                 worst_iou = min(worst_iou, float(iou_rows(g[:, :4], r[:, :4]).min()))
                 nbox += n
+    assert len(order_flips) <= max_order_flips, "%d frames differ through NMS-order near-ties: %s" % (len(order_flips), order_flips)
     assert worst_coord < 1e-3, "box coordinates differ by %g" % worst_coord
     assert worst_iou >= 0.999, "IoU vs oracle box %g" % worst_iou
-    assert nbox >= min_boxes_per_frame * n_clips * T, "only %.1f boxes per frame survive NMS" % (nbox / float(n_clips * T))
+    assert nbox >= min_boxes_per_frame * (n_clips * T - len(order_flips)), "only %.1f boxes per frame survive NMS" % (nbox / float(n_clips * T))
 
-    # ---- track ids: bit-exact
+    # ---- track ids: bit-exact (in a clip with an NMS-order flip: up to that frame -- one other box renumbers what follows)
     ids = res["ids"].cpu().numpy()
     nids = res["nids"].cpu().numpy()
     for i in range(n_clips):
         rid, rn = orc.associate_clip(rb[i], rc[i], assoc_thr)
-        assert np.array_equal(ids[i], rid), "track ids differ in clip %d" % i
-        assert int(nids[i]) == rn
+        tb = first_flip_t.get(i, T)
+        assert np.array_equal(ids[i, :tb], rid[:tb]), "track ids differ in clip %d" % i
+        if tb == T:
+            assert int(nids[i]) == rn
     _report("parity_%s.json" % tag, dict(
         config="%d clips x T=%d x %dx%d, C=12, %s" % (n_clips, T, size, size, "default policy" if not policy_env else
                                                       "the 48-clip bench step's kernel selection (%s)" % " ".join("%s=%s" % kv for kv in sorted(policy_env.items()))),
@@ -249,7 +271,8 @@ def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_pol
         grid_chan_err_max=max(err_t), score_err_near_threshold=score_err, box_coord_err=worst_coord,
         box_iou_min=worst_iou, obj_threshold_min=float(obj_thr.min()), obj_threshold_max=float(obj_thr.max()),
         obj_margin=m_obj, nms_threshold=nms_thr, nms_margin=m_nms,
-        assoc_threshold=assoc_thr, assoc_margin=m_assoc, ids_bit_exact=True, kernels=sorted(n for n in names if ":" in n)))
+        assoc_threshold=assoc_thr, assoc_margin=m_assoc, ids_bit_exact=not order_flips,
+        frames_differing_through_nms_order_near_ties=order_flips, kernels=sorted(n for n in names if ":" in n)))
 
 
 def _track_config_at_reference_defaults(size, n_clips, T, target_boxes, cap, tag, max_flip_frames, policy_env=None, expect_policy=(),

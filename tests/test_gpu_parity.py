@@ -346,6 +346,34 @@ def _detector(ctx_unused, H, W, C, seed=1234):
     return det, layers, blob
 
 
+@pytest.mark.parametrize("H,W,B", [(64, 96, 3), (416, 416, 2), (32, 32, 1)])
+def test_conv1_split_bf16_vs_oracle_and_fp32_mfma(ctx, monkeypatch, H, W, B):
+    """conv_1 + x/255 + BN + LeakyReLU + 2x2 max (KerasYOLO.py:278-282) as conv1_s3_kernel (bf16 MFMA on 3-term split
+    operands, the x/255 table holding the three terms per byte value; default) against the oracle, against the fp32 MFMA
+    kernel (DT_S3_CONV1=0), and uint8 frames against the same frames handed over as float32 x/255 (bit-equal: the in-kernel
+    split of a float32 frame makes the table's three roundings)."""
+    det, layers, _ = _detector(ctx, H, W, 12)
+    c = det.model.ctx
+    frames = np.random.RandomState(H + W).randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
+    frames[0, :2, :5] = 255; frames[0, -1, -3:] = 0                # extremes of the table on the image border
+    x = orc.normalize_u8(frames)
+    L = layers[1]
+    want = orc.maxpool2(orc.bn_leaky(orc.conv2d(x, L["kernel"]), L["gamma"], L["beta"], L["mean"], L["var"]))
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DT_S3_CONV1", mode)
+        c.reload_policy()
+        got[mode] = c.detector_extract(dev(frames, c), "max_pooling2d_1").cpu().numpy()
+        got[mode + "f"] = c.detector_extract(dev(x, c), "max_pooling2d_1").cpu().numpy()
+    monkeypatch.delenv("DT_S3_CONV1")
+    c.reload_policy()
+    assert np.array_equal(got["1"], got["1f"]) and np.array_equal(got["0"], got["0f"])
+    for k in ("1", "0"):
+        assert got[k].shape == (B, H // 2, W // 2, 32)
+        assert chan_err(got[k], want) < 5e-6, (k, chan_err(got[k], want))
+    assert chan_err(got["1"], got["0"]) < 2e-6
+
+
 @pytest.mark.parametrize("H,W,C,B", [(64, 64, 12, 3), (96, 64, 80, 2)])
 def test_detector_forward_vs_oracle_small(ctx, H, W, C, B):
     det, layers, _ = _detector(ctx, H, W, C)
@@ -1339,9 +1367,10 @@ def test_split_bf16_gemm_error_against_float64(ctx, monkeypatch):
 def test_split_bf16_gemm_benched_shapes_against_float64(ctx, P, Mt, K, N, half, what):
     """wino_gemm_s3.hip AT THE SHAPES THE BENCH STEP LAUNCHES (48 clips x 30 frames x 416x416), through the production
     pack kernel and launcher (dt_gemm_split_bf16), against float64 products of the same fp32 operands.  Operands spread
-    over 13 binades.  Error relative to sum_k |v||u| (the scale fp32 rounding is relative to): the split form must stay at
-    the level of an fp32 accumulation -- rms below 2^-24 x 0.75 (measured 3.7e-8; an fp32 fmaf chain on such data: 4.4e-8)
-    and not above 1.25 x the error of the fp32 library GEMM (torch.bmm, fp32 MFMA) on the same data; max below 3e-7."""
+    over 13 binades (heavy-tailed sums: a few terms dominate, so the accumulator rounds at the sum's own scale).  Error relative
+    to sum_k |v||u| (the scale fp32 rounding is relative to): the split form must not be above the error of the fp32 library
+    GEMM (torch.bmm: fp32 MFMA) on the same data -- rms and max -- and stay at the level of fp32 rounding in absolute terms
+    (rms < 1.5 x 2^-24).  (On Gaussian data tools/micro/gemm_s3_bench.hip measures 3.7e-8 rms against 4.4e-8 for an fp32 fmaf chain.)"""
     t = torch
     g = t.Generator(device=ctx.device)
     g.manual_seed(1000 + K + N)
@@ -1371,8 +1400,9 @@ def test_split_bf16_gemm_benched_shapes_against_float64(ctx, P, Mt, K, N, half, 
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, "parity_r04_gemm_s3_f64.txt"), "a") as fh:
         fh.write("P=%d Mt=%d K=%d N=%d half=%d  split-bf16: rms %.4g max %.4g   fp32 library GEMM: rms %.4g max %.4g   # %s\n" % (P, Mt, K, N, half, rms_e, me, rms_f, mf, what))
-    assert rms_e < 4.5e-8 and me < 3e-7, (rms_e, me)
-    assert rms_e < 1.25 * rms_f + 2e-9, (rms_e, rms_f)
+    # measured (profiles/parity_r04_gemm_s3_f64.txt): split 6.5-6.8e-8 rms / 0.94-1.1e-6 max, fp32 library GEMM 8.2-8.8e-8 / 1.3-1.7e-6
+    assert rms_e <= 1.02 * rms_f and me <= 1.05 * mf, (rms_e, rms_f, me, mf)      # not above an fp32 GEMM's error on the same data
+    assert rms_e < 1.5 * 2.0 ** -24 and me < 32 * 2.0 ** -24, (rms_e, me)        # and at the level of fp32 rounding in absolute terms
 
 
 def test_split_bf16_gemm_one_hot_taps(ctx, monkeypatch):
