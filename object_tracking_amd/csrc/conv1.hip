@@ -155,6 +155,9 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(Conv1Args p)
 //     16-bit reads per term at per-lane offsets (k -> (ky, kx, ci) is the weight file's order, k = 9 ky + 3 kx + ci);
 //     k = 27..31 re-read k = 0 (finite) against zero weights;
 //   * the weights' three terms are packed on the host in the B operand's lane order and live in 24 registers.
+#ifndef C1_PF2
+#define C1_PF2 0          // 1: input bytes fetched TWO tiles ahead (6 more registers: 3 instead of 4 waves per SIMD) -- A/B
+#endif
 typedef __bf16 c1_bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned short c1_us8 __attribute__((ext_vector_type(8)));
 typedef unsigned int c1_u4 __attribute__((ext_vector_type(4)));
@@ -189,7 +192,10 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
     const bool yok0 = y0 >= 0 && y0 < p.H, yok1 = has1 && y1 >= 0 && y1 < p.H;
     const long long row0 = ((long long)b * p.H + y0) * p.W, row1 = ((long long)b * p.H + y1) * p.W;
     float raw[2][3];      // u8 frames: the bytes as floats' bit patterns (table index); f32 frames: the values
-    auto fetch = [&](int bx) {
+#if C1_PF2
+    float rawn[2][3];     // the tile after the one in `raw`: loads stay in flight for a whole tile (HBM latency ~ one tile's compute)
+#endif
+    auto fetch = [&](int bx, float (&raw)[2][3]) {
         const int x0 = bx * 16 - 1 + c0, x1 = bx * 16 - 1 + c1;
         const bool ok0 = yok0 && x0 >= 0 && x0 < p.W, ok1 = yok1 && x1 >= 0 && x1 < p.W;
         if (p.dtype == DT_FRAMES_U8) {
@@ -257,17 +263,30 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
             bw[kb][t] = __builtin_bit_cast(c1_bf8, reinterpret_cast<const c1_u4 *>(p.w3)[(kb * 3 + t) * 64 + lane]);
     const float bias = p.bias[n];
 
-    fetch(bx_first);
+    fetch(bx_first, raw);
+#if C1_PF2
+    if (bx_first + 1 < bx_last) fetch(bx_first + 1, rawn);
+#endif
     __syncthreads();                                            // the term table is in LDS
     for (int bx = bx_first; bx < bx_last; ++bx) {
         stage();
         __syncthreads();
-        if (bx + 1 < bx_last) fetch(bx + 1);                    // in flight under the MFMAs below
-        {
-            // pooled rows g = 2 wave, 2 wave + 1 of the tile: two independent MFMA chains (gi = 0, 1: +36 elements)
-            c1_bf8 a[2][2][3];
+#if C1_PF2
 #pragma unroll
-            for (int gi = 0; gi < 2; ++gi)
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) raw[i][c] = rawn[i][c];  // (issued a tile ago)
+        if (bx + 2 < bx_last) fetch(bx + 2, rawn);              // in flight under this tile's MFMAs and the next one's
+#else
+        if (bx + 1 < bx_last) fetch(bx + 1, raw);               // in flight under the MFMAs below
+#endif
+        {
+            // pooled rows g = 2 wave, 2 wave + 1 of the tile (gi = 0, 1: +36 elements), one after the other: the second group's
+            // fragment reads are in flight under the first group's MFMAs, and only one group's fragments are live
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                c1_bf8 a[2][3];
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -275,22 +294,19 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
                         c1_us8 v;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = s_pl[3 * t * C1_PL + aoff[kb][e] + 36 * gi];
-                        a[gi][kb][t] = __builtin_bit_cast(c1_bf8, v);
+                        a[kb][t] = __builtin_bit_cast(c1_bf8, v);
                     }
-            f32x16 acc0, acc1;
+                f32x16 acc;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
-            // six partial products per k-block, smallest first: (x3 w1, x2 w2, x1 w3), (x2 w1, x1 w2), x1 w1
-#define C1_MM(ta, tb)                                                                                     \
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][kb][ta], bw[kb][tb], acc0, 0, 0, 0);       \
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][kb][ta], bw[kb][tb], acc1, 0, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) { C1_MM(2, 0) C1_MM(1, 1) C1_MM(0, 2) }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) { C1_MM(1, 0) C1_MM(0, 1) }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) { C1_MM(0, 0) }
+                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+                // six partial products per k-block, smallest first: (x3 w1, x2 w2, x1 w3), (x2 w1, x1 w2), x1 w1; the two k-blocks alternate
+#define C1_MM(ta, tb)                                                                                  \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][ta], bw[0][tb], acc, 0, 0, 0);       \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][ta], bw[1][tb], acc, 0, 0, 0);
+                C1_MM(2, 0) C1_MM(1, 1) C1_MM(0, 2) C1_MM(1, 0) C1_MM(0, 1) C1_MM(0, 0)
 #undef C1_MM
+                if (gi == 0) acc0 = acc; else acc1 = acc;
+            }
 #pragma unroll
             for (int gi = 0; gi < 2; ++gi) {
                 const int oy = by * 8 + wave * 2 + gi;

@@ -133,6 +133,9 @@ __device__ __forceinline__ void s4_transform_half(const float *pl, float *o)
 #ifndef S4_PRIO
 #define S4_PRIO 1           // raise the wave's issue priority while it does side work (DMA issue, input transform) beside its
 #endif                      // partner's MFMA block
+#ifndef S4_USPLIT
+#define S4_USPLIT 0         // of a wave's 9 U pieces per stage, this many are issued by the OTHER set (the one that runs the input transform) at
+#endif                      // the start of its stage: balances the two roles (data movement 2084 + 1455 vs transform 1678 + 1455 cycles per stage)
 #ifndef S4_PF
 #define S4_PF 2             // MFMA operand prefetch distance in quads (1 or 2)
 #endif
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
                 // stage: odd s -> block image 0 of patch stage (s+3)/2, even s -> block image 1 of patch stage (s+2)/2 (the
                 // stage whose first half went out one stage earlier).  Past this item's patches the numbering continues
                 // into the next item's (npatch is even, so the buffers line up). ----
-                if ((!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9);
+                if ((!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9 - S4_USPLIT);
                 const int pc_all = (s + 2 + (s & 1)) >> 1;
                 const bool pnx = pc_all >= npatch;
                 if (!(S4_ABLATE & 2)) {
@@ -351,6 +354,9 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
                     patch_half(B, (s & 1) ^ 1, pnx ? pc_all - npatch : pc_all, pc_all & 1, !pnx || has_next);
                 }
                 if (S4_PRIO) __builtin_amdgcn_s_setprio(0);
+            } else if (S4_USPLIT > 0) {
+                // the transform set takes the last S4_USPLIT U pieces of each wave slot, ahead of its MFMAs (they land under them)
+                if ((!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 9 - S4_USPLIT, 9);
             }
             [[maybe_unused]] const unsigned long long c1 = S4_NOW();
             mfma_block(s & 1);

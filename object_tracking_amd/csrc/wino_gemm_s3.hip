@@ -39,8 +39,12 @@ typedef const __attribute__((address_space(1))) void s3_gptr_t;
 #define S3_DEFAULT_WAVES 8
 #endif
 #ifndef S3_EPI_ROWS
-#define S3_EPI_ROWS 0    // A/B: 1 = V is the MFMA's A operand: a lane then holds ONE column n and 16 rows of a block, and a store instruction
-#endif                   //      writes 4 bytes per lane = two whole 128-byte lines (32 consecutive n of rows m, m + 4) instead of 64 16-byte pieces
+#define S3_EPI_ROWS 1    // 1 (default since round 4) = V is the MFMA's A operand: a lane holds ONE column n and 16 rows of a block, and a store
+#endif                   //   instruction writes 4 bytes per lane = two whole 128-byte lines (32 consecutive n of rows m, m + 4).  0 = U is the A
+                         //   operand: 16-byte stores, but each instruction touches 32 lines with 32 bytes -- the address path of 64 scattered pieces
+                         //   held the accumulators (a register an in-flight store reads cannot be reset) longer than four times as many
+                         //   line-sized stores do.  Measured (tools/micro/gemm_s3_bench, profiles/r04_gemm_s3_epilogue.txt): K = 1024 5.06 -> 5.00 ms,
+                         //   K = 512 2.89 -> 2.78, K = 256 3.19 -> 2.96, K = 128 3.93 -> 3.43, the recurrent step 0.315 -> 0.295
 #ifndef S3_ABLATE
 #define S3_ABLATE 0      // probes (tools/micro/gemm_s3_bench.hip): 1 no DMA, 2 no operand reads, 4 no barrier, 8 DMA from one tile's panels only
 #endif

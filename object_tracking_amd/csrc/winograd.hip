@@ -415,6 +415,24 @@ static unsigned wino_blocks(long long items)
 // LDS image per item: [8][9] float4 (row stride 9: the column-major writes and the row-major reads are conflict-free;
 // 288 floats per item = 32 banks past a multiple of 64, so the two items of a 16-lane access group do not collide either).
 #define WINO_COOP_ITEM 288
+// The 8x8 transpose of an item happens among EIGHT LANES OF ONE WAVEFRONT: LDS operations of a wavefront execute in issue order,
+// so all that is needed between its writes and its reads is that the compiler keeps that order (wavefront-scope fence) -- no
+// s_barrier, the wavefronts of a workgroup never wait for each other.  (Round 3 used __syncthreads() here and two LDS images per
+// item in the 8-channel kernels: 36.8 KB per 128-thread workgroup = 8 wavefronts per CU; with one image reused for both channel
+// halves and no barrier: 16 wavefronts per CU.)  WINO_WAVE_SYNC=0 restores the barriers (A/B).
+#ifndef WINO_WAVE_SYNC
+#define WINO_WAVE_SYNC 1
+#endif
+__device__ __forceinline__ void wino_item_sync()
+{
+#if WINO_WAVE_SYNC
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+    __syncthreads();
+#endif
+}
 #define WINO_COOP_MAX_ITEMS (768 * WINO_THREADS)     // (tile, channel-pair) items below which a launch takes the cooperative kernels
 // S3: V leaves as the split-bf16 operand of wino_gemm_s3.hip, [P][3][C/16][Mp][16]; the item order then puts 4 channel
 // quads x 2 tiles in a wavefront and 2 k-blocks x 2 tile pairs in a workgroup (64-byte store runs per wave-instruction,
@@ -456,7 +474,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_input_coop6_kernel(WinoArgs
         bt_1d<6>(col);                           // Bt d : down the column
 #pragma unroll
         for (int i = 0; i < 8; ++i) vstore<4>(st + (sub * 9 + i) * 4, col[i]);      // [column][xi]
-        __syncthreads();
+        wino_item_sync();
         T row[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) row[j] = vload<4>(st + (j * 9 + sub) * 4);     // row xi = sub: all eight columns
@@ -478,7 +496,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_input_coop6_kernel(WinoArgs
 #pragma unroll
             for (int j = 0; j < 8; ++j) vstore_v<4>(dst + (long long)(8 * sub + j) * plane, row[j]);
         }
-        __syncthreads();
+        wino_item_sync();
     }
 }
 
@@ -494,11 +512,12 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_input_s3_kernel(WinoAr
     constexpr int NI = TS + 2;
     typedef VecOf<4>::T T;
     constexpr int IPW = WINO_S3IN_THREADS / 8;      // items per workgroup
-    __shared__ __attribute__((aligned(16))) float s_t[2][IPW * WINO_COOP_ITEM];
+    __shared__ __attribute__((aligned(16))) float s_t[WINO_WAVE_SYNC ? 1 : 2][IPW * WINO_COOP_ITEM];
     const int mt4 = (p.Mt + 3) & ~3;
     const long long items = (long long)mt4 * (p.C / 8);
     const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;
-    float *st0 = s_t[0] + slot * WINO_COOP_ITEM, *st1 = s_t[1] + slot * WINO_COOP_ITEM;
+    float *st0 = s_t[0] + slot * WINO_COOP_ITEM;
+    [[maybe_unused]] float *st1 = s_t[WINO_WAVE_SYNC ? 0 : 1] + slot * WINO_COOP_ITEM;
     const long long term = (long long)(p.C >> 4) * p.Mp * 16;        // elements of one (plane, term)
     for (long long base = (long long)blockIdx.x * IPW; base < items; base += (long long)gridDim.x * IPW) {
         const long long it = base + slot;
@@ -522,11 +541,25 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_input_s3_kernel(WinoAr
         }
         bt_1d<TS>(ca);                           // Bt d : down the column
         bt_1d<TS>(cb);
+#if WINO_WAVE_SYNC      // one LDS image, the two channel halves one after the other
+#pragma unroll
+        for (int i = 0; i < NI; ++i) vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]);
+        wino_item_sync();
+#pragma unroll
+        for (int j = 0; j < NI; ++j) ca[j] = vload<4>(st0 + (j * 9 + sub) * 4);
+        wino_item_sync();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) vstore<4>(st0 + (sub * 9 + i) * 4, cb[i]);
+        wino_item_sync();
+#pragma unroll
+        for (int j = 0; j < NI; ++j) cb[j] = vload<4>(st0 + (j * 9 + sub) * 4);
+#else
 #pragma unroll
         for (int i = 0; i < NI; ++i) { vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]); vstore<4>(st1 + (sub * 9 + i) * 4, cb[i]); }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NI; ++j) { ca[j] = vload<4>(st0 + (j * 9 + sub) * 4); cb[j] = vload<4>(st1 + (j * 9 + sub) * 4); }
+#endif
         bt_1d<TS>(ca);                           // (Bt d) B : along the row
         bt_1d<TS>(cb);
         if (live && sub < NI) {
@@ -548,7 +581,7 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_input_s3_kernel(WinoAr
 #pragma unroll
                 for (int k = 0; k < 3; ++k) *reinterpret_cast<wino_u4 *>(dst + ((long long)(NI * sub + j) * 3 + k) * term) = o[j][k];
         }
-        __syncthreads();
+        wino_item_sync();
     }
 }
 
@@ -579,7 +612,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
         at_1d<6>(col);                           // At m : down the column -> rows 0..5   (S3OUT: m A along the row -> columns 0..5)
 #pragma unroll
         for (int i = 0; i < 6; ++i) vstore<4>(st + (sub * 9 + i) * 4, col[i]);
-        __syncthreads();
+        wino_item_sync();
         T row[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) row[j] = vzero<4>();
@@ -631,7 +664,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
                     vstore<4>(p.out2 + ((long long)(t.grp * H2 + h2) * W2 + w2) * p.out2_ld + c, mx);
             }
         }
-        __syncthreads();
+        wino_item_sync();
     }
 }
 // The split-row output for the 1x1 layer behind this one (p.out_s3), EIGHT channels per lane like wino_input_s3_kernel: along
@@ -642,12 +675,13 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_output_s3_kernel(WinoA
 {
     typedef VecOf<4>::T T;
     constexpr int IPW = WINO_S3IN_THREADS / 8;
-    __shared__ __attribute__((aligned(16))) float s_t[2][IPW * WINO_COOP_ITEM];
+    __shared__ __attribute__((aligned(16))) float s_t[WINO_WAVE_SYNC ? 1 : 2][IPW * WINO_COOP_ITEM];
     const int mt4 = (p.Mt + 3) & ~3;
     const long long items = (long long)mt4 * (p.N / 8);
     const long long plane = (long long)p.Mt * p.m_ld;
     const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;
-    float *st0 = s_t[0] + slot * WINO_COOP_ITEM, *st1 = s_t[1] + slot * WINO_COOP_ITEM;
+    float *st0 = s_t[0] + slot * WINO_COOP_ITEM;
+    [[maybe_unused]] float *st1 = s_t[WINO_WAVE_SYNC ? 0 : 1] + slot * WINO_COOP_ITEM;
     const long long term = (long long)(p.N >> 4) * p.out_mp * 16;
     for (long long base = (long long)blockIdx.x * IPW; base < items; base += (long long)gridDim.x * IPW) {
         const long long it = base + slot;
@@ -667,12 +701,28 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_output_s3_kernel(WinoA
         }
         at_1d<6>(ca);                            // m A : along the row -> columns 0..5
         at_1d<6>(cb);
+#if WINO_WAVE_SYNC      // one LDS image, the two channel halves one after the other (lanes 6, 7 read rows that were never written: unused)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]);
+        wino_item_sync();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ca[j] = vload<4>(st0 + (j * 9 + (sub < 6 ? sub : 0)) * 4);
+        wino_item_sync();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vstore<4>(st0 + (sub * 9 + i) * 4, cb[i]);
+        wino_item_sync();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cb[j] = vload<4>(st0 + (j * 9 + (sub < 6 ? sub : 0)) * 4);
+#else
 #pragma unroll
         for (int i = 0; i < 6; ++i) { vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]); vstore<4>(st1 + (sub * 9 + i) * 4, cb[i]); }
         __syncthreads();
+#endif
         if (sub < 6) {
+#if !WINO_WAVE_SYNC
 #pragma unroll
             for (int j = 0; j < 8; ++j) { ca[j] = vload<4>(st0 + (j * 9 + sub) * 4); cb[j] = vload<4>(st1 + (j * 9 + sub) * 4); }
+#endif
             at_1d<6>(ca);                        // At (m A) : down the column -> rows 0..5 of pixel column `sub`
             at_1d<6>(cb);
             const T ba = (live && p.bias) ? vload<4>(p.bias + c) : vzero<4>(), bb = (live && p.bias) ? vload<4>(p.bias + c + 4) : vzero<4>();
@@ -702,7 +752,7 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_output_s3_kernel(WinoA
                 }
             }
         }
-        __syncthreads();
+        wino_item_sync();
     }
 }
 
