@@ -18,8 +18,8 @@ struct Conv1Args {
     float slope;
     float *out;          // [B][H/2][W/2][32]
     int tpw;             // tiles a workgroup walks along x
-    const unsigned *lut3;   // [256][2]: the three bf16 terms of float32(i / 255.) as (t1 | t2 << 16, t3)   (conv1_s3_kernel)
     const unsigned *w3;     // [2 k-blocks][3 terms][64 lanes][4]: the weights as the B operand of v_mfma_f32_32x32x16_bf16, split into three bf16 terms
+    const unsigned *w3u8;   // the same for weights / 255 (uint8 frames: conv1_s3_kernel<true>)
 };
 
 // K = 27 is short, but the fp32 MFMA peak equals the packed-FMA peak and an MFMA is ONE issue slot per 64 cycles: the
@@ -144,20 +144,17 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(Conv1Args p)
 }
 
 
-// ---- the same layer on the bf16 matrix pipe at fp32 accuracy (default) ---------------------------------------------------
+// ---- the same layer on the bf16 matrix pipe at fp32 accuracy (default; Policy::s3_conv1) ----------------------------------
 // v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate and this layer spent 3.1 of its 5.0 ms per 1440 frames on the
-// matrix pipe.  Here every fp32 operand is carried as three bf16 terms (x = x1 + x2 + x3, exact to 2^-25 |x|; the arithmetic
-// of wino_gemm_s3.hip) and every product is formed from the six partial products of weight >= 2^-16, smallest first, fp32
-// accumulate: K = 27 padded to 32 = two k-blocks of 16 -> 12 MFMAs of 32 cycles per group of 32 pixels instead of 14 of 64.
-//   * x/255 needs NO arithmetic: the 256-entry table holds the three terms of float32(float64(i) / 255) per byte value
-//     (float32 frames are split with the same three roundings in the staging pass: both inputs give the same bits);
+// matrix pipe, the rest on LDS reads, staging and the epilogue's VALU -- all of them about equally (measured: halving the MFMA
+// time alone bought 6 %).  conv1_s3_kernel carries fp32 operands as bf16 terms (the arithmetic of wino_gemm_s3.hip: x = x1 + x2 +
+// x3 exact to 2^-25 |x|, products formed from the partial products of weight >= 2^-16, smallest first, fp32 accumulate), K = 27
+// padded to 32 = two k-blocks of v_mfma_f32_32x32x16_bf16:
 //   * the patch lies in LDS as bf16 planes [term][ci][18 x 18]; a lane's A fragment (8 consecutive k of its pixel) is eight
 //     16-bit reads per term at per-lane offsets (k -> (ky, kx, ci) is the weight file's order, k = 9 ky + 3 kx + ci);
 //     k = 27..31 re-read k = 0 (finite) against zero weights;
-//   * the weights' three terms are packed on the host in the B operand's lane order and live in 24 registers.
-#ifndef C1_PF2
-#define C1_PF2 0          // 1: input bytes fetched TWO tiles ahead (6 more registers: 3 instead of 4 waves per SIMD) -- A/B
-#endif
+//   * the weights' three terms are packed on the host in the B operand's lane order and live in 24 registers;
+//   * the 2x2 max is taken BEFORE bias + LeakyReLU (both non-decreasing: same bits, a quarter of the epilogue's VALU).
 typedef __bf16 c1_bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned short c1_us8 __attribute__((ext_vector_type(8)));
 typedef unsigned int c1_u4 __attribute__((ext_vector_type(4)));
@@ -169,10 +166,17 @@ __device__ __forceinline__ unsigned short c1_bf16_rne(float x)
 }
 __device__ __forceinline__ float c1_bf16_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
+// U8 = true (uint8 frames, the production input): the byte values 0..255 are EXACT bf16 numbers, so the patch needs ONE term and
+// no table at all; the 1/255 of normalize() is folded into the weights instead -- w' = float32(float64(w) / 255), carried as
+// three bf16 terms -- and a product is three MFMAs (x w'3, x w'2, x w'1).  Against the reference's float32(x / 255) * w this
+// moves one float32 rounding from the activation to the weight (each product still carries exactly one rounding of 2^-24):
+// fp32 accuracy, not the same bits as the float32-frame path (tests: both within 5e-6 of the oracle, 2e-6 of each other).
+// U8 = false (float32 frames, already normalised): arbitrary values, the general three-term form with six products.
+template <bool U8>
 __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
 {
-    __shared__ unsigned short s_pl[9 * C1_PL];        // [term 3][ci 3][18 x 18 (+4)]
-    __shared__ c1_u2 s_lut[256];
+    constexpr int NT = U8 ? 1 : 3;                    // bf16 terms of a patch value
+    __shared__ unsigned short s_pl[3 * NT * C1_PL];   // [term][ci 3][18 x 18 (+4)]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H2 = p.H >> 1, W2 = p.W >> 1;
@@ -182,8 +186,6 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
     const int bx_last = min(bx_first + p.tpw, ntx);
     const int cy0 = by * 16 - 1;                      // patch origin row in input pixels
 
-    s_lut[tid] = reinterpret_cast<const c1_u2 *>(p.lut3)[tid];
-
     // patch pixels of this thread: i0 = tid, i1 = tid + 256 (< 324 for tid < 68)
     const int r0 = tid / 18, c0 = tid - r0 * 18;
     const int i1 = tid + 256, r1 = i1 / 18, c1 = i1 - r1 * 18;
@@ -191,19 +193,16 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
     const int y0 = cy0 + r0, y1 = cy0 + r1;
     const bool yok0 = y0 >= 0 && y0 < p.H, yok1 = has1 && y1 >= 0 && y1 < p.H;
     const long long row0 = ((long long)b * p.H + y0) * p.W, row1 = ((long long)b * p.H + y1) * p.W;
-    float raw[2][3];      // u8 frames: the bytes as floats' bit patterns (table index); f32 frames: the values
-#if C1_PF2
-    float rawn[2][3];     // the tile after the one in `raw`: loads stay in flight for a whole tile (HBM latency ~ one tile's compute)
-#endif
-    auto fetch = [&](int bx, float (&raw)[2][3]) {
+    float raw[2][3];      // the values as floats (u8 frames: the byte value, converted exactly)
+    auto fetch = [&](int bx) {
         const int x0 = bx * 16 - 1 + c0, x1 = bx * 16 - 1 + c1;
         const bool ok0 = yok0 && x0 >= 0 && x0 < p.W, ok1 = yok1 && x1 >= 0 && x1 < p.W;
-        if (p.dtype == DT_FRAMES_U8) {
+        if (U8) {
             const unsigned char *f = reinterpret_cast<const unsigned char *>(p.frames);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                raw[0][c] = __int_as_float(ok0 ? (int)f[(row0 + x0) * 3 + c] : -1);
-                raw[1][c] = __int_as_float(ok1 ? (int)f[(row1 + x1) * 3 + c] : -1);
+                raw[0][c] = ok0 ? (float)f[(row0 + x0) * 3 + c] : 0.0f;
+                raw[1][c] = ok1 ? (float)f[(row1 + x1) * 3 + c] : 0.0f;
             }
         } else {
             const float *f = reinterpret_cast<const float *>(p.frames);
@@ -214,28 +213,24 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
             }
         }
     };
-    auto terms_of = [&](float v, unsigned short t[3]) {
-        if (p.dtype == DT_FRAMES_U8) {
-            const int q = __float_as_int(v);
-            const c1_u2 e = s_lut[q >= 0 ? q : 0];
-            t[0] = q >= 0 ? (unsigned short)(e.x & 0xffffu) : (unsigned short)0;
-            t[1] = q >= 0 ? (unsigned short)(e.x >> 16) : (unsigned short)0;
-            t[2] = q >= 0 ? (unsigned short)e.y : (unsigned short)0;
-        } else {              // the table's three roundings (network.hip:conv1_split_tables, wino_s3_split_host)
+    auto terms_of = [&](float v, unsigned short t[NT]) {
+        if (U8) {
+            t[0] = (unsigned short)(__float_as_uint(v) >> 16);      // 0..255 has at most 8 significant bits: exact
+        } else {              // three roundings to nearest even (host twin: wino_s3_split_host)
             t[0] = c1_bf16_rne(v);
             const float r1 = v - c1_bf16_f32(t[0]);
-            t[1] = c1_bf16_rne(r1);
-            t[2] = c1_bf16_rne(r1 - c1_bf16_f32(t[1]));
+            t[1 % NT] = c1_bf16_rne(r1);
+            t[2 % NT] = c1_bf16_rne(r1 - c1_bf16_f32(t[1 % NT]));
         }
     };
     auto stage = [&]() {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            unsigned short t0[3], t1[3];
+            unsigned short t0[NT], t1[NT];
             terms_of(raw[0][c], t0);
             terms_of(raw[1][c], t1);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 s_pl[(3 * t + c) * C1_PL + tid] = t0[t];
                 if (has1) s_pl[(3 * t + c) * C1_PL + i1] = t1[t];
             }
@@ -260,67 +255,52 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int t = 0; t < 3; ++t)
-            bw[kb][t] = __builtin_bit_cast(c1_bf8, reinterpret_cast<const c1_u4 *>(p.w3)[(kb * 3 + t) * 64 + lane]);
+            bw[kb][t] = __builtin_bit_cast(c1_bf8, reinterpret_cast<const c1_u4 *>(U8 ? p.w3u8 : p.w3)[(kb * 3 + t) * 64 + lane]);
     const float bias = p.bias[n];
 
-    fetch(bx_first, raw);
-#if C1_PF2
-    if (bx_first + 1 < bx_last) fetch(bx_first + 1, rawn);
-#endif
-    __syncthreads();                                            // the term table is in LDS
+    fetch(bx_first);
     for (int bx = bx_first; bx < bx_last; ++bx) {
         stage();
         __syncthreads();
-#if C1_PF2
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) raw[i][c] = rawn[i][c];  // (issued a tile ago)
-        if (bx + 2 < bx_last) fetch(bx + 2, rawn);              // in flight under this tile's MFMAs and the next one's
-#else
-        if (bx + 1 < bx_last) fetch(bx + 1, raw);               // in flight under the MFMAs below
-#endif
+        if (bx + 1 < bx_last) fetch(bx + 1);                    // in flight under the MFMAs below
         {
             // pooled rows g = 2 wave, 2 wave + 1 of the tile (gi = 0, 1: +36 elements), one after the other: the second group's
             // fragment reads are in flight under the first group's MFMAs, and only one group's fragments are live
-            f32x16 acc0, acc1;
+            f32x16 acc[2];
 #pragma unroll
             for (int gi = 0; gi < 2; ++gi) {
-                c1_bf8 a[2][3];
+                c1_bf8 a[2][NT];
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
+                    for (int t = 0; t < NT; ++t) {
                         c1_us8 v;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = s_pl[3 * t * C1_PL + aoff[kb][e] + 36 * gi];
                         a[kb][t] = __builtin_bit_cast(c1_bf8, v);
                     }
-                f32x16 acc;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-                // six partial products per k-block, smallest first: (x3 w1, x2 w2, x1 w3), (x2 w1, x1 w2), x1 w1; the two k-blocks alternate
-#define C1_MM(ta, tb)                                                                                  \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][ta], bw[0][tb], acc, 0, 0, 0);       \
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][ta], bw[1][tb], acc, 0, 0, 0);
-                C1_MM(2, 0) C1_MM(1, 1) C1_MM(0, 2) C1_MM(1, 0) C1_MM(0, 1) C1_MM(0, 0)
+                for (int i = 0; i < 16; ++i) acc[gi][i] = 0.0f;
+                // partial products smallest first; the two k-blocks alternate.  U8: x w3, x w2, x w1.  General form: the six of
+                // weight >= 2^-16: (x3 w1, x2 w2, x1 w3), (x2 w1, x1 w2), x1 w1
+#define C1_MM(ta, tb)                                                                                                  \
+                acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][ta], bw[0][tb], acc[gi], 0, 0, 0);               \
+                acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][ta], bw[1][tb], acc[gi], 0, 0, 0);
+                if (U8) { C1_MM(0, 2) C1_MM(0, 1) C1_MM(0, 0) }
+                else { C1_MM(2 % NT, 0) C1_MM(1 % NT, 1) C1_MM(0, 2) C1_MM(1 % NT, 0) C1_MM(0, 1) C1_MM(0, 0) }
 #undef C1_MM
-                if (gi == 0) acc0 = acc; else acc1 = acc;
             }
+            // bias + LeakyReLU + 2x2 max: LeakyReLU (slope >= 0) and the bias add are non-decreasing, so the max of the window's
+            // four accumulators goes first and the activation is applied once -- the same bits as activating all four
 #pragma unroll
             for (int gi = 0; gi < 2; ++gi) {
                 const int oy = by * 8 + wave * 2 + gi;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {                   // window w = h + 2 j
-                    float mx = -INFINITY;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float v = (gi ? acc1[4 * j + q] : acc0[4 * j + q]) + bias;
-                        v = v > 0.0f ? v : v * p.slope;
-                        mx = fmaxf(mx, v);
-                    }
+                    const float mx = fmaxf(fmaxf(acc[gi][4 * j], acc[gi][4 * j + 1]), fmaxf(acc[gi][4 * j + 2], acc[gi][4 * j + 3])) + bias;
+                    const float v = mx > 0.0f ? mx : mx * p.slope;
                     const int ox = bx * 8 + h + 2 * j;
-                    if (oy < H2 && ox < W2) p.out[(((long long)b * H2 + oy) * W2 + ox) * 32 + n] = mx;
+                    if (oy < H2 && ox < W2) p.out[(((long long)b * H2 + oy) * W2 + ox) * 32 + n] = v;
                 }
             }
         }
@@ -328,18 +308,14 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
     }
 }
 
-// Host: the two constant tables of conv1_s3_kernel.
-//   lut3 [256][2]: the three bf16 terms of float32(float64(i) / 255.) (utils.py:150-153) as (t1 | t2 << 16, t3)
+// Host: the weight tables of conv1_s3_kernel.
 //   w3 [2][3][64][4]: B operand of v_mfma_f32_32x32x16_bf16 per (k-block kb, term): lane = 32 h + n holds k = 16 kb + 8 h .. + 7
 //   of column n as four dwords (k even | k odd << 16); w = [27][32] (k = 9 ky + 3 kx + ci, BatchNorm scale folded), k >= 27: 0
-void conv1_split_tables(const float *w /*[27][32]*/, unsigned *lut3 /*[512]*/, unsigned *w3 /*[1536]*/)
+//   scale255: the uint8 form -- every weight divided by 255 in float64 first (normalize(), utils.py:150-153, folded into the weights)
+void conv1_split_tables(const float *w_in /*[27][32]*/, bool scale255, unsigned *w3 /*[1536]*/)
 {
-    for (int i = 0; i < 256; ++i) {
-        unsigned short t[3];
-        wino_s3_split_host((float)((double)i / 255.0), t);
-        lut3[2 * i] = (unsigned)t[0] | ((unsigned)t[1] << 16);
-        lut3[2 * i + 1] = t[2];
-    }
+    float w[27 * 32];
+    for (int i = 0; i < 27 * 32; ++i) w[i] = scale255 ? (float)((double)w_in[i] / 255.0) : w_in[i];
     for (int kb = 0; kb < 2; ++kb)
         for (int ln = 0; ln < 64; ++ln)
             for (int j = 0; j < 4; ++j) {
@@ -352,13 +328,13 @@ void conv1_split_tables(const float *w /*[27][32]*/, unsigned *lut3 /*[512]*/, u
 }
 
 int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, int H, int W, const float *w_packed,
-                        const float *bias, const float *lut, float slope, float *out, const unsigned *lut3, const unsigned *w3)
+                        const float *bias, const float *lut, float slope, float *out, const unsigned *w3, const unsigned *w3u8)
 {
     if ((H & 1) || (W & 1) || B <= 0) return 2;
     Conv1Args a;
     a.frames = frames; a.dtype = dtype; a.B = B; a.H = H; a.W = W;
     a.w = w_packed; a.bias = bias; a.lut = lut; a.slope = slope; a.out = out;
-    a.lut3 = lut3; a.w3 = w3;
+    a.w3 = w3; a.w3u8 = w3u8;
     const int H2 = H / 2, W2 = W / 2;
     // whole rows per workgroup when there are thousands of rows (the walk hides each tile's load latency); with a few
     // frames per call shorter walks keep every CU busy
@@ -368,7 +344,10 @@ int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, in
     while (tpw > 1 && rows * ((ntx + tpw - 1) / tpw) < 2048) tpw = (tpw + 1) / 2;
     a.tpw = tpw;
     const dim3 grid((unsigned)((ntx + tpw - 1) / tpw), (unsigned)((H2 + 7) / 8), (unsigned)B);
-    if (lut3 && w3) hipLaunchKernelGGL(conv1_s3_kernel, grid, dim3(256), 0, st, a);      // split-bf16 form (Policy::s3 != 0)
-    else hipLaunchKernelGGL(conv1_mfma_kernel, grid, dim3(256), 0, st, a);
+    if (w3 && w3u8) {      // split-bf16 form (Policy::s3_conv1)
+        if (dtype == DT_FRAMES_U8) hipLaunchKernelGGL(conv1_s3_kernel<true>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(conv1_s3_kernel<false>, grid, dim3(256), 0, st, a);
+    } else
+        hipLaunchKernelGGL(conv1_mfma_kernel, grid, dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

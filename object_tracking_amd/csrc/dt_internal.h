@@ -191,8 +191,8 @@ void wino_pack_weights(int ts, const float *hwio, int cin_src, int cout_src, con
 int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, int H, int W,
                         const float *w_packed /*[27][32]*/, const float *bias /*[32]*/,
                         const float *lut /*[256] or null*/, float slope, float *out /*[B,H/2,W/2,32]*/,
-                        const unsigned *lut3 = nullptr /*[256][2]*/, const unsigned *w3 = nullptr /*[2][3][64][4]: both set -> conv1_s3_kernel*/);
-void conv1_split_tables(const float *w /*[27][32]*/, unsigned *lut3 /*[512]*/, unsigned *w3 /*[1536]*/);
+                        const unsigned *w3 = nullptr /*[2][3][64][4]*/, const unsigned *w3u8 = nullptr /*weights / 255: both set -> conv1_s3_kernel*/);
+void conv1_split_tables(const float *w /*[27][32]*/, bool scale255, unsigned *w3 /*[1536]*/);
 
 int launch_decode(hipStream_t st, const float *netout, long long frame_stride, int batch, int GH, int GW, int NB,
                   int NC, float obj_thr, float nms_thr, const float *anchors_dev, int cap, float *boxes,
@@ -284,7 +284,8 @@ struct Policy {
     int s3_conv1 = 1;        // DT_S3_CONV1: conv_1 on the bf16 pipe with split operands (conv1_s3_kernel); 0 = conv1_mfma_kernel (fp32 MFMA)
     int s3 = 1;              // DT_S3: the F(6x6) layers' batched GEMMs on the bf16 matrix pipe with 3-term split operands (wino_gemm_s3.hip):
                              //        0 never (fp32 MFMA) / 1 where it wins (K >= s3_mink, GEMM rows >= s3_minrows) / 2 wherever the shape allows
-    int s3_mink = 256, s3_minrows = 2048;   // DT_S3_MINK / DT_S3_MINROWS
+    int s3_mink = 128, s3_minrows = 2048;   // DT_S3_MINK / DT_S3_MINROWS (K >= 128 since round 4: with the line-sized epilogue stores the K = 128 GEMMs of
+                                            // conv_6 / conv_8 take 3.4 instead of 4.3 ms on the fp32 kernel, their split input transform costs 0.7 back)
     int s3_half = 0;          // DT_S3_HALF: 128-row tiles / two workgroups per CU in the split GEMM: 0 where it needs fewer rounds (default) / 1 always (N % 256 == 0) / -1 never
     int s3_rec_minrows = 512; // DT_S3_REC_MINROWS: the ConvLSTM recurrent step's F(4x4) GEMM (gate update in its output transform) takes the split
                               //                    kernel from this many GEMM rows (48 clips at 13x13: 588); 0 = never
@@ -315,7 +316,7 @@ struct dt_ctx {
     unsigned short *s3_ones = nullptr;   // device, [3][256][16]: split terms of the A rows (1, 0, .., 0) that carry a 1x1 layer's bias through wino_gemm_s3.hip
     std::map<const void *, unsigned short *> wino_s3;   // F(6x6) Winograd weights (device pointer) -> their split-bf16 form (wino_gemm_s3.hip), when built
     float *conv1_w = nullptr, *conv1_b = nullptr, *lut255 = nullptr;
-    unsigned *conv1_lut3 = nullptr, *conv1_w3 = nullptr;   // device: split-bf16 tables of conv1_s3_kernel (conv1.hip:conv1_split_tables)
+    unsigned *conv1_w3 = nullptr, *conv1_w3u8 = nullptr;   // device: split-bf16 weight tables of conv1_s3_kernel: w and w / 255 (conv1.hip:conv1_split_tables)
     std::vector<float> conv1_hwio32, conv1_scale, conv1_shift;   // host copy of conv_1 as a Cin = 32 layer (dt_detector_extract)
     // tracker head
     bool trk_loaded = false;

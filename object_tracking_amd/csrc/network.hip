@@ -219,8 +219,8 @@ extern "C" void dt_destroy(dt_ctx *ctx)
     s3_drop(ctx, ctx->trk_wx_wino);
     s3_drop(ctx, ctx->trk_wh_wino);
     if (ctx->s3_ones) (void)hipFree(ctx->s3_ones);
-    if (ctx->conv1_lut3) (void)hipFree(ctx->conv1_lut3);
     if (ctx->conv1_w3) (void)hipFree(ctx->conv1_w3);
+    if (ctx->conv1_w3u8) (void)hipFree(ctx->conv1_w3u8);
     for (float *p : singles)
         if (p) (void)hipFree(p);
     for (auto &e : ctx->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -380,10 +380,11 @@ extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t 
             if (rc) return rc;
             rc = upload(ctx, &ctx->conv1_b, shift);
             if (rc) return rc;
-            {   // the same weights and the x/255 table as three bf16 terms (conv1_s3_kernel)
-                std::vector<unsigned> lut3(512), w3(1536);
-                conv1_split_tables(w.data(), lut3.data(), w3.data());
-                for (auto pr : {std::make_pair(&ctx->conv1_lut3, &lut3), std::make_pair(&ctx->conv1_w3, &w3)}) {
+            {   // the same weights as three bf16 terms, plain (float32 frames) and with normalize()'s 1/255 folded in (uint8 frames): conv1_s3_kernel
+                std::vector<unsigned> w3(1536), w3u8(1536);
+                conv1_split_tables(w.data(), false, w3.data());
+                conv1_split_tables(w.data(), true, w3u8.data());
+                for (auto pr : {std::make_pair(&ctx->conv1_w3, &w3), std::make_pair(&ctx->conv1_w3u8, &w3u8)}) {
                     if (*pr.first) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(*pr.first); *pr.first = nullptr; }
                     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(pr.first), pr.second->size() * sizeof(unsigned)));
                     HIP_TRY(ctx, hipMemcpy(*pr.first, pr.second->data(), pr.second->size() * sizeof(unsigned), hipMemcpyHostToDevice));
@@ -977,7 +978,7 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
                      (double)B * H * W * 3.0 * (dtype == DT_FRAMES_U8 ? 1 : 4) + 4.0 * B * (H / 2) * (W / 2) * 32.0);
         const bool c1s3 = ctx->pol.s3 != 0 && ctx->pol.s3_conv1 != 0;
         if (launch_conv1_direct(ctx->stream, frames, dtype, B, H, W, ctx->conv1_w, ctx->conv1_b, ctx->lut255, LEAKY,
-                                bufA, c1s3 ? ctx->conv1_lut3 : nullptr, c1s3 ? ctx->conv1_w3 : nullptr))
+                                bufA, c1s3 ? ctx->conv1_w3 : nullptr, c1s3 ? ctx->conv1_w3u8 : nullptr))
             return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");
     }
     const int h = H / 32, w = W / 32;
@@ -1102,7 +1103,7 @@ extern "C" int dt_detector_extract(dt_ctx *ctx, const void *d_frames, int frames
         ctx->tap_feat = ctx->tap_netout = false;
         const bool c1s3 = ctx->pol.s3 != 0 && ctx->pol.s3_conv1 != 0;
         if (launch_conv1_direct(ctx->stream, d_frames, frames_dtype, B, H, W, ctx->conv1_w, ctx->conv1_b, ctx->lut255, LEAKY, bufA,
-                                c1s3 ? ctx->conv1_lut3 : nullptr, c1s3 ? ctx->conv1_w3 : nullptr))
+                                c1s3 ? ctx->conv1_w3 : nullptr, c1s3 ? ctx->conv1_w3u8 : nullptr))
             return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");
         if (idx == 1) {   // max_pooling2d_1
             HIP_TRY(ctx, hipMemcpyAsync(d_out, bufA, need * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));

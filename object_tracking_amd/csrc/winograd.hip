@@ -423,6 +423,9 @@ static unsigned wino_blocks(long long items)
 #ifndef WINO_WAVE_SYNC
 #define WINO_WAVE_SYNC 1
 #endif
+#ifndef WINO_ONE_IMAGE
+#define WINO_ONE_IMAGE WINO_WAVE_SYNC      // 8-channel kernels: one LDS image reused for both channel halves (needs the wave-local sync)
+#endif
 __device__ __forceinline__ void wino_item_sync()
 {
 #if WINO_WAVE_SYNC
@@ -512,12 +515,12 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_input_s3_kernel(WinoAr
     constexpr int NI = TS + 2;
     typedef VecOf<4>::T T;
     constexpr int IPW = WINO_S3IN_THREADS / 8;      // items per workgroup
-    __shared__ __attribute__((aligned(16))) float s_t[WINO_WAVE_SYNC ? 1 : 2][IPW * WINO_COOP_ITEM];
+    __shared__ __attribute__((aligned(16))) float s_t[WINO_ONE_IMAGE ? 1 : 2][IPW * WINO_COOP_ITEM];
     const int mt4 = (p.Mt + 3) & ~3;
     const long long items = (long long)mt4 * (p.C / 8);
     const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;
     float *st0 = s_t[0] + slot * WINO_COOP_ITEM;
-    [[maybe_unused]] float *st1 = s_t[WINO_WAVE_SYNC ? 0 : 1] + slot * WINO_COOP_ITEM;
+    [[maybe_unused]] float *st1 = s_t[WINO_ONE_IMAGE ? 0 : 1] + slot * WINO_COOP_ITEM;
     const long long term = (long long)(p.C >> 4) * p.Mp * 16;        // elements of one (plane, term)
     for (long long base = (long long)blockIdx.x * IPW; base < items; base += (long long)gridDim.x * IPW) {
         const long long it = base + slot;
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_input_s3_kernel(WinoAr
         }
         bt_1d<TS>(ca);                           // Bt d : down the column
         bt_1d<TS>(cb);
-#if WINO_WAVE_SYNC      // one LDS image, the two channel halves one after the other
+#if WINO_ONE_IMAGE      // one LDS image, the two channel halves one after the other
 #pragma unroll
         for (int i = 0; i < NI; ++i) vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]);
         wino_item_sync();
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_input_s3_kernel(WinoAr
 #else
 #pragma unroll
         for (int i = 0; i < NI; ++i) { vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]); vstore<4>(st1 + (sub * 9 + i) * 4, cb[i]); }
-        __syncthreads();
+        wino_item_sync();
 #pragma unroll
         for (int j = 0; j < NI; ++j) { ca[j] = vload<4>(st0 + (j * 9 + sub) * 4); cb[j] = vload<4>(st1 + (j * 9 + sub) * 4); }
 #endif
@@ -675,13 +678,13 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_output_s3_kernel(WinoA
 {
     typedef VecOf<4>::T T;
     constexpr int IPW = WINO_S3IN_THREADS / 8;
-    __shared__ __attribute__((aligned(16))) float s_t[WINO_WAVE_SYNC ? 1 : 2][IPW * WINO_COOP_ITEM];
+    __shared__ __attribute__((aligned(16))) float s_t[WINO_ONE_IMAGE ? 1 : 2][IPW * WINO_COOP_ITEM];
     const int mt4 = (p.Mt + 3) & ~3;
     const long long items = (long long)mt4 * (p.N / 8);
     const long long plane = (long long)p.Mt * p.m_ld;
     const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;
     float *st0 = s_t[0] + slot * WINO_COOP_ITEM;
-    [[maybe_unused]] float *st1 = s_t[WINO_WAVE_SYNC ? 0 : 1] + slot * WINO_COOP_ITEM;
+    [[maybe_unused]] float *st1 = s_t[WINO_ONE_IMAGE ? 0 : 1] + slot * WINO_COOP_ITEM;
     const long long term = (long long)(p.N >> 4) * p.out_mp * 16;
     for (long long base = (long long)blockIdx.x * IPW; base < items; base += (long long)gridDim.x * IPW) {
         const long long it = base + slot;
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_output_s3_kernel(WinoA
         }
         at_1d<6>(ca);                            // m A : along the row -> columns 0..5
         at_1d<6>(cb);
-#if WINO_WAVE_SYNC      // one LDS image, the two channel halves one after the other (lanes 6, 7 read rows that were never written: unused)
+#if WINO_ONE_IMAGE      // one LDS image, the two channel halves one after the other (lanes 6, 7 read rows that were never written: unused)
 #pragma unroll
         for (int i = 0; i < 6; ++i) vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]);
         wino_item_sync();
@@ -716,10 +719,10 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_output_s3_kernel(WinoA
 #else
 #pragma unroll
         for (int i = 0; i < 6; ++i) { vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]); vstore<4>(st1 + (sub * 9 + i) * 4, cb[i]); }
-        __syncthreads();
+        wino_item_sync();
 #endif
         if (sub < 6) {
-#if !WINO_WAVE_SYNC
+#if !WINO_ONE_IMAGE
 #pragma unroll
             for (int j = 0; j < 8; ++j) { ca[j] = vload<4>(st0 + (j * 9 + sub) * 4); cb[j] = vload<4>(st1 + (j * 9 + sub) * 4); }
 #endif

@@ -348,10 +348,11 @@ def _detector(ctx_unused, H, W, C, seed=1234):
 
 @pytest.mark.parametrize("H,W,B", [(64, 96, 3), (416, 416, 2), (32, 32, 1)])
 def test_conv1_split_bf16_vs_oracle_and_fp32_mfma(ctx, monkeypatch, H, W, B):
-    """conv_1 + x/255 + BN + LeakyReLU + 2x2 max (KerasYOLO.py:278-282) as conv1_s3_kernel (bf16 MFMA on 3-term split
-    operands, the x/255 table holding the three terms per byte value; default) against the oracle, against the fp32 MFMA
-    kernel (DT_S3_CONV1=0), and uint8 frames against the same frames handed over as float32 x/255 (bit-equal: the in-kernel
-    split of a float32 frame makes the table's three roundings)."""
+    """conv_1 + x/255 + BN + LeakyReLU + 2x2 max (KerasYOLO.py:278-282) as conv1_s3_kernel (bf16 MFMA on split operands; default)
+    against the oracle and against the fp32 MFMA kernel (DT_S3_CONV1=0), for uint8 frames (bytes are exact bf16 numbers; 1/255
+    folded into the three-term weights) and for the same frames handed over as float32 x/255 (general three-term form).  The fp32
+    MFMA kernel gives the same bits for both inputs (x/255 table); the split kernel's two forms place one float32 rounding
+    differently (activation vs weight) and agree to 2e-6."""
     det, layers, _ = _detector(ctx, H, W, 12)
     c = det.model.ctx
     frames = np.random.RandomState(H + W).randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
@@ -367,11 +368,11 @@ def test_conv1_split_bf16_vs_oracle_and_fp32_mfma(ctx, monkeypatch, H, W, B):
         got[mode + "f"] = c.detector_extract(dev(x, c), "max_pooling2d_1").cpu().numpy()
     monkeypatch.delenv("DT_S3_CONV1")
     c.reload_policy()
-    assert np.array_equal(got["1"], got["1f"]) and np.array_equal(got["0"], got["0f"])
-    for k in ("1", "0"):
+    assert np.array_equal(got["0"], got["0f"])
+    for k in ("1", "1f", "0"):
         assert got[k].shape == (B, H // 2, W // 2, 32)
         assert chan_err(got[k], want) < 5e-6, (k, chan_err(got[k], want))
-    assert chan_err(got["1"], got["0"]) < 2e-6
+    assert chan_err(got["1"], got["0"]) < 2e-6 and chan_err(got["1f"], got["0"]) < 2e-6 and chan_err(got["1"], got["1f"]) < 2e-6
 
 
 @pytest.mark.parametrize("H,W,C,B", [(64, 64, 12, 3), (96, 64, 80, 2)])
@@ -383,9 +384,11 @@ def test_detector_forward_vs_oracle_small(ctx, H, W, C, B):
     net, feat = det.model.ctx.detect_forward(dev(frames, det.model.ctx), want_feat=True)
     assert chan_err(flat_c(net.cpu().numpy()), flat_c(ref_net)) < NET_TOL
     assert chan_err(feat.cpu().numpy(), ref_feat) < NET_TOL
-    # float32 frames (already normalised) take the same path
+    # float32 frames (already normalised): conv_1's general split form instead of the uint8 one (one float32 rounding sits on
+    # the activation instead of on the weight): the same network to rounding
     net32 = det.model.ctx.detect_forward(dev(orc.normalize_u8(frames), det.model.ctx))
-    assert torch.equal(net32, net)
+    assert chan_err(flat_c(net32.cpu().numpy()), flat_c(net.cpu().numpy())) < 3e-5
+    assert chan_err(flat_c(net32.cpu().numpy()), flat_c(ref_net)) < NET_TOL
     # named taps (KerasYOLO.extract)
     det.model.ctx.detect_forward_internal(dev(frames, det.model.ctx))
     a13 = det.model.ctx.detector_tap("act_13", B).cpu().numpy()
