@@ -186,9 +186,24 @@ __device__ __forceinline__ void s3_split4(const VecOf<4>::T x, wino_u2 t[3])
     t[0] = __builtin_bit_cast(wino_u2, h); t[1] = __builtin_bit_cast(wino_u2, m); t[2] = __builtin_bit_cast(wino_u2, l);
 }
 
+typedef __bf16 wino_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void s3_split2(const VecOf<2>::T x, unsigned t[3])
+{
+    const wino_bf2 h = __builtin_convertvector(x, wino_bf2);
+    const VecOf<2>::T r1 = x - __builtin_convertvector(h, VecOf<2>::T);
+    const wino_bf2 m = __builtin_convertvector(r1, wino_bf2);
+    const VecOf<2>::T r2 = r1 - __builtin_convertvector(m, VecOf<2>::T);
+    const wino_bf2 l = __builtin_convertvector(r2, wino_bf2);
+    t[0] = __builtin_bit_cast(unsigned, h); t[1] = __builtin_bit_cast(unsigned, m); t[2] = __builtin_bit_cast(unsigned, l);
+}
+
 // One work item = (tile, V channels).  Tile (grp, ty, tx) covers virtual rows TS*ty-1 .. TS*ty+TS, cols
 // TS*tx-1 .. TS*tx+TS ('same' padding, separators and the rows/columns past the image read as zero).
-// S3 (V == 4): V leaves as split-bf16 terms [P][3][C/16][Mp][16] (the recurrent step's F(4x4) GEMM on wino_gemm_s3.hip)
+// S3: V leaves as split-bf16 terms [P][3][C/16][Mp][16] (wino_gemm_s3.hip).  Items then run (16-channel block, tile, channel group)
+// with the channel group fastest and the tile next: the 16 / V lanes of a block's channel groups and the consecutive tiles behind
+// them are CONTIGUOUS in every (position, term) plane -- a store instruction of a wavefront writes one 256-byte (V = 2) run of ONE
+// plane, where the lane-cooperative producers write eight 128-byte lines of eight planes.  V = 2 is the F(6x6) producer for large
+// launches since round 4 (5.3-5.8 instead of 4.2-4.6 TB/s); V = 4: the F(4x4) recurrent step with DT_WINO_COOP=0.
 template <int TS, int V, bool S3 = false> __global__ __launch_bounds__(WINO_THREADS) void wino_input_kernel(WinoArgs p)
 {
     typedef typename VecOf<V>::T T;
@@ -198,8 +213,16 @@ template <int TS, int V, bool S3 = false> __global__ __launch_bounds__(WINO_THRE
     const long long plane = (long long)p.Mt * p.C;
     for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items;
          it += (long long)gridDim.x * blockDim.x) {
-        const int tile = (int)(it / cq_n);
-        const int c = (int)(it - (long long)tile * cq_n) * V;
+        int tile, c;
+        if constexpr (S3) {
+            constexpr int GPB = 16 / V;                 // channel groups per 16-channel block
+            const long long tb = it / GPB;
+            c = (int)(tb / p.Mt) * 16 + (int)(it - tb * GPB) * V;
+            tile = (int)(tb % p.Mt);
+        } else {
+            tile = (int)(it / cq_n);
+            c = (int)(it - (long long)tile * cq_n) * V;
+        }
         const TileId t = tile_id(p, tile);
         T d[NI][NI];
 #pragma unroll
@@ -235,6 +258,21 @@ template <int TS, int V, bool S3 = false> __global__ __launch_bounds__(WINO_THRE
                 for (int j = 0; j < NI; ++j)
 #pragma unroll
                     for (int k = 0; k < 3; ++k) *reinterpret_cast<wino_u2 *>(dst + ((long long)(NI * i + j) * 3 + k) * term) = tr[j][k];
+            }
+        } else if constexpr (S3 && V == 2) {
+            const long long term = (long long)(p.C >> 4) * p.Mp * 16;
+            unsigned short *dst = p.v_s3 + ((long long)(c >> 4) * p.Mp + tile) * 16 + (c & 15);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                bt_1d<TS>(d[i]);
+                unsigned tr[NI][3];      // a row's splits before its stores (a VALU write to a register an in-flight store reads waits for it)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) s3_split2(d[i][j], tr[j]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        __builtin_nontemporal_store(tr[j][k], reinterpret_cast<unsigned *>(dst + ((long long)(NI * i + j) * 3 + k) * term));
             }
         } else {
             float *dst = p.v + (long long)tile * p.C + c;
@@ -804,7 +842,11 @@ int launch_wino_input(hipStream_t st, const WinoArgs &a)
             hipLaunchKernelGGL((wino_input_kernel<4, 4, true>), dim3(wino_blocks((long long)a.Mt * (a.C / 4))), dim3(wino_threads((long long)a.Mt * (a.C / 4))), 0, st, a);
     } else if (a.v_s3) {
         if (a.ts != 6 || a.C % 32 || a.Mp < a.Mt) return 2;
-        if (a.coop == 0) {      // A/B: the 4-channel form
+        if (a.coop == 0 || (a.coop < 0 && (long long)a.Mt * (a.C / 2) >= (long long)WINO_COOP_MAX_ITEMS)) {
+            // large launches: one thread per (tile, channel pair), plane-contiguous stores (DT_WINO_COOP=1 keeps the cooperative producer: A/B)
+            const long long items = (long long)a.Mt * (a.C / 2);
+            hipLaunchKernelGGL((wino_input_kernel<6, 2, true>), dim3(wino_blocks(items)), dim3(wino_threads(items)), 0, st, a);
+        } else if (a.coop == 2) {      // A/B: the 4-channel cooperative form
             const long long wgs = ((long long)((a.Mt + 3) & ~3) * (a.C / 4) + WINO_THREADS / 8 - 1) / (WINO_THREADS / 8);
             hipLaunchKernelGGL(wino_input_coop6_kernel<true>, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
         } else {

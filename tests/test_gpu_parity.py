@@ -387,7 +387,7 @@ def test_detector_forward_vs_oracle_small(ctx, H, W, C, B):
     # float32 frames (already normalised): conv_1's general split form instead of the uint8 one (one float32 rounding sits on
     # the activation instead of on the weight): the same network to rounding
     net32 = det.model.ctx.detect_forward(dev(orc.normalize_u8(frames), det.model.ctx))
-    assert chan_err(flat_c(net32.cpu().numpy()), flat_c(net.cpu().numpy())) < 3e-5
+    assert chan_err(flat_c(net32.cpu().numpy()), flat_c(net.cpu().numpy())) < 1e-4      # (F(6x6) on every layer, DT_WINO=2: 4e-5)
     assert chan_err(flat_c(net32.cpu().numpy()), flat_c(ref_net)) < NET_TOL
     # named taps (KerasYOLO.extract)
     det.model.ctx.detect_forward_internal(dev(frames, det.model.ctx))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # scratch experiment runner on the GPU box (via gpurun): edit freely between calls; outputs land in gpurun_out/<tag>/
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-exp}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
-timeout 1200 python -m pytest tests/test_gpu_parity.py -q -x -k "conv1_split or split_bf16 or winograd or detector_forward or tracker" 2>&1 | tail -8
+timeout 1200 python -m pytest tests/test_gpu_parity.py -q -x -k "split_bf16 or winograd or detector_forward or tracker or convlstm" 2>&1 | tail -8
 run() {   # label, env assignments...
   local label=$1; shift
   env "$@" timeout 600 python bench.py --no-extra --no-cpu-baseline --steps 3 --warmup 1 --layer-report $O/layers_$label.txt 2>$O/bench_$label.err | tail -1 | python -c "
@@ -12,7 +12,5 @@ print('%-10s %8.1f frames/s %7.2f ms | ' % ('$label', d['value'], d['ms_per_step
 run base X=1
 run winB MI355_DT_LIB=$R/tools/_probe_builds/libmi355_dt_winB.so
 run winC MI355_DT_LIB=$R/tools/_probe_builds/libmi355_dt_winC.so
-run 1x1k256 DT_S3_1X1_MINK=256
-run c1f32 DT_S3_CONV1=0
-run mink256 DT_S3_MINK=256
+run winCcoop MI355_DT_LIB=$R/tools/_probe_builds/libmi355_dt_winC.so DT_WINO_COOP=1
 run base2 X=1
