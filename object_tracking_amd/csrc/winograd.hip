@@ -202,8 +202,9 @@ __device__ __forceinline__ void s3_split2(const VecOf<2>::T x, unsigned t[3])
 // S3: V leaves as split-bf16 terms [P][3][C/16][Mp][16] (wino_gemm_s3.hip).  Items then run (16-channel block, tile, channel group)
 // with the channel group fastest and the tile next: the 16 / V lanes of a block's channel groups and the consecutive tiles behind
 // them are CONTIGUOUS in every (position, term) plane -- a store instruction of a wavefront writes one 256-byte (V = 2) run of ONE
-// plane, where the lane-cooperative producers write eight 128-byte lines of eight planes.  V = 2 is the F(6x6) producer for large
-// launches since round 4 (5.3-5.8 instead of 4.2-4.6 TB/s); V = 4: the F(4x4) recurrent step with DT_WINO_COOP=0.
+// plane, where the lane-cooperative producers write eight 128-byte lines of eight planes.  Built and measured in round 4 as a
+// candidate for the big F(6x6) launches (V = 2): 12.2 ms per step against 11.5 for the cooperative producer -- kept as the
+// DT_WINO_COOP=0 form (A/B, parity tests); V = 4: the F(4x4) recurrent step with DT_WINO_COOP=0.
 template <int TS, int V, bool S3 = false> __global__ __launch_bounds__(WINO_THREADS) void wino_input_kernel(WinoArgs p)
 {
     typedef typename VecOf<V>::T T;
@@ -553,12 +554,16 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_input_s3_kernel(WinoAr
     constexpr int NI = TS + 2;
     typedef VecOf<4>::T T;
     constexpr int IPW = WINO_S3IN_THREADS / 8;      // items per workgroup
-    __shared__ __attribute__((aligned(16))) float s_t[WINO_ONE_IMAGE ? 1 : 2][IPW * WINO_COOP_ITEM];
+    // measured (profiles/r04_transform_ab.txt): the big F(6x6) launches are fastest with round 3's form -- two LDS images and a
+    // workgroup barrier (11.5 vs 12.4 ms per step: the serialised halves of the one-image form cost more than its occupancy
+    // returns) --, the recurrent step's small F(4x4) launch with the wave-local sync (25 vs 28 us)
+    constexpr bool ONE = WINO_ONE_IMAGE && TS == 4;
+    __shared__ __attribute__((aligned(16))) float s_t[ONE ? 1 : 2][IPW * WINO_COOP_ITEM];
     const int mt4 = (p.Mt + 3) & ~3;
     const long long items = (long long)mt4 * (p.C / 8);
     const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;
     float *st0 = s_t[0] + slot * WINO_COOP_ITEM;
-    [[maybe_unused]] float *st1 = s_t[WINO_ONE_IMAGE ? 0 : 1] + slot * WINO_COOP_ITEM;
+    [[maybe_unused]] float *st1 = s_t[ONE ? 0 : 1] + slot * WINO_COOP_ITEM;
     const long long term = (long long)(p.C >> 4) * p.Mp * 16;        // elements of one (plane, term)
     for (long long base = (long long)blockIdx.x * IPW; base < items; base += (long long)gridDim.x * IPW) {
         const long long it = base + slot;
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_input_s3_kernel(WinoAr
         }
         bt_1d<TS>(ca);                           // Bt d : down the column
         bt_1d<TS>(cb);
-#if WINO_ONE_IMAGE      // one LDS image, the two channel halves one after the other
+if constexpr (ONE) {      // one LDS image, the two channel halves one after the other
 #pragma unroll
         for (int i = 0; i < NI; ++i) vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]);
         wino_item_sync();
@@ -594,13 +599,13 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_input_s3_kernel(WinoAr
         wino_item_sync();
 #pragma unroll
         for (int j = 0; j < NI; ++j) cb[j] = vload<4>(st0 + (j * 9 + sub) * 4);
-#else
+        } else {
 #pragma unroll
         for (int i = 0; i < NI; ++i) { vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]); vstore<4>(st1 + (sub * 9 + i) * 4, cb[i]); }
-        wino_item_sync();
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < NI; ++j) { ca[j] = vload<4>(st0 + (j * 9 + sub) * 4); cb[j] = vload<4>(st1 + (j * 9 + sub) * 4); }
-#endif
+        }
         bt_1d<TS>(ca);                           // (Bt d) B : along the row
         bt_1d<TS>(cb);
         if (live && sub < NI) {
@@ -622,7 +627,7 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_input_s3_kernel(WinoAr
 #pragma unroll
                 for (int k = 0; k < 3; ++k) *reinterpret_cast<wino_u4 *>(dst + ((long long)(NI * sub + j) * 3 + k) * term) = o[j][k];
         }
-        wino_item_sync();
+        if constexpr (ONE) wino_item_sync(); else __syncthreads();
     }
 }
 
@@ -842,8 +847,9 @@ int launch_wino_input(hipStream_t st, const WinoArgs &a)
             hipLaunchKernelGGL((wino_input_kernel<4, 4, true>), dim3(wino_blocks((long long)a.Mt * (a.C / 4))), dim3(wino_threads((long long)a.Mt * (a.C / 4))), 0, st, a);
     } else if (a.v_s3) {
         if (a.ts != 6 || a.C % 32 || a.Mp < a.Mt) return 2;
-        if (a.coop == 0 || (a.coop < 0 && (long long)a.Mt * (a.C / 2) >= (long long)WINO_COOP_MAX_ITEMS)) {
-            // large launches: one thread per (tile, channel pair), plane-contiguous stores (DT_WINO_COOP=1 keeps the cooperative producer: A/B)
+        if (a.coop == 0) {
+            // A/B (DT_WINO_COOP=0): one thread per (tile, channel pair), 256-byte runs of ONE plane per store instruction -- measured
+            // SLOWER than the cooperative producer's eight 128-byte lines of eight planes (12.2 vs 11.5 ms per step)
             const long long items = (long long)a.Mt * (a.C / 2);
             hipLaunchKernelGGL((wino_input_kernel<6, 2, true>), dim3(wino_blocks(items)), dim3(wino_threads(items)), 0, st, a);
         } else if (a.coop == 2) {      // A/B: the 4-channel cooperative form
