@@ -45,11 +45,6 @@ typedef const __attribute__((address_space(1))) void s3_gptr_t;
                          //   held the accumulators (a register an in-flight store reads cannot be reset) longer than four times as many
                          //   line-sized stores do.  Measured (tools/micro/gemm_s3_bench, profiles/r04_gemm_s3_epilogue.txt): K = 1024 5.06 -> 5.00 ms,
                          //   K = 512 2.89 -> 2.78, K = 256 3.19 -> 2.96, K = 128 3.93 -> 3.43, the recurrent step 0.315 -> 0.295
-#ifndef S3_DRAIN63
-#define S3_DRAIN63 1     // the first DMA wait after a tile's epilogue: vmcnt(63) instead of vmcnt(0).  vmcnt counts stores too and completes in
-#endif                   //   issue order; the next stage's pieces were issued BEFORE the epilogue's >= 64 stores, so "all but the newest 63
-                         //   operations are done" covers them without waiting for the stores themselves.  Only after a tile whose rows all
-                         //   exist (a ragged tile skips stores: fewer than 63 may follow the pieces).  0 = vmcnt(0) (round 3)
 #ifndef S3_ABLATE
 #define S3_ABLATE 0      // probes (tools/micro/gemm_s3_bench.hip): 1 no DMA, 2 no operand reads, 4 no barrier, 8 DMA from one tile's panels only
 #endif
@@ -214,8 +209,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     // wait until at most `keep` of this wave's DMA stages are still in flight (PT pieces per stage; 3 PV for the waves
     // that move no U rows when BN = 128 at eight waves)
     auto wait_dma = [&](int keep) {
-        if (keep == -63) s3_wait_vm<63>();
-        else if (keep <= 0) s3_wait_vm<0>();
+        if (keep <= 0) s3_wait_vm<0>();
         else if (keep == 1) {
             if (!U_HALF || wave < BN / 32) s3_wait_vm<PT>();
             else s3_wait_vm<3 * PV>();
@@ -241,7 +235,6 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
         for (int t3 = 0; t3 < 3; ++t3) ua[t3] = frag(sb, offU[0] + t3 * BN * 32);
     }
     bool drain = false;       // global stores were issued since the last full wait
-    bool drain_full = false;  // ... by a tile all of whose rows exist (NBW * MB * 16 >= 64 stores per wave)
 #ifdef S3_TIMING
     unsigned long long tm_lgkm = 0, tm_vm = 0, tm_bar = 0, tm_n = 0;
     const unsigned long long tm_start = __builtin_readcyclecounter();
@@ -275,7 +268,10 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                     const unsigned long long t1 = __builtin_readcyclecounter();
 #endif
                     --n_ahead;                                           // this stage is consumed
-                    wait_dma(drain ? ((S3_DRAIN63 && drain_full && NBW * MB * 16 >= 64) ? -63 : 0) : n_ahead - 1);
+                    // (after an epilogue: vmcnt(0).  vmcnt(63) -- "all but the newest 63 operations", i.e. the pieces issued before the
+                    // epilogue's stores -- was tried in round 4: 0.5 % at best, and WRONG in the two-stage ring of the 128-row form,
+                    // where a needed piece can be younger than the stores)
+                    wait_dma(drain ? 0 : n_ahead - 1);
                     drain = false;
 #ifdef S3_TIMING
                     const unsigned long long t2 = __builtin_readcyclecounter();
@@ -397,7 +393,6 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
 #endif
         if (Lcur >= ntiles) break;
         drain = true;
-        drain_full = S3_EPI_ROWS && cur.m0 + BM <= p.Mt;
         cur = tile_of(Lcur);
     }
 }

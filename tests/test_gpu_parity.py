@@ -416,7 +416,13 @@ def test_detector_full_size_one_frame_vs_oracle(ctx):
     assert n > 0 and n == len(rows)
     assert np.array_equal(got[:, 7], rows[:, 7]) and np.array_equal(got[:, 5], rows[:, 5])
     assert box_err(got, rows) < 1e-3
-    assert iou_rows(got[:, :4], rows[:, :4]).min() >= 0.999
+    # IoU >= 0.999 for every box at least one pixel high and wide.  The random head also emits degenerate boxes (w = 1.6 image
+    # widths x h = 0.0009 = 0.4 pixels): there a centre error of 7e-7 -- three orders inside the coordinate bar above -- is
+    # 7.5e-4 of the box height and the IoU reads 0.9985 (tools/diag_iou.py); for those the coordinate bar is the statement
+    real = np.minimum(rows[:, 2], rows[:, 3]) >= 1.0 / 416.0
+    assert real.sum() > 100
+    assert iou_rows(got[real, :4], rows[real, :4]).min() >= 0.999
+    assert iou_rows(got[:, :4], rows[:, :4]).min() >= 0.995
 
 
 def test_detector_full_size_default_policy_vs_oracle(ctx):
