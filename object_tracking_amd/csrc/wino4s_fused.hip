@@ -1,10 +1,10 @@
 // wino4s_fused.hip -- second-generation fused Winograd F(4x4,3x3) kernel for the early wide 3x3 layers
 // (conv_2: 32 -> 64 at 208x208 (+pool), conv_3 / conv_5: 64 -> 128 at 104x104, conv_6 / conv_8: 128 -> 256 at 52x52;
-// models_detection/KerasYOLO.py:285-320).  Same mathematics as wino4_fused.hip (V and M' never leave the CU); what
-// changed is how the operands reach the matrix cores:
+// models_detection/KerasYOLO.py:285-320).  V and M' never leave the CU.  How the operands reach the matrix cores (the first
+// fused F(4x4) kernel of round 2, deleted in round 4, streamed U through each wave's registers: profiles/HISTORY.md):
 //
-//   * the B operand U = G g Gt no longer streams through each wave's registers from L2 (the ~17 B/clk/CU limit that
-//     capped wino4_fused at 38 % of the MFMA peak): a stage's U slice is brought into LDS ONCE per
+//   * the B operand U = G g Gt does not stream through each wave's registers from L2 (a CU sustains only ~17 B/clk of such
+//     loads: 38 % of the MFMA peak in the round-2 kernel): a stage's U slice is brought into LDS ONCE per
 //     workgroup with asynchronous global->LDS DMA (global_load_lds_dwordx4, 36 x 1 KiB pieces per 4-channel stage,
 //     double-buffered) and all eight waves read their fragments from there with conflict-free ds_read_b128;
 //   * every wave owns ALL 36 Winograd positions of one block of 16 tiles x 16 output channels (144 accumulators), so
@@ -18,7 +18,8 @@
 //     next item's V(0) -- only the first item of a workgroup pays a prologue;
 //   * two wave sets swap roles every stage: one issues the stage's data movement and then its MFMAs, the other its MFMAs
 //     and then the input transform of the next stage -- on every SIMD one wave feeds the matrix pipe while its partner does
-//     the side work (issuing the side work BETWEEN the MFMA quads of every wave was measured slower: DESIGN.md 4.2e).
+//     the side work (issuing the side work BETWEEN the MFMA quads of every wave was measured slower, and so was moving 2-4 of a
+//     wave's 9 U pieces per stage to the transform set to balance the two roles: profiles/HISTORY.md, profiles/r04_experiments.txt).
 //
 // Workgroup = 8 waves = 2 blocks (4x4 tiles of 4x4 pixels each) x 4 column groups of 16 channels; v_mfma_f32_16x16x4_f32
 // (row = tile, column = channel, k = input channel).  K runs in stages of 4 input channels (one MFMA k-step), one
@@ -27,7 +28,7 @@
 //                 the other set: 36 MFMAs on V(s), U(s);  V(s+1) = Bt d B for (block, xi-half) from the patch -> Vbuf[(s+1)&1]
 //                 vmcnt(0); barrier.
 // LDS (157.7 KB of 160): U 2 x 36.9 KB | V 2 x 18.4 KB | patch 2 x 24.6 KB.
-// fp32 throughout; rounding identical in kind to wino4_fused / winograd.hip TS = 4 (products summed in another order).
+// fp32 throughout; rounding identical in kind to winograd.hip TS = 4 (products summed in another order).
 #include <type_traits>
 
 #include "dt_internal.h"
@@ -80,30 +81,37 @@ __device__ __forceinline__ void s4_at(T *m, int st)      // At (4x6): 6 inputs -
     m[0] = y0; m[st] = y1; m[2 * st] = y2; m[3 * st] = y3;
 }
 
-// Bt d B restricted to three xi rows (HALF 0: rows 0-2, HALF 1: rows 3-5) of one 6x6 window; pl = window pixel (0,0) of
-// this lane's channel in the padded patch image, o = this lane's slot of pair 0 of the half in the V stage
-template <int HALF>
-__device__ __forceinline__ void s4_transform_half(const float *pl, float *o)
+// Bt d B restricted to three xi rows (HALF 0: rows 0-2, HALF 1: rows 3-5) of one 6x6 window, in two steps so that the LDS round trip
+// of the window reads can be taken BEFORE the wave's MFMA block and the arithmetic after it (S4_TLOAD_EARLY):
+//   s4_window_load: the five window rows the half needs (HALF 0: rows 0-4, HALF 1: rows 1-5; 30 values); pl = window pixel (0,0) of
+//                   this lane's channel in the padded patch image
+//   s4_transform_half: column pass, row pass, stores; o = this lane's slot of pair 0 of the half in the V stage
+__device__ __forceinline__ void s4_window_load(const float *pl, int half, float (&w5)[5][6])
 {
-    float t[3][6];
-    float w[6][6];             // HALF 0 never reads window row 5, HALF 1 never row 0
+    const float *p0 = pl + half * (S4_PROW * 4);
 #pragma unroll
     for (int j = 0; j < 6; ++j)
 #pragma unroll
-        for (int i = (HALF == 0 ? 0 : 1); i < (HALF == 0 ? 5 : 6); ++i) w[i][j] = pl[(S4_PROW * i + 2 * j + (j >> 2)) * 4];
-    __builtin_amdgcn_sched_barrier(0);      // all 30 requests go out before the first value is consumed
+        for (int i = 0; i < 5; ++i) w5[i][j] = p0[(S4_PROW * i + 2 * j + (j >> 2)) * 4];
+}
+template <int HALF>
+__device__ __forceinline__ void s4_transform_half(const float (&w5)[5][6], float *o)
+{
+    float t[3][6];
+#define W(i, j) w5[(i) - HALF][j]           /* window row i: HALF 0 never reads row 5, HALF 1 never row 0 */
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         if (HALF == 0) {           // Bt rows 0, 1, 2
-            t[0][j] = 4.0f * w[0][j] - 5.0f * w[2][j] + w[4][j];
-            t[1][j] = -4.0f * (w[1][j] + w[2][j]) + w[3][j] + w[4][j];
-            t[2][j] = 4.0f * (w[1][j] - w[2][j]) - w[3][j] + w[4][j];
+            t[0][j] = 4.0f * W(0, j) - 5.0f * W(2, j) + W(4, j);
+            t[1][j] = -4.0f * (W(1, j) + W(2, j)) + W(3, j) + W(4, j);
+            t[2][j] = 4.0f * (W(1, j) - W(2, j)) - W(3, j) + W(4, j);
         } else {                   // Bt rows 3, 4, 5
-            t[0][j] = 2.0f * (w[3][j] - w[1][j]) - w[2][j] + w[4][j];
-            t[1][j] = 2.0f * (w[1][j] - w[3][j]) - w[2][j] + w[4][j];
-            t[2][j] = 4.0f * w[1][j] - 5.0f * w[3][j] + w[5][j];
+            t[0][j] = 2.0f * (W(3, j) - W(1, j)) - W(2, j) + W(4, j);
+            t[1][j] = 2.0f * (W(1, j) - W(3, j)) - W(2, j) + W(4, j);
+            t[2][j] = 4.0f * W(1, j) - 5.0f * W(3, j) + W(5, j);
         }
     }
+#undef W
 #pragma unroll
     for (int x = 0; x < 3; ++x) {
         const float d0 = t[x][0], d1 = t[x][1], d2 = t[x][2], d3 = t[x][3], d4 = t[x][4], d5 = t[x][5];
@@ -133,9 +141,9 @@ __device__ __forceinline__ void s4_transform_half(const float *pl, float *o)
 #ifndef S4_PRIO
 #define S4_PRIO 1           // raise the wave's issue priority while it does side work (DMA issue, input transform) beside its
 #endif                      // partner's MFMA block
-#ifndef S4_USPLIT
-#define S4_USPLIT 0         // of a wave's 9 U pieces per stage, this many are issued by the OTHER set (the one that runs the input transform) at
-#endif                      // the start of its stage: balances the two roles (data movement 2084 + 1455 vs transform 1678 + 1455 cycles per stage)
+#ifndef S4_TLOAD_EARLY
+#define S4_TLOAD_EARLY 1    // the transforming set requests its 30 window values BEFORE its MFMA block and computes after it: the LDS round trip
+#endif                      // (contended by the partner's operand reads) runs under the MFMAs instead of in front of the column pass
 #ifndef S4_PF
 #define S4_PF 2             // MFMA operand prefetch distance in quads (1 or 2)
 #endif
@@ -263,13 +271,18 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
             }
     };
     // input transform of one stage: (patch buffer pbuf, channel half hf) -> V buffer vbuf; this lane's (tile, channel), xi rows
-    // 3 vhalf .. + 2.  All 36 window values are requested before the first is used (one LDS round trip, not twelve).
-    auto transform = [&](int pbuf, int hf, int vbuf) {
-        const float *pl = Pb + pbuf * S4_PBUF + vsrc + hf * 4;
-        float *o = Vb + vbuf * S4_VBUF + vdst;
-        if (vhalf == 0) s4_transform_half<0>(pl, o);
-        else s4_transform_half<1>(pl, o);
+    // 3 vhalf .. + 2.  All 30 window values are requested at once (one LDS round trip, not ten).
+    float w5[5][6];
+    auto transform_load = [&](int pbuf, int hf) {
+        s4_window_load(Pb + pbuf * S4_PBUF + vsrc + hf * 4, vhalf, w5);
+        __builtin_amdgcn_sched_barrier(0);      // all 30 requests go out before anything else is scheduled
     };
+    auto transform_compute = [&](int vbuf) {
+        float *o = Vb + vbuf * S4_VBUF + vdst;
+        if (vhalf == 0) s4_transform_half<0>(w5, o);
+        else s4_transform_half<1>(w5, o);
+    };
+    auto transform = [&](int pbuf, int hf, int vbuf) { transform_load(pbuf, hf); transform_compute(vbuf); };
 
     const float *const a_base = Vb + (blk * 64 + lane) * 2;            // + stage buffer + pg2 * 256
     const float *const b_base = Ub + (wn * 64 + lane) * 4;             // + stage buffer + pg * 1024
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
                 // stage: odd s -> block image 0 of patch stage (s+3)/2, even s -> block image 1 of patch stage (s+2)/2 (the
                 // stage whose first half went out one stage earlier).  Past this item's patches the numbering continues
                 // into the next item's (npatch is even, so the buffers line up). ----
-                if ((!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9 - S4_USPLIT);
+                if ((!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9);
                 const int pc_all = (s + 2 + (s & 1)) >> 1;
                 const bool pnx = pc_all >= npatch;
                 if (!(S4_ABLATE & 2)) {
@@ -354,19 +367,19 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
                     patch_half(B, (s & 1) ^ 1, pnx ? pc_all - npatch : pc_all, pc_all & 1, !pnx || has_next);
                 }
                 if (S4_PRIO) __builtin_amdgcn_s_setprio(0);
-            } else if (S4_USPLIT > 0) {
-                // the transform set takes the last S4_USPLIT U pieces of each wave slot, ahead of its MFMAs (they land under them)
-                if ((!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 9 - S4_USPLIT, 9);
             }
             [[maybe_unused]] const unsigned long long c1 = S4_NOW();
+            // ---- the other set: the input transform of stage s + 1 (stage 0 of the next item after the last stage) around its MFMAs:
+            // patch buffer ((s+1)/2) & 1, channel half (s+1) & 1 (landed before the last barrier) -> V buffer (s+1) & 1 ----
+            const bool do_tr = !dset && (!last || has_next) && !(S4_ABLATE & 4);
+            const int s1 = s + 1;
+            if (S4_TLOAD_EARLY && do_tr) transform_load((s1 >> 1) & 1, s1 & 1);
             mfma_block(s & 1);
             [[maybe_unused]] const unsigned long long c2 = S4_NOW();
-            if (!dset && (!last || has_next) && !(S4_ABLATE & 4)) {
-                // ---- the other set: after its MFMAs, the input transform of stage s + 1 (stage 0 of the next item after the
-                // last stage): patch buffer ((s+1)/2) & 1, channel half (s+1) & 1, V buffer (s+1) & 1 ----
-                const int s1 = s + 1;
+            if (do_tr) {
                 if (S4_PRIO) __builtin_amdgcn_s_setprio(2);
-                transform((s1 >> 1) & 1, s1 & 1, s1 & 1);
+                if (!S4_TLOAD_EARLY) transform_load((s1 >> 1) & 1, s1 & 1);
+                transform_compute(s1 & 1);
                 if (S4_PRIO) __builtin_amdgcn_s_setprio(0);
             }
 #ifdef DT_S4_TIMING
