@@ -142,8 +142,9 @@ __device__ __forceinline__ void s4_transform_half(const float (&w5)[5][6], float
 #define S4_PRIO 1           // raise the wave's issue priority while it does side work (DMA issue, input transform) beside its
 #endif                      // partner's MFMA block
 #ifndef S4_TLOAD_EARLY
-#define S4_TLOAD_EARLY 1    // the transforming set requests its 30 window values BEFORE its MFMA block and computes after it: the LDS round trip
-#endif                      // (contended by the partner's operand reads) runs under the MFMAs instead of in front of the column pass
+#define S4_TLOAD_EARLY 0    // 1: the transforming set requests its 30 window values BEFORE its MFMA block and computes after it (the LDS round
+#endif                      // trip under the MFMAs).  Measured in round 4: 26.9-27.0 against 25.7-26.0 ms per step for conv_2 + 3 + 5 -- slower
+                            // (30 more live registers across the MFMA block, and the block's first operand reads queue behind the 30 requests)
 #ifndef S4_PF
 #define S4_PF 2             // MFMA operand prefetch distance in quads (1 or 2)
 #endif
