@@ -40,7 +40,8 @@ typedef __attribute__((address_space(3))) void s4_lptr_t;
 // debug build only (tools/s4_timing.py): per workgroup / wave / item cycle stamps and per-phase cycle sums
 #define S4_TT_WG 64
 #define S4_TT_ITEMS 8
-#define S4_TT_SLOTS 8      // 0 start, 1 prologue end, 2 loop end, 3 epilogue end, 4 sum(transform), 5 sum(mfma block), 6 sum(wait+barrier), 7 sum(dma issue)
+#define S4_TT_SLOTS 10     // 0 start, 1 prologue end, 2 loop end, 3 epilogue end, 4 sum(transform), 5 sum(mfma block), 6 sum(vmcnt wait, data-movement
+                           // stages), 7 sum(dma issue), 8 sum(barrier wait, data-movement stages), 9 sum(vmcnt + barrier wait, transform stages)
 __device__ unsigned long long g_s4_times[S4_TT_WG * 8 * S4_TT_ITEMS * S4_TT_SLOTS];
 extern "C" __attribute__((visibility("default"))) int dt_debug_s4_times(unsigned long long *dst, int clear)
 {
@@ -141,6 +142,9 @@ __device__ __forceinline__ void s4_transform_half(const float (&w5)[5][6], float
 #ifndef S4_PRIO
 #define S4_PRIO 1           // raise the wave's issue priority while it does side work (DMA issue, input transform) beside its
 #endif                      // partner's MFMA block
+#ifndef S4_PATCH_FIRST
+#define S4_PATCH_FIRST 1    // the data-movement set issues its three patch pieces (HBM: the longest latency) BEFORE its nine U pieces (L2 hits)
+#endif
 #ifndef S4_TLOAD_EARLY
 #define S4_TLOAD_EARLY 0    // 1: the transforming set requests its 30 window values BEFORE its MFMA block and computes after it (the LDS round
 #endif                      // trip under the MFMAs).  Measured in round 4: 26.9-27.0 against 25.7-26.0 ms per step for conv_2 + 3 + 5 -- slower
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
         const bool has_next = nxt < nitems;
         const Item nx = item_of(has_next ? nxt : item, has_next);
 #ifdef DT_S4_TIMING
-        unsigned long long tt_tr = 0, tt_mm = 0, tt_bw = 0, tt_dm = 0;
+        unsigned long long tt_tr = 0, tt_mm = 0, tt_bw = 0, tt_dm = 0, tt_bd = 0, tt_wt = 0;
 #endif
         S4_PUT(1, S4_NOW());
 #pragma unroll
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
                 // stage: odd s -> block image 0 of patch stage (s+3)/2, even s -> block image 1 of patch stage (s+2)/2 (the
                 // stage whose first half went out one stage earlier).  Past this item's patches the numbering continues
                 // into the next item's (npatch is even, so the buffers line up). ----
-                if ((!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9);
+                if (!S4_PATCH_FIRST && (!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9);
                 const int pc_all = (s + 2 + (s & 1)) >> 1;
                 const bool pnx = pc_all >= npatch;
                 if (!(S4_ABLATE & 2)) {
@@ -367,6 +371,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
 #undef S4_SEL
                     patch_half(B, (s & 1) ^ 1, pnx ? pc_all - npatch : pc_all, pc_all & 1, !pnx || has_next);
                 }
+                if (S4_PATCH_FIRST && (!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9);
                 if (S4_PRIO) __builtin_amdgcn_s_setprio(0);
             }
             [[maybe_unused]] const unsigned long long c1 = S4_NOW();
@@ -388,9 +393,11 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
 #endif
             [[maybe_unused]] const unsigned long long c3 = S4_NOW();
             __builtin_amdgcn_s_waitcnt(0x0f70);     // this wave's DMA pieces have landed
+            [[maybe_unused]] const unsigned long long c4 = S4_NOW();
             __syncthreads();
 #ifdef DT_S4_TIMING
-            tt_bw += S4_NOW() - c3;
+            if (dset) { tt_bw += c4 - c3; tt_bd += S4_NOW() - c4; }
+            else tt_wt += S4_NOW() - c3;
 #endif
         }
         S4_PUT(2, S4_NOW());
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
             }
         }
 #ifdef DT_S4_TIMING
-        S4_PUT(3, S4_NOW()); S4_PUT(4, tt_tr); S4_PUT(5, tt_mm); S4_PUT(6, tt_bw); S4_PUT(7, tt_dm);
+        S4_PUT(3, S4_NOW()); S4_PUT(4, tt_tr); S4_PUT(5, tt_mm); S4_PUT(6, tt_bw); S4_PUT(7, tt_dm); S4_PUT(8, tt_bd); S4_PUT(9, tt_wt);
         ++tt_i;
         S4_PUT(0, S4_NOW());
 #endif

@@ -105,7 +105,7 @@ _SETUP = {}
 # at 9 clips (1,470 / 147 rows) and 4 clips of 608x608 (1,400 / 100 rows) the DEFAULT thresholds keep them on the
 # fp32 MFMA kernel.  Lowering the two row thresholds selects exactly the bench's kernels for every launch.
 BENCH_SELECTION = {"DT_S3_MINROWS": "1024", "DT_S3_REC_MINROWS": "64"}
-S3_BENCH_LAUNCHES = ["conv_gemm_s3:conv_9", "conv_gemm_s3:conv_10", "conv_gemm_s3:conv_11", "conv_gemm_s3:conv_12", "conv_gemm_s3:conv_13",
+S3_BENCH_LAUNCHES = ["conv_gemm_s3:conv_6", "conv_gemm_s3:conv_8", "conv_gemm_s3:conv_9", "conv_gemm_s3:conv_10", "conv_gemm_s3:conv_11", "conv_gemm_s3:conv_12", "conv_gemm_s3:conv_13",
                      "conv_gemm_s3:conv_14", "conv_gemm_s3:conv_15", "conv_gemm_s3:conv_16", "conv_gemm_s3:conv_17", "conv_gemm_s3:conv_18",
                      "conv_gemm_s3:conv_19", "conv_gemm_s3:conv_20", "conv_gemm_s3:conv_22", "conv_gemm_s3:convlstm_xproj",
                      "conv_gemm_s3:convlstm_step"]
@@ -395,7 +395,7 @@ def test_configs2_bench_size_48_clips_vs_oracle():
     ctx.profile_enable(False)
     names = set(ctx.profile_names())
     for want in S3_BENCH_LAUNCHES + ["conv_fused:conv_2", "conv_fused:conv_3", "conv_fused:conv_5", "s3_tile:128x2", "s3_tile:256",
-                                     "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4", "conv_igemm:conv_6", "conv_igemm:conv_8"]:
+                                     "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4", "conv_igemm:conv_4", "conv_igemm:conv_7"]:
         assert want in names, "%s did not run; ran: %s" % (want, sorted(n for n in names if ":" in n))
     assert ctx.profile_read("conv_gemm_s3:convlstm_step")["launches"] == T - 1
     assert ctx.profile_read("s3_tile:128x2")["launches"] == T - 1      # the recurrent step only (588 rows = 5 x 128)

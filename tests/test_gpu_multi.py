@@ -108,25 +108,32 @@ out = track_clips_frame_sharded(trk, frames)
 ref = trk.track_clips(frames)
 # the two halves run the layers at other batch sizes than the one-process forward (split-K / Winograd choice): values
 # agree to rounding, everything discrete -- counts, cells, labels, track ids -- is exact
-ok = (torch.equal(out["counts"], ref["counts"]) and torch.equal(out["boxes"][..., 5], ref["boxes"][..., 5])
-      and torch.equal(out["boxes"][..., 7], ref["boxes"][..., 7])
-      and torch.allclose(out["boxes"], ref["boxes"], rtol=1e-4, atol=1e-5)
-      and torch.equal(out["ids"], ref["ids"]) and torch.equal(out["gids"], global_track_ids(ref["ids"], ref["nids"]))
-      and int(ref["counts"].sum()) > 0)
+flags = dict(counts=torch.equal(out["counts"], ref["counts"]), labels=torch.equal(out["boxes"][..., 5], ref["boxes"][..., 5]),
+             cells=torch.equal(out["boxes"][..., 7], ref["boxes"][..., 7]),
+             boxes=bool(torch.allclose(out["boxes"], ref["boxes"], rtol=1e-3, atol=1e-4)),      # 7-8-frame detector batches take other kernels than the 15-frame one
+             ids=torch.equal(out["ids"], ref["ids"]), gids=torch.equal(out["gids"], global_track_ids(ref["ids"], ref["nids"])),
+             nonempty=int(ref["counts"].sum()) > 0)
+flags["box_err"] = float((out["boxes"] - ref["boxes"]).abs().max())
 # and the halves compose to the whole: detect + recurrent == forward, bit for bit at equal batch
 ctx = trk.model.ctx
 d = trk.detector.model.to_device(frames)
 z = ctx.track_detect(d.reshape(N * T, H, W, 3))
 halves = ctx.track_recurrent(z.reshape(N, T, 3, 3, -1))
-ok &= torch.equal(halves, ctx.track_forward(d, want_det=False))
+whole = ctx.track_forward(d, want_det=False)
+flags["halves_z"] = torch.equal(halves, whole)
+flags["halves_z_err"] = float((halves - whole).abs().max())
+flags["deterministic"] = torch.equal(whole, ctx.track_forward(d, want_det=False))
 # ... and so does the split one step later (input projection on the detector's side), which is what the frame-shard ships by default
 xp = ctx.track_detect_xproj(d.reshape(N * T, H, W, 3))
-ok &= xp.shape[-1] == ctx.track_xproj_width() == 4 * 512
-ok &= torch.equal(ctx.track_recurrent_xproj(xp.reshape(N, T, 3, 3, -1)), ctx.track_forward(d, want_det=False))
+flags["xp_width"] = xp.shape[-1] == ctx.track_xproj_width() == 4 * 512
+hx = ctx.track_recurrent_xproj(xp.reshape(N, T, 3, 3, -1))
+flags["halves_xproj"] = torch.equal(hx, whole)
+flags["halves_xproj_err"] = float((hx - whole).abs().max())
 # both row kinds give the single-process ids
 out_z = track_clips_frame_sharded(trk, frames, rows="z")
-ok &= torch.equal(out_z["ids"], ref["ids"]) and torch.equal(out_z["counts"], ref["counts"])
-print("RANK", rank, "OK" if ok else "MISMATCH", int(ref["counts"].sum()), flush=True)
+flags["rows_z"] = torch.equal(out_z["ids"], ref["ids"]) and torch.equal(out_z["counts"], ref["counts"])
+ok = all(v for k, v in flags.items() if not k.endswith("err"))
+print("RANK", rank, "OK" if ok else "MISMATCH", int(ref["counts"].sum()), flags, flush=True)
 dist.barrier(); dist.destroy_process_group()
 sys.exit(0 if ok else 1)
 '''

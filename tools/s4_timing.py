@@ -30,7 +30,7 @@ ctx.profile_reset(); ctx.profile_enable(True)
 ctx.conv2d(x, w, b, leaky_slope=0.1, pool=pool)
 ctx.profile_enable(False)
 ms = ctx.profile_read("conv_fused")["ms"]
-WG, NI, NS = 64, 8, 8
+WG, NI, NS = 64, 8, 10
 buf = np.zeros(WG * 8 * NI * NS, dtype=np.uint64)
 assert lib.dt_debug_s4_times(buf.ctypes.data_as(ctypes.c_void_p), 0) == 0
 t = buf.reshape(WG, 8, NI, NS).astype(np.int64)
@@ -46,11 +46,12 @@ print("  item total %7.0f cycles | prologue %6.0f | loop %7.0f (per stage %5.0f)
     m(tt[..., 3] - tt[..., 0]), m(tt[..., 1] - tt[..., 0]), m(tt[..., 2] - tt[..., 1]), m(tt[..., 2] - tt[..., 1]) / nst,
     m(tt[..., 3] - tt[..., 2]),
     float((t[:, :, 2:, 0] - t[:, :, 1:-1, 3])[(t[:, :, 2:, 0] > 0) & (t[:, :, 1:-1, 3] > 0)].mean())))
-print("  per stage (mean over waves): dma issue %5.0f | transform %5.0f | mfma block %5.0f | vmcnt+barrier %5.0f" % (
-    m(tt[..., 7]) / nst, m(tt[..., 4]) / nst, m(tt[..., 5]) / nst, m(tt[..., 6]) / nst))
+print("  per stage (mean over waves; a wave is in each role every other stage): dma issue %5.0f | transform %5.0f | mfma block %5.0f | data-movement stages: vmcnt wait %5.0f, barrier wait %5.0f | transform stages: vmcnt + barrier wait %5.0f" % (
+    m(tt[..., 7]) / nst, m(tt[..., 4]) / nst, m(tt[..., 5]) / nst, m(tt[..., 6]) / nst, m(tt[..., 8]) / nst, m(tt[..., 9]) / nst))
 for wv in range(8):
     sel = tt[:, wv]
     o = sel[..., 0] > 0
-    print("    wave %d: dma %5.0f transform %5.0f mfma %5.0f wait %5.0f | prologue %6.0f epilogue %6.0f" % (
+    print("    wave %d: dma %5.0f transform %5.0f mfma %5.0f | dm stages: vmcnt %5.0f barrier %5.0f | tr stages: wait %5.0f | prologue %6.0f epilogue %6.0f" % (
         wv, sel[..., 7][o].mean() / nst, sel[..., 4][o].mean() / nst, sel[..., 5][o].mean() / nst, sel[..., 6][o].mean() / nst,
+        sel[..., 8][o].mean() / nst, sel[..., 9][o].mean() / nst,
         (sel[..., 1] - sel[..., 0])[o].mean(), (sel[..., 3] - sel[..., 2])[o].mean()))
