@@ -72,13 +72,13 @@ def main():
     out["per_kernel_bytes_per_step"] = {k: {"fetch": a, "write": b} for k, (a, b) in sorted(by.items())}
     # per kernel FAMILY of bench.py's roofline.families (each family's own launches only)
     fams = {"wino_gemm_s3": ("wino_gemm_s3",), "conv_igemm_f32": ("conv_igemm_f32",), "wino4s_fused": ("wino4s_fused",),
-            "conv1_mfma": ("conv1_mfma",), "wino_transforms": ("wino_input", "wino_output")}
+            "conv1_mfma": ("conv1_mfma", "conv1_s3"), "wino_transforms": ("wino_input", "wino_output")}
     out["family_bytes_per_step"] = {
         f: (sum(v for _, k, v in fetch if any(t in k for t in pats)) * f_read + sum(v for _, k, v in write if any(t in k for t in pats)) * f_write) * 1024.0 / passes
         for f, pats in fams.items()}
     out["family_launches_per_step"] = {f: sum(1 for _, k, _v in fetch if any(t in k for t in pats)) / passes for f, pats in fams.items()}
-    out["conv1_bytes_per_step"] = {"fetch": sum(v for _, k, v in fetch if "conv1_mfma" in k) * 1024.0 * f_read / passes,
-                                   "write": sum(v for _, k, v in write if "conv1_mfma" in k) * 1024.0 * f_write / passes}
+    out["conv1_bytes_per_step"] = {"fetch": sum(v for _, k, v in fetch if "conv1_" in k) * 1024.0 * f_read / passes,
+                                   "write": sum(v for _, k, v in write if "conv1_" in k) * 1024.0 * f_write / passes}
     json.dump(out, sys.stdout, indent=1)
     print()
 
