@@ -18,8 +18,10 @@
 //     next item's V(0) -- only the first item of a workgroup pays a prologue;
 //   * two wave sets swap roles every stage: one issues the stage's data movement and then its MFMAs, the other its MFMAs
 //     and then the input transform of the next stage -- on every SIMD one wave feeds the matrix pipe while its partner does
-//     the side work (issuing the side work BETWEEN the MFMA quads of every wave was measured slower, and so was moving 2-4 of a
-//     wave's 9 U pieces per stage to the transform set to balance the two roles: profiles/HISTORY.md, profiles/r04_experiments.txt).
+//     the side work.  Measured slower, each of them: the side work issued BETWEEN the MFMA quads of every wave; 2-6 of a wave's 9 U
+//     pieces per stage moved to the transform set (at the start of its stage, between its MFMA block and its transform, or in its
+//     ~1700 cycles of barrier slack after the transform); the patch pieces ahead of the U pieces; the transform's window reads ahead
+//     of the MFMA block (profiles/HISTORY.md, profiles/r04_experiments.txt, profiles/r04_s4_timing.txt).
 //
 // Workgroup = 8 waves = 2 blocks (4x4 tiles of 4x4 pixels each) x 4 column groups of 16 channels; v_mfma_f32_16x16x4_f32
 // (row = tile, column = channel, k = input channel).  K runs in stages of 4 input channels (one MFMA k-step), one
@@ -146,15 +148,6 @@ __device__ __forceinline__ void s4_transform_half(const float (&w5)[5][6], float
 #define S4_PATCH_FIRST 0    // 1: the data-movement set issues its three patch pieces (HBM: the longest latency) BEFORE its nine U pieces (L2 hits).
 #endif                      // Measured in round 4: 30.0 against 26.3 ms per step for conv_2 + 3 + 5 (and the vmcnt wait it was meant to shorten
                             // is 50-70 cycles per stage: the pieces have long landed when a wave reaches its end-of-stage wait)
-#ifndef S4_USPLIT_AT
-#define S4_USPLIT_AT 0      // where the transform set issues its U pieces: 0 after its input transform, 1 between its MFMA block and the transform
-#endif
-#ifndef S4_USPLIT
-#define S4_USPLIT 4         // of a wave slot's 9 U pieces per stage, the last S4_USPLIT are issued by the TRANSFORM set, AFTER its input transform: per
-#endif                      // stage a data-movement wave is busy 2096 + 1457 cycles, a transform wave 1457 + 1086 and then waits ~1700 at the barrier
-                            // (tools/s4_timing.py, profiles/r04_s4_timing.txt); pieces issued in that slack land long before the next stage and do
-                            // not meet the data-movement set's burst at the start of the stage (issued THERE they cost more than they saved: the
-                            // first S4_USPLIT experiment of round 4)
 #ifndef S4_TLOAD_EARLY
 #define S4_TLOAD_EARLY 0    // 1: the transforming set requests its 30 window values BEFORE its MFMA block and computes after it (the LDS round
 #endif                      // trip under the MFMAs).  Measured in round 4: 26.9-27.0 against 25.7-26.0 ms per step for conv_2 + 3 + 5 -- slower
@@ -370,7 +363,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
                 // stage: odd s -> block image 0 of patch stage (s+3)/2, even s -> block image 1 of patch stage (s+2)/2 (the
                 // stage whose first half went out one stage earlier).  Past this item's patches the numbering continues
                 // into the next item's (npatch is even, so the buffers line up). ----
-                if (!S4_PATCH_FIRST && (!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9 - S4_USPLIT);
+                if (!S4_PATCH_FIRST && (!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9);
                 const int pc_all = (s + 2 + (s & 1)) >> 1;
                 const bool pnx = pc_all >= npatch;
                 if (!(S4_ABLATE & 2)) {
@@ -381,7 +374,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
 #undef S4_SEL
                     patch_half(B, (s & 1) ^ 1, pnx ? pc_all - npatch : pc_all, pc_all & 1, !pnx || has_next);
                 }
-                if (S4_PATCH_FIRST && (!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9 - S4_USPLIT);
+                if (S4_PATCH_FIRST && (!last || has_next) && !(S4_ABLATE & 1)) u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 0, 9);
                 if (S4_PRIO) __builtin_amdgcn_s_setprio(0);
             }
             [[maybe_unused]] const unsigned long long c1 = S4_NOW();
@@ -392,16 +385,12 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
             if (S4_TLOAD_EARLY && do_tr) transform_load((s1 >> 1) & 1, s1 & 1);
             mfma_block(s & 1);
             [[maybe_unused]] const unsigned long long c2 = S4_NOW();
-            if (S4_USPLIT > 0 && S4_USPLIT_AT == 1 && !dset && (!last || has_next) && !(S4_ABLATE & 1))
-                u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 9 - S4_USPLIT, 9);
             if (do_tr) {
                 if (S4_PRIO) __builtin_amdgcn_s_setprio(2);
                 if (!S4_TLOAD_EARLY) transform_load((s1 >> 1) & 1, s1 & 1);
                 transform_compute(s1 & 1);
                 if (S4_PRIO) __builtin_amdgcn_s_setprio(0);
             }
-            if (S4_USPLIT > 0 && S4_USPLIT_AT == 0 && !dset && (!last || has_next) && !(S4_ABLATE & 1))      // the transform set's share of U(s + 1), in its slack
-                u_pieces(last ? nx.u : cur.u + (long long)(s + 1) * S4_UBUF, (s + 1) & 1, 9 - S4_USPLIT, 9);
 #ifdef DT_S4_TIMING
             tt_dm += c1 - c0; tt_mm += c2 - c1; tt_tr += S4_NOW() - c2;
 #endif
