@@ -186,6 +186,15 @@ __device__ __forceinline__ void s3_split4(const VecOf<4>::T x, wino_u2 t[3])
     t[0] = __builtin_bit_cast(wino_u2, h); t[1] = __builtin_bit_cast(wino_u2, m); t[2] = __builtin_bit_cast(wino_u2, l);
 }
 
+#ifndef WINO_S3_NT
+#define WINO_S3_NT 1      // bit 0: the V terms of the input transforms, bit 1: the split rows of the output transforms, as nontemporal stores.
+#endif                    // Measured (profiles/r04_experiments.txt): V terms 11.6 -> 11.1 ms per step, split rows 14.6 -> 15.0-15.4 (the 1x1 GEMM
+                          // behind reads the rows at once: they want to stay in L2) -> default: V terms only
+template <int BIT, typename T> __device__ __forceinline__ void s3_store(unsigned short *p, const T &v)
+{
+    if (WINO_S3_NT & BIT) __builtin_nontemporal_store(v, reinterpret_cast<T *>(p));
+    else *reinterpret_cast<T *>(p) = v;
+}
 typedef __bf16 wino_bf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void s3_split2(const VecOf<2>::T x, unsigned t[3])
 {
@@ -258,7 +267,7 @@ template <int TS, int V, bool S3 = false> __global__ __launch_bounds__(WINO_THRE
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) *reinterpret_cast<wino_u2 *>(dst + ((long long)(NI * i + j) * 3 + k) * term) = tr[j][k];
+                    for (int k = 0; k < 3; ++k) s3_store<1>(dst + ((long long)(NI * i + j) * 3 + k) * term, tr[j][k]);
             }
         } else if constexpr (S3 && V == 2) {
             const long long term = (long long)(p.C >> 4) * p.Mp * 16;
@@ -273,7 +282,7 @@ template <int TS, int V, bool S3 = false> __global__ __launch_bounds__(WINO_THRE
                 for (int j = 0; j < NI; ++j)
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
-                        __builtin_nontemporal_store(tr[j][k], reinterpret_cast<unsigned *>(dst + ((long long)(NI * i + j) * 3 + k) * term));
+                        s3_store<1>(dst + ((long long)(NI * i + j) * 3 + k) * term, tr[j][k]);
             }
         } else {
             float *dst = p.v + (long long)tile * p.C + c;
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_input_coop6_kernel(WinoArgs
             for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                    *reinterpret_cast<wino_u2 *>(dst + ((long long)(8 * sub + j) * 3 + k) * term) = tr[j][k];
+                    s3_store<1>(dst + ((long long)(8 * sub + j) * 3 + k) * term, tr[j][k]);
         } else if (live) {
             float *dst = p.v + (long long)tile * p.C + c;
 #pragma unroll
@@ -625,7 +634,7 @@ if constexpr (ONE) {      // one LDS image, the two channel halves one after the
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) *reinterpret_cast<wino_u4 *>(dst + ((long long)(NI * sub + j) * 3 + k) * term) = o[j][k];
+                for (int k = 0; k < 3; ++k) s3_store<1>(dst + ((long long)(NI * sub + j) * 3 + k) * term, o[j][k]);
         }
         if constexpr (ONE) wino_item_sync(); else __syncthreads();
     }
@@ -690,7 +699,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
                     if (live && vpixel(p, t.grp, 6 * t.ty + j, 6 * t.tx + sub, b, h, w)) {
                         unsigned short *d = p.out_s3 + ((long long)(c >> 4) * p.out_mp + ((long long)b * p.H + h) * p.W + w) * 16 + (c & 15);
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) *reinterpret_cast<wino_u2 *>(d + k * term) = tr[j][k];
+                        for (int k = 0; k < 3; ++k) s3_store<2>(d + k * term, tr[j][k]);
                     }
                 }
             }
@@ -794,7 +803,7 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_output_s3_kernel(WinoA
                 if (live && vpixel(p, t.grp, 6 * t.ty + j, 6 * t.tx + sub, b, h, w)) {
                     unsigned short *d = p.out_s3 + ((long long)(c >> 4) * p.out_mp + ((long long)b * p.H + h) * p.W + w) * 16 + (c & 15);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) *reinterpret_cast<wino_u4 *>(d + k * term) = o[j][k];
+                    for (int k = 0; k < 3; ++k) s3_store<2>(d + k * term, o[j][k]);
                 }
             }
         }

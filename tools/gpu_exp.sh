@@ -1,9 +1,6 @@
 #!/bin/bash
 # scratch experiment runner on the GPU box (via gpurun): edit freely between calls; outputs land in gpurun_out/<tag>/
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-exp}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
-for L in conv_3 conv_2; do echo "== s4 timing $L"; MI355_DT_LIB=$R/tools/_probe_builds/libmi355_dt_s4tt.so timeout 300 python tools/s4_timing.py $L 1440 2>&1 | grep -v "^Native\|amdgpu.ids" | head -12; done
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -k "fused" 2>&1 | tail -3
-for i in 1 2 3; do timeout 600 python -m pytest tests/test_gpu_multi.py -q -k "two_ranks_one_gpu" 2>&1 | grep -E "passed|failed|MISMATCH" | cut -c1-600 | tail -3; done
 run() {   # label, env assignments...
   local label=$1; shift
   env "$@" timeout 600 python bench.py --no-extra --no-cpu-baseline --steps 3 --warmup 1 --layer-report $O/layers_$label.txt 2>$O/bench_$label.err | tail -1 | python -c "
@@ -12,8 +9,6 @@ d=json.loads(sys.stdin.read()); k=d['kernels']
 print('%-10s %8.1f frames/s %7.2f ms | ' % ('$label', d['value'], d['ms_per_step']) + ' '.join('%s %.2f' % (n.replace('conv_','').replace('wino_','w_'), k[n]['ms_per_step']) for n in ('conv1_direct','conv_fused','wino_input','wino_output','conv_gemm_s3','conv_igemm') if n in k))"
 }
 run base X=1
-run usb0 MI355_DT_LIB=$R/tools/_probe_builds/libmi355_dt_usb0.so
-run usb2 MI355_DT_LIB=$R/tools/_probe_builds/libmi355_dt_usb2.so
-run usb6 MI355_DT_LIB=$R/tools/_probe_builds/libmi355_dt_usb6.so
-run usb4m MI355_DT_LIB=$R/tools/_probe_builds/libmi355_dt_usb4m.so
+run nt0 MI355_DT_LIB=$R/tools/_probe_builds/libmi355_dt_nt0.so
 run base2 X=1
+run nt0b MI355_DT_LIB=$R/tools/_probe_builds/libmi355_dt_nt0.so
