@@ -437,7 +437,8 @@ def _run():
     # launches computed -- booked per family by the library (network.hip:prof_direct_form), never across families
     df = {"conv_gemm_s3": ctx.profile_read("conv_direct_form_s3"), "conv_igemm": ctx.profile_read("conv_direct_form"),
           "conv_fused": ctx.profile_read("conv_direct_form_fused"),
-          "conv1_direct": {"flops": conv1["flops"], "bytes": conv1["bytes"]}}      # conv_1 runs in direct form: executed = algorithmic
+          "conv1_direct": ctx.profile_read("conv_direct_form_conv1")}
+    conv1_bf16 = ctx.profile_read("conv1_direct:bf16")["launches"] > 0      # conv1_s3_kernel (default) or the fp32 MFMA kernel (DT_S3_CONV1=0 / DT_S3=0)
     tr = load_traffic(args.clips, args.T, args.size) if args.workload == "track" else None
     fam_traffic = (tr[1].get("family_bytes_per_step") or {}) if tr is not None else {}
 
@@ -468,8 +469,10 @@ def _run():
                                  "v_mfma_f32_32x32x2_f32", PEAK_F32_MFMA_TFLOPS, "conv_igemm_f32"),
         "wino4s_fused": family("conv_fused", fused, "wino4s_fused_kernel (conv_2 / conv_3 / conv_5: fused F(4x4,3x3))", "v_mfma_f32_16x16x4_f32",
                                PEAK_F32_MFMA_TFLOPS, "wino4s_fused"),
-        "conv1_mfma": family("conv1_direct", conv1, "conv1_mfma_kernel (conv_1 + x/255 + BN + LeakyReLU + 2x2 max)", "v_mfma_f32_32x32x2_f32",
-                             PEAK_F32_MFMA_TFLOPS, "conv1_mfma"),
+        "conv1_mfma": family("conv1_direct", conv1, "conv1_s3_kernel (conv_1 + x/255 + BN + LeakyReLU + 2x2 max; K = 27 padded to 32)" if conv1_bf16 else
+                             "conv1_mfma_kernel (conv_1 + x/255 + BN + LeakyReLU + 2x2 max; K = 27 padded to 28)",
+                             "v_mfma_f32_32x32x16_bf16: uint8 values are exact bf16 numbers, weights / 255 as three bf16 terms, three per multiply-add" if conv1_bf16
+                             else "v_mfma_f32_32x32x2_f32", PEAK_BF16_MFMA_TFLOPS if conv1_bf16 else PEAK_F32_MFMA_TFLOPS, "conv1_mfma"),
     }
     if families["wino_gemm_s3"]:
         families["wino_gemm_s3"]["fp32_equivalent_tflops"] = families["wino_gemm_s3"]["achieved"] / 6.0
@@ -486,8 +489,9 @@ def _run():
     # whole conv path: time the matrix pipe would need AT ITS PEAKS for everything the conv kernels execute (bf16 and fp32
     # instructions have different peaks) / the time the conv path takes, transforms included
     conv_path_ms = s3["ms"] + ig["ms"] + fused["ms"] + conv1["ms"] + wino_ms
-    conv_path_flops = ig["flops"] + fused["flops"] + conv1["flops"]        # executed on the fp32 MFMA instructions
-    conv_path_pipe_frac = ((s3["flops"] / (PEAK_BF16_MFMA_TFLOPS * 1e12) + conv_path_flops / (PEAK_F32_MFMA_TFLOPS * 1e12)) /
+    conv_path_flops = ig["flops"] + fused["flops"] + (0.0 if conv1_bf16 else conv1["flops"])      # executed on the fp32 MFMA instructions
+    conv_path_bf16 = s3["flops"] + (conv1["flops"] if conv1_bf16 else 0.0)                          # ... on the bf16 instruction
+    conv_path_pipe_frac = ((conv_path_bf16 / (PEAK_BF16_MFMA_TFLOPS * 1e12) + conv_path_flops / (PEAK_F32_MFMA_TFLOPS * 1e12)) /
                            (conv_path_ms * 1e-3)) if conv_path_ms > 0 else None
     direct_form_all = sum(v["flops"] for v in df.values())
     direct_form_bytes_all = sum(v["bytes"] for v in df.values())
@@ -584,8 +588,8 @@ def _run():
                 "families": families, "transforms": transforms,
                 "frac_whole_conv_path": conv_path_pipe_frac,
                 "whole_conv_path": {"executed_fp32_mfma_tflop_per_step": conv_path_flops / steps / 1e12,
-                                    "executed_bf16_mfma_tflop_per_step": s3["flops"] / steps / 1e12,
-                                    "fp32_equivalent_tflops": ((conv_path_flops + s3["flops"] / 6.0) / (conv_path_ms * 1e-3) / 1e12)
+                                    "executed_bf16_mfma_tflop_per_step": conv_path_bf16 / steps / 1e12,
+                                    "fp32_equivalent_tflops": ((conv_path_flops + s3["flops"] / 6.0 + (conv1["flops"] / 3.0 if conv1_bf16 else 0.0)) / (conv_path_ms * 1e-3) / 1e12)
                                     if conv_path_ms > 0 else None,
                                     "ms_per_step": conv_path_ms / steps,
                                     "direct_form_tflop_per_step": direct_form_all / steps / 1e12,

@@ -420,11 +420,11 @@ extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t 
 // under the kernel FAMILY whose launch computed it -- "conv_direct_form" (conv_igemm_f32 launches), "conv_direct_form_s3"
 // (wino_gemm_s3 launches), "conv_direct_form_fused" (the fused Winograd kernel) -- so that bench.py divides each family's
 // algorithmic work by that family's own time and no family is credited with work another kernel did.
-enum { DF_IGEMM = 0, DF_FUSED = 1, DF_S3 = 2 };
+enum { DF_IGEMM = 0, DF_FUSED = 1, DF_S3 = 2, DF_CONV1 = 3 };
 static void prof_direct_form(dt_ctx *ctx, double flops, double bytes, int family = DF_IGEMM)
 {
     if (!ctx->prof) return;
-    ProfEntry &e = ctx->prof_tab[family == DF_FUSED ? "conv_direct_form_fused" : (family == DF_S3 ? "conv_direct_form_s3" : "conv_direct_form")];
+    ProfEntry &e = ctx->prof_tab[family == DF_FUSED ? "conv_direct_form_fused" : (family == DF_S3 ? "conv_direct_form_s3" : (family == DF_CONV1 ? "conv_direct_form_conv1" : "conv_direct_form"))];
     e.flops += flops;
     e.bytes += bytes;   // in + weights + out of the reference's layer, float32
 }
@@ -974,9 +974,12 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
     }
 
     {   // conv_1 + norm_1 + leaky + pool, with x/255 fused
-        ProfScope ps(ctx, "conv1_direct", 2.0 * B * H * W * 27.0 * 32.0,
-                     (double)B * H * W * 3.0 * (dtype == DT_FRAMES_U8 ? 1 : 4) + 4.0 * B * (H / 2) * (W / 2) * 32.0);
         const bool c1s3 = ctx->pol.s3 != 0 && ctx->pol.s3_conv1 != 0;
+        const double c1_bytes = (double)B * H * W * 3.0 * (dtype == DT_FRAMES_U8 ? 1 : 4) + 4.0 * B * (H / 2) * (W / 2) * 32.0;
+        // EXECUTED MFMA FLOPs: K = 27 padded to 32 (bf16: 3 partial products per multiply for uint8 frames, 6 for float32 frames) or to 28 (fp32 MFMA)
+        const double c1_exec = c1s3 ? (dtype == DT_FRAMES_U8 ? 3.0 : 6.0) * 2.0 * B * H * W * 32.0 * 32.0 : 2.0 * B * H * W * 28.0 * 32.0;
+        ProfScope ps(ctx, "conv1_direct", c1_exec, c1_bytes, c1s3 ? "bf16" : "f32");
+        prof_direct_form(ctx, 2.0 * B * H * W * 27.0 * 32.0, c1_bytes, DF_CONV1);
         if (launch_conv1_direct(ctx->stream, frames, dtype, B, H, W, ctx->conv1_w, ctx->conv1_b, ctx->lut255, LEAKY,
                                 bufA, c1s3 ? ctx->conv1_w3 : nullptr, c1s3 ? ctx->conv1_w3u8 : nullptr))
             return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");

@@ -35,7 +35,7 @@ fi
 # the split-bf16 GEMM on its own: rate, error against float64, effective clock with / without the LDS fragment reads and the DMA
 if [ -x $R/tools/micro/gemm_s3_bench ]; then
   (cd $R && timeout 300 tools/micro/gemm_s3_bench > $O/gemm_s3_micro.txt 2>&1; cat $O/gemm_s3_micro.txt | cut -c1-170)
-  (bash $R/tools/s3_clock.sh - _a1 _a2 _a3 > $O/gemm_s3_clock.txt 2>&1; cat $O/gemm_s3_clock.txt)
+  (bash $R/tools/s3_clock.sh - _a1 _a2 _a3 -zero -const > $O/gemm_s3_clock.txt 2>&1; cat $O/gemm_s3_clock.txt)
 fi
 # keep the merged payload small: drop raw per-dispatch CSVs above 20 MB
 find $O -name "*.csv" -size +20M -delete
