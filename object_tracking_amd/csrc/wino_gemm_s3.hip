@@ -292,7 +292,8 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                     if (iss_go) { buf_issue = buf_issue == NS - 1 ? 0 : buf_issue + 1; ++n_ahead; }
                 }
                 // The group's other MFMAs -- six partial products per block, smallest first, consecutive MFMAs to DIFFERENT
-                // accumulators -- with the side work placed between them in source order and frozen there (sched_barrier): one
+                // accumulators (block by block in runs that share the V fragment measured the same: the kernel's clock does not care
+                // which operand repeats, profiles/r04_experiments.txt) -- with the side work placed between them in source order and frozen there (sched_barrier): one
                 // LDS fragment read or one DMA piece per MFMA slot, so that the issuing wave never leaves the pipe idle for
                 // longer than one instruction (it matters when the wave has the SIMD to itself, NW = 4).
                 //   side work: next group's U fragments (3 reads; last group: the next stage's V and first U fragments,
