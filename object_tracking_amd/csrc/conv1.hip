@@ -172,6 +172,20 @@ __device__ __forceinline__ float c1_bf16_f32(unsigned short h) { return __uint_a
 // moves one float32 rounding from the activation to the weight (each product still carries exactly one rounding of 2^-24):
 // fp32 accuracy, not the same bits as the float32-frame path (tests: both within 5e-6 of the oracle, 2e-6 of each other).
 // U8 = false (float32 frames, already normalised): arbitrary values, the general three-term form with six products.
+#ifndef C1_PF
+#define C1_PF 2              // tiles of frame loads in flight ahead of the tile being computed (1 or 2)
+#endif
+#ifndef C1_LDS_BARRIER
+#define C1_LDS_BARRIER 1     // 0: __syncthreads() (round 3's form) for A/B
+#endif
+#if C1_LDS_BARRIER
+#define C1_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define C1_SYNC() __syncthreads()
+#endif
+#ifndef C1_ABLATE
+#define C1_ABLATE 0          // timing-only builds (results WRONG): 1 no output stores, 2 no frame loads, 4 no fragment reads + MFMAs, 8 no staging
+#endif
 template <bool U8>
 __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
 {
@@ -186,53 +200,74 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
     const int bx_last = min(bx_first + p.tpw, ntx);
     const int cy0 = by * 16 - 1;                      // patch origin row in input pixels
 
-    // patch pixels of this thread: i0 = tid, i1 = tid + 256 (< 324 for tid < 68)
-    const int r0 = tid / 18, c0 = tid - r0 * 18;
+    // ---- staging.  Every load is UNCONDITIONAL (the address is selected, not the load): a load inside a lane-divergent branch is
+    // followed by vmcnt(0) at the join, which serialises the tile's loads and drains the stores in flight (round 3's form: 2.6 of
+    // the layer's 4.4 ms).
+    // uint8 frames (W % 4 == 0: every frame row starts on a dword): the 18 x 54-byte patch rows are read as 14 aligned dwords per row,
+    // bytes 48 bx - 4 .. 48 bx + 51 of the row -- ONE dword per thread (252 of 256) instead of six byte loads; its four bytes are patch
+    // elements e = 4 d - 1 + i (pixel e / 3, channel e % 3; e = -1 and 54 fall outside and go to a pad slot).  A dword lies
+    // entirely inside or outside its row, and outside means zero padding.
+    // float32 frames: pixel tid and tid + 256 of the patch, three values each.
+    struct Raw { unsigned dw; float v[2][3]; };
+    const int r0 = U8 ? tid / 14 : tid / 18, c0 = U8 ? tid - r0 * 14 : tid - r0 * 18;
     const int i1 = tid + 256, r1 = i1 / 18, c1 = i1 - r1 * 18;
-    const bool has1 = i1 < 18 * 18;
+    const bool has1 = !U8 && i1 < 18 * 18;
     const int y0 = cy0 + r0, y1 = cy0 + r1;
-    const bool yok0 = y0 >= 0 && y0 < p.H, yok1 = has1 && y1 >= 0 && y1 < p.H;
+    const bool yok0 = (!U8 || tid < 252) && y0 >= 0 && y0 < p.H, yok1 = has1 && y1 >= 0 && y1 < p.H;
     const long long row0 = ((long long)b * p.H + y0) * p.W, row1 = ((long long)b * p.H + y1) * p.W;
-    float raw[2][3];      // the values as floats (u8 frames: the byte value, converted exactly)
-    auto fetch = [&](int bx) {
-        const int x0 = bx * 16 - 1 + c0, x1 = bx * 16 - 1 + c1;
-        const bool ok0 = yok0 && x0 >= 0 && x0 < p.W, ok1 = yok1 && x1 >= 0 && x1 < p.W;
-        if (U8) {
-            const unsigned char *f = reinterpret_cast<const unsigned char *>(p.frames);
+    int poff[4];          // uint8: plane slot of byte i of this thread's dword
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                raw[0][c] = ok0 ? (float)f[(row0 + x0) * 3 + c] : 0.0f;
-                raw[1][c] = ok1 ? (float)f[(row1 + x1) * 3 + c] : 0.0f;
-            }
+    for (int i = 0; i < 4; ++i) {
+        const int e = 4 * c0 - 1 + i;
+        poff[i] = (U8 && tid < 252 && e >= 0 && e < 54) ? (e % 3) * C1_PL + r0 * 18 + e / 3 : C1_PL - 1;
+    }
+    auto fetch = [&](int bx, Raw &raw) {
+        if (C1_ABLATE & 2) {
+            raw.dw = 0x01020304u * (unsigned)(bx + 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { raw.v[0][c] = (float)(bx + c); raw.v[1][c] = (float)(bx - c); }
+            return;
+        }
+        if (U8) {
+            // an out-of-image dword is read from the zero words behind the weight table: no select after the load (it would wait for it)
+            const int xb = 48 * bx - 4 + 4 * c0;
+            const bool ok = yok0 && xb >= 0 && xb < 3 * p.W;
+            const unsigned *src = ok ? reinterpret_cast<const unsigned *>(p.frames) + ((row0 * 3 + xb) >> 2) : p.w3u8 + 1536;
+            raw.dw = *src;
         } else {
-            const float *f = reinterpret_cast<const float *>(p.frames);
+            const int x0 = bx * 16 - 1 + c0, x1 = bx * 16 - 1 + c1;
+            const bool ok0 = yok0 && x0 >= 0 && x0 < p.W, ok1 = yok1 && x1 >= 0 && x1 < p.W;
+            const float *zero = reinterpret_cast<const float *>(p.w3 + 1536);
+            const float *f0 = ok0 ? reinterpret_cast<const float *>(p.frames) + (row0 + x0) * 3 : zero;
+            const float *f1 = ok1 ? reinterpret_cast<const float *>(p.frames) + (row1 + x1) * 3 : zero;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { raw.v[0][c] = f0[c]; raw.v[1][c] = f1[c]; }
+        }
+    };
+    auto stage = [&](const Raw &raw) {
+        if (C1_ABLATE & 8) { if (raw.dw == 0x12345u && raw.v[0][0] == -1.0f) s_pl[tid] = 1; return; }
+        if (U8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)      // 0..255 has at most 8 significant bits: the float's high half is the exact bf16
+                s_pl[poff[i]] = (unsigned short)(__float_as_uint((float)((raw.dw >> (8 * i)) & 255u)) >> 16);
+        } else {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                raw[0][c] = ok0 ? f[(row0 + x0) * 3 + c] : 0.0f;
-                raw[1][c] = ok1 ? f[(row1 + x1) * 3 + c] : 0.0f;
-            }
-        }
-    };
-    auto terms_of = [&](float v, unsigned short t[NT]) {
-        if (U8) {
-            t[0] = (unsigned short)(__float_as_uint(v) >> 16);      // 0..255 has at most 8 significant bits: exact
-        } else {              // three roundings to nearest even (host twin: wino_s3_split_host)
-            t[0] = c1_bf16_rne(v);
-            const float r1 = v - c1_bf16_f32(t[0]);
-            t[1 % NT] = c1_bf16_rne(r1);
-            t[2 % NT] = c1_bf16_rne(r1 - c1_bf16_f32(t[1 % NT]));
-        }
-    };
-    auto stage = [&]() {
+                unsigned short t0[3], t1[3];       // three roundings to nearest even (host twin: wino_s3_split_host)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            unsigned short t0[NT], t1[NT];
-            terms_of(raw[0][c], t0);
-            terms_of(raw[1][c], t1);
+                for (int q = 0; q < 2; ++q) {
+                    unsigned short *t = q ? t1 : t0;
+                    const float v = raw.v[q][c];
+                    t[0] = c1_bf16_rne(v);
+                    const float d1 = v - c1_bf16_f32(t[0]);
+                    t[1] = c1_bf16_rne(d1);
+                    t[2] = c1_bf16_rne(d1 - c1_bf16_f32(t[1]));
+                }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                s_pl[(3 * t + c) * C1_PL + tid] = t0[t];
-                if (has1) s_pl[(3 * t + c) * C1_PL + i1] = t1[t];
+                for (int t = 0; t < NT; ++t) {
+                    s_pl[(3 * t + c) * C1_PL + tid] = t0[t];
+                    if (has1) s_pl[(3 * t + c) * C1_PL + i1] = t1[t];
+                }
             }
         }
     };
@@ -257,12 +292,22 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
         for (int t = 0; t < 3; ++t)
             bw[kb][t] = __builtin_bit_cast(c1_bf8, reinterpret_cast<const c1_u4 *>(U8 ? p.w3u8 : p.w3)[(kb * 3 + t) * 64 + lane]);
     const float bias = p.bias[n];
+    // Retire these loads HERE, on the straight path: consumed first inside the lane-divergent store branches of the loop, the bias
+    // gets a vmcnt(0) in front of every use -- which waits for every store issued so far, one store at a time.
+    asm volatile("" ::"v"(bias));
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) asm volatile("" ::"v"(bw[kb][t]));
 
-    fetch(bx_first);
-    for (int bx = bx_first; bx < bx_last; ++bx) {
-        stage();
-        __syncthreads();
-        if (bx + 1 < bx_last) fetch(bx + 1);                    // in flight under the MFMAs below
+    // One tile: planes -> LDS, barrier, the tile C1_PF ahead requested into the register set just freed, MFMAs + epilogue, barrier.
+    // The barriers order LDS traffic only (C1_SYNC: lgkmcnt(0) + s_barrier): __syncthreads() also drains vmcnt, i.e. waits at
+    // EVERY tile for the frame loads just issued and for the write acknowledgements of the tile's stores -- measured (round 4,
+    // tools/c1_time.py ablations): 4.47 ms with, against 1.9 ms without the loads and 1.5 ms of compute alone.
+    auto tile = [&](int bx, Raw &raw) {
+        stage(raw);
+        C1_SYNC();
+        if (bx + C1_PF < bx_last) fetch(bx + C1_PF, raw);       // in flight across the next C1_PF tiles
         {
             // pooled rows g = 2 wave, 2 wave + 1 of the tile (gi = 0, 1: +36 elements), one after the other: the second group's
             // fragment reads are in flight under the first group's MFMAs, and only one group's fragments are live
@@ -276,7 +321,7 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
                     for (int t = 0; t < NT; ++t) {
                         c1_us8 v;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = s_pl[3 * t * C1_PL + aoff[kb][e] + 36 * gi];
+                        for (int e = 0; e < 8; ++e) v[e] = (C1_ABLATE & 4) ? (unsigned short)(0x3f80 + e + gi) : s_pl[3 * t * C1_PL + aoff[kb][e] + 36 * gi];
                         a[kb][t] = __builtin_bit_cast(c1_bf8, v);
                     }
 #pragma unroll
@@ -286,7 +331,8 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
 #define C1_MM(ta, tb)                                                                                                  \
                 acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][ta], bw[0][tb], acc[gi], 0, 0, 0);               \
                 acc[gi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][ta], bw[1][tb], acc[gi], 0, 0, 0);
-                if (U8) { C1_MM(0, 2) C1_MM(0, 1) C1_MM(0, 0) }
+                if (C1_ABLATE & 4) { acc[gi][0] = bias * (float)(bx + gi); }
+                else if (U8) { C1_MM(0, 2) C1_MM(0, 1) C1_MM(0, 0) }
                 else { C1_MM(2 % NT, 0) C1_MM(1 % NT, 1) C1_MM(0, 2) C1_MM(1 % NT, 0) C1_MM(0, 1) C1_MM(0, 0) }
 #undef C1_MM
             }
@@ -300,11 +346,19 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
                     const float mx = fmaxf(fmaxf(acc[gi][4 * j], acc[gi][4 * j + 1]), fmaxf(acc[gi][4 * j + 2], acc[gi][4 * j + 3])) + bias;
                     const float v = mx > 0.0f ? mx : mx * p.slope;
                     const int ox = bx * 8 + h + 2 * j;
-                    if (oy < H2 && ox < W2) p.out[(((long long)b * H2 + oy) * W2 + ox) * 32 + n] = v;
+                    if ((C1_ABLATE & 1) ? v == 12345.678f : (oy < H2 && ox < W2)) p.out[(((long long)b * H2 + oy) * W2 + ox) * 32 + n] = v;
                 }
             }
         }
-        __syncthreads();                                        // every wave is done reading the planes
+        C1_SYNC();                                              // every wave is done reading the planes
+    };
+    Raw rawA, rawB;
+    fetch(bx_first, rawA);
+    if (C1_PF == 2 && bx_first + 1 < bx_last) fetch(bx_first + 1, rawB);
+#pragma unroll 1
+    for (int bx = bx_first; bx < bx_last; bx += C1_PF) {
+        tile(bx, rawA);
+        if (C1_PF == 2 && bx + 1 < bx_last) tile(bx + 1, rawB);
     }
 }
 

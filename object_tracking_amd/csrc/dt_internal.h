@@ -192,7 +192,8 @@ int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, in
                         const float *w_packed /*[27][32]*/, const float *bias /*[32]*/,
                         const float *lut /*[256] or null*/, float slope, float *out /*[B,H/2,W/2,32]*/,
                         const unsigned *w3 = nullptr /*[2][3][64][4]*/, const unsigned *w3u8 = nullptr /*weights / 255: both set -> conv1_s3_kernel*/);
-void conv1_split_tables(const float *w /*[27][32]*/, bool scale255, unsigned *w3 /*[1536]*/);
+#define C1_W3_WORDS 1540      // 1536 table words + 16 bytes of zeros: where conv1_s3_kernel points the loads of out-of-image pixels
+void conv1_split_tables(const float *w /*[27][32]*/, bool scale255, unsigned *w3 /*[1536 of C1_W3_WORDS]*/);
 
 int launch_decode(hipStream_t st, const float *netout, long long frame_stride, int batch, int GH, int GW, int NB,
                   int NC, float obj_thr, float nms_thr, const float *anchors_dev, int cap, float *boxes,

@@ -380,7 +380,7 @@ extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t 
             rc = upload(ctx, &ctx->conv1_b, shift);
             if (rc) return rc;
             {   // the same weights as three bf16 terms, plain (float32 frames) and with normalize()'s 1/255 folded in (uint8 frames): conv1_s3_kernel
-                std::vector<unsigned> w3(1536), w3u8(1536);
+                std::vector<unsigned> w3(C1_W3_WORDS, 0u), w3u8(C1_W3_WORDS, 0u);   // 1536 table words + 4 zero words (the kernel's source of padding pixels)
                 conv1_split_tables(w.data(), false, w3.data());
                 conv1_split_tables(w.data(), true, w3u8.data());
                 for (auto pr : {std::make_pair(&ctx->conv1_w3, &w3), std::make_pair(&ctx->conv1_w3u8, &w3u8)}) {
