@@ -693,6 +693,55 @@ __global__ __launch_bounds__(64) void associate_kernel(const float *boxes, const
     int *id = ids + (long long)clip * T * cap;
     int next_id = 0;
     int np = 0;
+    // ---- register form (every frame of the clip has at most 64 boxes, T <= 64: the tracking workloads) ----
+    // Lane j holds box j of the previous and of the current frame and its id in registers; box i reaches the other lanes
+    // through v_readlane, the claim is a lane-select.  No LDS, no fence: the frame loop is the wavefront's own program order.
+    // The next frame's boxes are requested a whole frame ahead (address selected, not the load: lanes >= n re-read box 0), and
+    // a frame's ids are stored one frame late, after the wait for the boxes -- so the loop never waits for a store.
+    const int cnt_l = lane < T ? min(cnt[lane], cap) : 0;
+    if (T <= 64 && !__ballot(cnt_l > 64)) {
+        auto request = [&](int t, float4 &q, float &ql) {
+            const int n = __builtin_amdgcn_readlane(cnt_l, t);
+            const float *src = bx + ((long long)t * cap + (lane < n ? lane : 0)) * DT_BOX_FLOATS;
+            q = *reinterpret_cast<const float4 *>(src);
+            ql = src[5];
+        };
+        float4 nq; float nl;
+        request(0, nq, nl);
+        float pbx = 0.0f, pby = 0.0f, pbw = 0.0f, pbh = 0.0f, pbl = 0.0f;
+        int pidv = -1, outv = -1;
+        for (int t = 0; t < T; ++t) {
+            const int n = __builtin_amdgcn_readlane(cnt_l, t);
+            const float cx = nq.x, cy = nq.y, cw = nq.z, ch = nq.w, cl = nl;        // waits for frame t's boxes
+            if (t + 1 < T) request(t + 1, nq, nl);
+            if (t > 0)
+                for (int j = lane; j < cap; j += 64) id[(t - 1) * cap + j] = j < 64 ? outv : -1;
+            int cid = -1;
+            for (int i = 0; i < n; ++i) {
+                const float ax = readlane_f(cx, i), ay = readlane_f(cy, i), aw = readlane_f(cw, i), ah = readlane_f(ch, i);
+                const float al = readlane_f(cl, i);
+                // largest IoU among the unclaimed same-label boxes of the previous frame, ties -> lowest j (as below)
+                const float iou = bbox_iou_ref(ax, ay, aw, ah, pbx, pby, pbw, pbh);
+                const unsigned key = (lane < np && pidv >= 0 && pbl == al && iou >= thr) ? __float_as_uint(iou) + 1u : 0u;
+                const unsigned m = wave_umax_dpp(key);
+                int my_id;
+                if (m != 0u) {
+                    const int bj = __ffsll((long long)__ballot(key == m)) - 1;
+                    my_id = __builtin_amdgcn_readlane(pidv, bj);
+                    pidv = lane == bj ? -1 : pidv;      // claimed
+                } else {
+                    my_id = next_id++;
+                }
+                cid = lane == i ? my_id : cid;
+            }
+            outv = cid;                                 // lanes >= n keep -1
+            pbx = cx; pby = cy; pbw = cw; pbh = ch; pbl = cl; pidv = cid; np = n;
+        }
+        for (int j = lane; j < cap; j += 64) id[(T - 1) * cap + j] = j < 64 ? outv : -1;
+        if (lane == 0) nids[clip] = next_id;
+        return;
+    }
+    // ---- general form (any count up to cap): previous / current frame in LDS ----
     for (int t = 0; t < T; ++t) {
         const int n = min(cnt[t], cap);
         const float *cur = bx + (long long)t * cap * DT_BOX_FLOATS;

@@ -387,6 +387,9 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
 // N axis packed [j/32][gate][j%32] like EPI_GATES of conv_igemm.hip.  One work item = (tile, V hidden
 // channels): the i,f,c,o pre-activations of the recurrent convolution come out of the transform in
 // registers, the input projection (bias included) is added, c is updated in place and h written.
+#ifndef WINO_GATES_PIN
+#define WINO_GATES_PIN 1
+#endif
 template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_output_gates_kernel(WinoArgs p)
 {
     typedef typename VecOf<V>::T T;
@@ -411,30 +414,59 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
 #pragma unroll
                 for (int j = 0; j < TS; ++j) y[g][i][j] = m[i][j];
         }
+        // The x-projection and cell-state reads of a whole group of pixel rows go out together, with the address SELECTED for the
+        // pixels outside the frame (they re-read pixel 0; nothing is stored for them) -- not pixel by pixel behind the previous
+        // pixel's stores, each a round trip of its own (round 3's form: 17 dependent round trips per item).
+        constexpr int RG = TS >= 4 ? TS / 2 : TS;          // pixel rows per group (register budget: 5 V (RG TS) values in flight)
+#if WINO_GATES_PIN      // y is materialised HERE (hipcc otherwise sinks the whole transform below the first group's loads: 4 NI NI + 5 RG TS values live)
 #pragma unroll
-        for (int i = 0; i < TS; ++i)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int j = 0; j < TS; ++j) {
-                int b, h, w;
-                if (!vpixel(p, t.grp, TS * t.ty + i, TS * t.tx + j, b, h, w)) continue;
-                const long long pix = h * p.W + w;
-                const float *xp = p.xproj + (long long)b * p.xp_bs + pix * p.xp_ld + col;
-                const T zi = y[0][i][j] + vload<V>(xp), zf = y[1][i][j] + vload<V>(xp + 32);
-                const T zc = y[2][i][j] + vload<V>(xp + 64), zo = y[3][i][j] + vload<V>(xp + 96);
-                float *cp = p.cstate + (long long)b * p.c_bs + pix * p.c_ld + jc;
-                const T cprev = vload<V>(cp);
-                T cn, hn;
+            for (int i = 0; i < TS; ++i)
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const float gi = wino_hard_sigmoid(lane_of<V>(zi, e)), gf = wino_hard_sigmoid(lane_of<V>(zf, e));
-                    const float go = wino_hard_sigmoid(lane_of<V>(zo, e));
-                    const float cv = gf * lane_of<V>(cprev, e) + gi * tanhf(lane_of<V>(zc, e));
-                    set_lane<V>(cn, e, cv);
-                    set_lane<V>(hn, e, go * tanhf(cv));
+                for (int j = 0; j < TS; ++j) asm volatile("" ::"v"(y[g][i][j]));
+#endif
+#pragma unroll
+        for (int i0 = 0; i0 < TS; i0 += RG) {
+            T xz[RG][TS][4], cpv[RG][TS];
+            long long cofs[RG][TS], oofs[RG][TS];
+            bool ok[RG][TS];
+#pragma unroll
+            for (int i = 0; i < RG; ++i)
+#pragma unroll
+                for (int j = 0; j < TS; ++j) {
+                    int b = 0, h = 0, w = 0;
+                    ok[i][j] = vpixel(p, t.grp, TS * t.ty + i0 + i, TS * t.tx + j, b, h, w);
+                    if (!ok[i][j]) { b = 0; h = 0; w = 0; }
+                    const long long pix = h * p.W + w;
+                    const float *xp = p.xproj + (long long)b * p.xp_bs + pix * p.xp_ld + col;
+                    cofs[i][j] = (long long)b * p.c_bs + pix * p.c_ld + jc;
+                    oofs[i][j] = (long long)b * p.out_bs + pix * p.out_ld + jc;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) xz[i][j][g] = vload<V>(xp + 32 * g);
+                    cpv[i][j] = vload<V>(p.cstate + cofs[i][j]);
                 }
-                vstore<V>(cp, cn);
-                vstore<V>(p.out + (long long)b * p.out_bs + pix * p.out_ld + jc, hn);
-            }
+#pragma unroll
+            for (int i = 0; i < RG; ++i)
+#pragma unroll
+                for (int j = 0; j < TS; ++j) {
+                    const T zi = y[0][i0 + i][j] + xz[i][j][0], zf = y[1][i0 + i][j] + xz[i][j][1];
+                    const T zc = y[2][i0 + i][j] + xz[i][j][2], zo = y[3][i0 + i][j] + xz[i][j][3];
+                    T cn, hn;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        const float gi = wino_hard_sigmoid(lane_of<V>(zi, e)), gf = wino_hard_sigmoid(lane_of<V>(zf, e));
+                        const float go = wino_hard_sigmoid(lane_of<V>(zo, e));
+                        const float cv = gf * lane_of<V>(cpv[i][j], e) + gi * tanhf(lane_of<V>(zc, e));
+                        set_lane<V>(cn, e, cv);
+                        set_lane<V>(hn, e, go * tanhf(cv));
+                    }
+                    if (ok[i][j]) {
+                        vstore<V>(p.cstate + cofs[i][j], cn);
+                        vstore<V>(p.out + oofs[i][j], hn);
+                    }
+                }
+        }
     }
 }
 
@@ -658,6 +690,8 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
         const TileId t = tile_id(p, tile);
         T col[8];
         const float *src = p.m + (long long)tile * p.m_ld + c;
+        T bv = vzero<4>();                       // requested with the M' loads (not inside the divergent part: a second round trip per item)
+        if (p.bias) bv = vload<4>(p.bias + c);
 #pragma unroll
         // S3OUT takes the two passes in the other order (along the rows first), so that the LANES of the second pass are
         // consecutive pixels of one image row: a store instruction then covers 6 pixels x 32 bytes of a K block contiguously
@@ -665,6 +699,7 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
         for (int i = 0; i < 8; ++i)
             col[i] = live ? vload_nt<4>(src + (long long)(S3OUT ? 8 * sub + i : 8 * i + sub) * plane) : vzero<4>();   // column nu = sub (S3OUT: row xi = sub)
         at_1d<6>(col);                           // At m : down the column -> rows 0..5   (S3OUT: m A along the row -> columns 0..5)
+        asm volatile("" ::"v"(bv));
 #pragma unroll
         for (int i = 0; i < 6; ++i) vstore<4>(st + (sub * 9 + i) * 4, col[i]);
         wino_item_sync();
@@ -675,7 +710,6 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
 #pragma unroll
             for (int j = 0; j < 8; ++j) row[j] = vload<4>(st + (j * 9 + sub) * 4);
             at_1d<6>(row);                       // (At m) A : along the row -> 6 pixels of output row `sub`
-            const T bv = (live && p.bias) ? vload<4>(p.bias + c) : vzero<4>();
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 T v = row[j] + bv;
@@ -749,6 +783,10 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_output_s3_kernel(WinoA
         const TileId t = tile_id(p, tile);
         T ca[8], cb[8];
         const float *src = p.m + (long long)tile * p.m_ld + c;
+        // the bias goes out with the M' loads and is retired with them on the straight path: requested inside the lane-divergent
+        // part below, every store group got a vmcnt(0) -- a wait for the previous group's stores -- in front of it (round 4)
+        T ba = vzero<4>(), bb = vzero<4>();
+        if (p.bias) { ba = vload<4>(p.bias + c); bb = vload<4>(p.bias + c + 4); }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {           // row xi = sub of the 8x8 M' tile, all eight nu
             ca[i] = live ? vload_nt<4>(src + (long long)(8 * sub + i) * plane) : vzero<4>();
@@ -756,6 +794,7 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_output_s3_kernel(WinoA
         }
         at_1d<6>(ca);                            // m A : along the row -> columns 0..5
         at_1d<6>(cb);
+        asm volatile("" ::"v"(ba), "v"(bb));
 #if WINO_ONE_IMAGE      // one LDS image, the two channel halves one after the other (lanes 6, 7 read rows that were never written: unused)
 #pragma unroll
         for (int i = 0; i < 6; ++i) vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]);
@@ -780,7 +819,6 @@ __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_output_s3_kernel(WinoA
 #endif
             at_1d<6>(ca);                        // At (m A) : down the column -> rows 0..5 of pixel column `sub`
             at_1d<6>(cb);
-            const T ba = (live && p.bias) ? vload<4>(p.bias + c) : vzero<4>(), bb = (live && p.bias) ? vload<4>(p.bias + c + 4) : vzero<4>();
             wino_u4 o[6][3];                     // every split before the first store, each in its own registers
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
