@@ -292,6 +292,8 @@ struct Policy {
                               //                    kernel from this many GEMM rows (48 clips at 13x13: 588); 0 = never
     int s3_1x1_mink = 512;   // DT_S3_1X1_MINK: ... only for 1x1 layers with at least this many input channels (conv_10 / 12 / 15 / 17): the producer's
                              //                  split output transform costs more than fp32 NHWC, which only the long-K GEMMs win back
+    int s3_1x1_minrows = 16384;   // DT_S3_1X1_MINROWS: ... and at least this many pixels: one split GEMM of a 1x1 layer has M / 256 row tiles and no split-K, so at
+                                  // batch 8 (conv_10 / 12: 5408 rows = 22 workgroups) the fp32 kernel with split-K is faster (0.035 vs 0.061 ms)
     int s3_1x1 = 1;          // DT_S3_1X1: a 1x1 layer that follows a Winograd layer takes its input as split-bf16 terms straight from that
                              //            layer's output transform and runs on wino_gemm_s3.hip (same K / rows thresholds); 0 = fp32 MFMA
     int wino_coop = -1;      // DT_WINO_COOP: lane-cooperative F(6x6) transform kernels: -1 for small launches (default) / 0 never / 1 always

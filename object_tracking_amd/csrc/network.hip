@@ -459,6 +459,7 @@ void policy_from_env(Policy &p)
     p.s3_minrows = geti("DT_S3_MINROWS", d.s3_minrows);
     p.s3_1x1 = geti("DT_S3_1X1", d.s3_1x1);
     p.s3_1x1_mink = geti("DT_S3_1X1_MINK", d.s3_1x1_mink);
+    p.s3_1x1_minrows = geti("DT_S3_1X1_MINROWS", d.s3_1x1_minrows);
     p.s3_rec_minrows = geti("DT_S3_REC_MINROWS", d.s3_rec_minrows);
     p.s3_half = geti("DT_S3_HALF", d.s3_half);
     p.persist = geti("DT_PERSIST", d.persist);
@@ -731,7 +732,7 @@ struct S3Handoff {
 static bool s3_1x1_eligible(const dt_ctx *ctx, const ConvLayer &L, long long M)
 {
     return L.ks == 1 && L.wt_s3 && ctx->pol.s3 != 0 && ctx->pol.s3_1x1 != 0 && L.cin % 32 == 0 && L.cout % 128 == 0 && M < (1ll << 31) - 256 &&
-           (ctx->pol.s3 == 2 || (L.cin >= ctx->pol.s3_mink && L.cin >= ctx->pol.s3_1x1_mink && M >= ctx->pol.s3_minrows));
+           (ctx->pol.s3 == 2 || (L.cin >= ctx->pol.s3_mink && L.cin >= ctx->pol.s3_1x1_mink && M >= ctx->pol.s3_minrows && M >= ctx->pol.s3_1x1_minrows));
 }
 
 static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld, int B, int H, int W, float *out,

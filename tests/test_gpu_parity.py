@@ -1456,7 +1456,8 @@ def test_split_bf16_handover_to_1x1_layers(ctx, monkeypatch):
     layers = None
     for mode in ("1", "0"):
         monkeypatch.setenv("DT_S3_1X1", mode)          # read when the context is created (dt_create)
-        monkeypatch.setenv("DT_S3_1X1_MINK", "256")    # every eligible pair (the default policy hands over to conv_15 / conv_17 only)
+        monkeypatch.setenv("DT_S3_1X1_MINK", "256")    # every eligible pair (the default policy: K >= 512 -- conv_10 / 12 / 15 / 17 --
+        monkeypatch.setenv("DT_S3_1X1_MINROWS", "0")   # and from 16384 pixels per launch)
         det, layers, _ = _detector(ctx, H, W, C, seed=77)
         c = det.model.ctx
         c.profile_reset(); c.profile_enable(True)
