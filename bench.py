@@ -188,7 +188,7 @@ def _time_steps(step, warmup, steps):
     return (time.perf_counter() - t0) / steps
 
 
-def track_extra(device, size, clips, T, boxes, steps=3, env=None, what=None):
+def track_extra(device, size, clips, T, boxes, steps=3, env=None, what=None, graphs=False):
     """BASELINE.json configs[4]'s single-GPU shard under the same clock: MultiObjDetTracker at size x size with
     ~`boxes` candidate boxes per frame, `clips` clips x T frames per step, its own context.  `env`: policy knobs the
     context is created under (read once in dt_create), e.g. {"DT_S3": "0"} = every GEMM on the fp32 MFMA instruction."""
@@ -205,10 +205,12 @@ def track_extra(device, size, clips, T, boxes, steps=3, env=None, what=None):
                 os.environ[k] = v
     cap = max(128, 2 * boxes)
     res = {}
+    if graphs:
+        trk.model.ctx.graph_enable(True)      # captured on the second warm-up call, replayed afterwards
 
     def step():
         res["r"] = trk.track_clips(frames, cap=cap)
-    sec = _time_steps(step, 2, steps)
+    sec = _time_steps(step, 3 if graphs else 2, steps)
     return {"workload": what or "BASELINE.json configs[4] on one GPU: MultiObjDetTracker %dx%d, %d clips x %d frames per step, "
                                 "head calibrated to %d candidate boxes per frame" % (size, size, clips, T, boxes),
             "ms_per_step": 1e3 * sec, "frames_per_s": clips * T / sec,
@@ -616,6 +618,11 @@ def _run():
             for key, fn in (("detect_batch8", lambda: detect_batch8_extra(device, H, W, seed0=4242)),
                             ("track_608_128boxes", lambda: track_extra(device, 608, 24, args.T, 128)),
                             ("tiny_T64", lambda: tiny_extra(device, H, W, 32)),
+                            # the headline workload with hipGraph replay of the detector trunk and the recurrence (dt_graph_enable): no
+                            # per-launch events are possible inside a replayed graph, so the headline number (which carries them) runs without
+                            ("track_hipgraph", lambda: track_extra(device, H, args.clips, args.T, args.boxes, steps=args.steps, graphs=True,
+                                                                   what="the headline workload (BASELINE.json configs[2], %d clips x %d frames) with dt_graph_enable: the detector trunk "
+                                                                        "and the ConvLSTM recurrence replayed as hipGraphs, no per-launch events" % (args.clips, args.T))),
                             # the headline workload with the split-bf16 GEMMs switched off (DT_S3=0: v_mfma_f32_32x32x2_f32
                             # everywhere), same run, same clock: what the bf16-pipe arithmetic buys
                             ("track_fp32_mfma_only", lambda: track_extra(
