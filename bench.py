@@ -486,7 +486,13 @@ def _run():
         "implementation_GBps": (wino_in["bytes"] + wino_out["bytes"]) / (wino_ms * 1e-3) / 1e9,
         "frac_of_8TBps": (wino_in["bytes"] + wino_out["bytes"]) / (wino_ms * 1e-3) / 8e12,
         "implementation_bytes_per_step": (wino_in["bytes"] + wino_out["bytes"]) / steps,
-        "traffic_bytes_per_step": fam_traffic.get("wino_transforms")}
+        "traffic_bytes_per_step": fam_traffic.get("wino_transforms"),
+        "input_GBps": (wino_in["bytes"] / (wino_in["ms"] * 1e-3) / 1e9) if wino_in["ms"] > 0 else None,
+        "output_GBps": (wino_out["bytes"] / (wino_out["ms"] * 1e-3) / 1e9) if wino_out["ms"] > 0 else None,
+        # what a plain streaming kernel reaches on an MI355X of this pool, per traffic mix (tools/micro/hbm_rw, profiles/r04_hbm_ceilings.txt):
+        # the split input transforms write 2.7 bytes per byte read, the output transforms read 1.8 per byte written
+        "streaming_kernel_GBps": {"read_only": 5670, "write_only": 4400, "copy": 4790, "1_read_to_2.7_writes": 4180, "1.8_reads_to_1_write": 4700,
+                                  "source": "profiles/r04_hbm_ceilings.txt"}}
     dominant = max((k for k in families if families[k]), key=lambda k: families[k]["ms_per_step"], default=None)
     # whole conv path: time the matrix pipe would need AT ITS PEAKS for everything the conv kernels execute (bf16 and fp32
     # instructions have different peaks) / the time the conv path takes, transforms included

@@ -37,6 +37,8 @@ if [ -x $R/tools/micro/gemm_s3_bench ]; then
   (cd $R && timeout 300 tools/micro/gemm_s3_bench > $O/gemm_s3_micro.txt 2>&1; cat $O/gemm_s3_micro.txt | cut -c1-170)
   (bash $R/tools/s3_clock.sh - _a1 _a2 _a3 -zero -const > $O/gemm_s3_clock.txt 2>&1; cat $O/gemm_s3_clock.txt)
 fi
+# practical HBM ceilings of this box per traffic mix (read / write / copy / the transforms' mixes)
+[ -x $R/tools/micro/hbm_rw ] && (cd $R && timeout 120 tools/micro/hbm_rw > $O/hbm_ceilings.txt 2>&1; cat $O/hbm_ceilings.txt)
 # keep the merged payload small: drop raw per-dispatch CSVs above 20 MB
 find $O -name "*.csv" -size +20M -delete
 python $R/tools/make_traffic_json.py $O ${CLIPS:-48} > $O/traffic.json 2>/dev/null; cat $O/traffic.json | head -20
