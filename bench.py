@@ -491,7 +491,8 @@ def _run():
         "output_GBps": (wino_out["bytes"] / (wino_out["ms"] * 1e-3) / 1e9) if wino_out["ms"] > 0 else None,
         # what a plain streaming kernel reaches on an MI355X of this pool, per traffic mix (tools/micro/hbm_rw, profiles/r04_hbm_ceilings.txt):
         # the split input transforms write 2.7 bytes per byte read, the output transforms read 1.8 per byte written
-        "streaming_kernel_GBps": {"read_only": 5670, "write_only": 4400, "copy": 4790, "1_read_to_2.7_writes": 4180, "1.8_reads_to_1_write": 4700,
+        "streaming_kernel_GBps": {"read_only": 5670, "write_only": 4400, "copy": 4800, "1_read_to_2.7_writes": 4250, "1.8_reads_to_1_write": 4850,
+                                  "note": "means over three boxes; +/- 5 % between boxes",
                                   "source": "profiles/r04_hbm_ceilings.txt"}}
     dominant = max((k for k in families if families[k]), key=lambda k: families[k]["ms_per_step"], default=None)
     # whole conv path: time the matrix pipe would need AT ITS PEAKS for everything the conv kernels execute (bf16 and fp32

@@ -14,5 +14,6 @@ cp $T/pytest_gpu.txt $P/${R}_pytest_gpu.txt
   echo; echo "# effective shader clock and MFMA-busy share of every kernel INSIDE the step -- one pass --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES (tools/rocprof_summary.py mfma)"; cat $T/rocprof_pmc_MFMA.txt; } > $P/${R}_rocprof_pmc.txt
 [ -f $T/gemm_s3_micro.txt ] && cp $T/gemm_s3_micro.txt $P/${R}_gemm_s3_micro.txt
 [ -f $T/gemm_s3_clock.txt ] && cp $T/gemm_s3_clock.txt $P/${R}_gemm_s3_clock.txt
+[ -f $T/hbm_ceilings.txt ] && { echo "# tools/micro/hbm_rw (16 B per lane, grid-stride, nontemporal): what a plain streaming kernel reaches on the box, per traffic mix"; cat $T/hbm_ceilings.txt; } > $P/${R}_hbm_ceilings.txt
 for f in gpurun_out/parity_${R}_*.json gpurun_out/parity_${R}_*.txt; do [ -f $f ] && cp $f $P/; done
 ls $P | grep "^${R}_\|parity_${R}"
