@@ -398,7 +398,7 @@ int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, in
     while (tpw > 1 && rows * ((ntx + tpw - 1) / tpw) < 2048) tpw = (tpw + 1) / 2;
     a.tpw = tpw;
     const dim3 grid((unsigned)((ntx + tpw - 1) / tpw), (unsigned)((H2 + 7) / 8), (unsigned)B);
-    if (w3 && w3u8) {      // split-bf16 form (Policy::s3_conv1)
+    if (w3 && w3u8 && (dtype != DT_FRAMES_U8 || W % 4 == 0)) {      // split-bf16 form (Policy::s3_conv1); uint8: the kernel reads aligned dwords of the rows
         if (dtype == DT_FRAMES_U8) hipLaunchKernelGGL(conv1_s3_kernel<true>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(conv1_s3_kernel<false>, grid, dim3(256), 0, st, a);
     } else

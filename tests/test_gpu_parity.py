@@ -555,14 +555,16 @@ def test_track_clips_boxes_and_ids_vs_oracle(ctx):
     assert total > 0, "test is vacuous without boxes"
 
 
-def test_associate_vs_oracle_synthetic(ctx):
-    """Moving boxes with births, deaths, label changes and ties."""
+@pytest.mark.parametrize("n_clips,T,cap,obj0,dobj", [(7, 12, 40, 5, 4), (3, 8, 120, 70, 20), (2, 70, 16, 5, 3)],
+                         ids=["register_form", "general_form_over_64_boxes", "general_form_T_over_64"])
+def test_associate_vs_oracle_synthetic(ctx, n_clips, T, cap, obj0, dobj):
+    """Moving boxes with births, deaths, label changes and ties.  associate_kernel has two forms: boxes and ids in registers
+    (every frame of the clip <= 64 boxes, T <= 64) and in LDS (anything else)."""
     rs = np.random.RandomState(3)
-    n_clips, T, cap = 7, 12, 40
     boxes = np.zeros((n_clips, T, cap, 8), dtype=np.float32)
     counts = np.zeros((n_clips, T), dtype=np.int32)
     for c in range(n_clips):
-        n_obj = 5 + 4 * c
+        n_obj = obj0 + dobj * c
         pos = rs.rand(n_obj, 2); vel = (rs.rand(n_obj, 2) - .5) * .06; wh = rs.rand(n_obj, 2) * .2 + .05
         lab = rs.randint(0, 3, n_obj)
         for t in range(T):
