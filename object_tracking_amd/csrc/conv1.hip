@@ -186,7 +186,7 @@ __device__ __forceinline__ float c1_bf16_f32(unsigned short h) { return __uint_a
 #ifndef C1_ABLATE
 #define C1_ABLATE 0          // timing-only builds (results WRONG): 1 no output stores, 2 no frame loads, 4 no fragment reads + MFMAs, 8 no staging
 #endif
-template <bool U8>
+template <bool U8, bool FULL = false>      // FULL: H and W are multiples of 16 -- every tile is whole, no bounds checks around the stores
 __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
 {
     constexpr int NT = U8 ? 1 : 3;                    // bf16 terms of a patch value
@@ -307,7 +307,10 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
     auto tile = [&](int bx, Raw &raw) {
         stage(raw);
         C1_SYNC();
-        if (bx + C1_PF < bx_last) fetch(bx + C1_PF, raw);       // in flight across the next C1_PF tiles
+        // in flight across the next C1_PF tiles.  FULL: requested unconditionally (past the end: the last tile again), so that
+        // every trip of the loop issues the same loads and stores and hipcc can COUNT its way to the right vmcnt
+        if (FULL) fetch(min(bx + C1_PF, bx_last - 1), raw);
+        else if (bx + C1_PF < bx_last) fetch(bx + C1_PF, raw);
         {
             // pooled rows g = 2 wave, 2 wave + 1 of the tile (gi = 0, 1: +36 elements), one after the other: the second group's
             // fragment reads are in flight under the first group's MFMAs, and only one group's fragments are live
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
                     const float mx = fmaxf(fmaxf(acc[gi][4 * j], acc[gi][4 * j + 1]), fmaxf(acc[gi][4 * j + 2], acc[gi][4 * j + 3])) + bias;
                     const float v = mx > 0.0f ? mx : mx * p.slope;
                     const int ox = bx * 8 + h + 2 * j;
-                    if ((C1_ABLATE & 1) ? v == 12345.678f : (oy < H2 && ox < W2)) p.out[(((long long)b * H2 + oy) * W2 + ox) * 32 + n] = v;
+                    if ((C1_ABLATE & 1) ? v == 12345.678f : (FULL || (oy < H2 && ox < W2))) p.out[(((long long)b * H2 + oy) * W2 + ox) * 32 + n] = v;
                 }
             }
         }
@@ -354,6 +357,22 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
     };
     Raw rawA, rawB;
     fetch(bx_first, rawA);
+    if (FULL && C1_PF == 2) {
+        // Whole tiles: a loop over PAIRS of tiles in which nothing is conditional (one load and eight stores per tile), entered with
+        // both prefetched tiles LANDED (one wait per workgroup walk).  The wait in front of a tile's staging then counts the stores
+        // and the load issued since its own load -- vmcnt(17) -- instead of draining them: the loop head's vmcnt(0) of the guarded
+        // form waited for the previous tile's eight stores to be acknowledged (it must assume the path on which none was issued).
+        fetch(min(bx_first + 1, bx_last - 1), rawB);
+        asm volatile("" ::"v"(rawA.dw), "v"(rawB.dw), "v"(rawA.v[0][0]), "v"(rawB.v[0][0]));
+        int bx = bx_first;
+#pragma unroll 1
+        for (; bx + 1 < bx_last; bx += 2) {
+            tile(bx, rawA);
+            tile(bx + 1, rawB);
+        }
+        if (bx < bx_last) tile(bx, rawA);
+        return;
+    }
     if (C1_PF == 2 && bx_first + 1 < bx_last) fetch(bx_first + 1, rawB);
 #pragma unroll 1
     for (int bx = bx_first; bx < bx_last; bx += C1_PF) {
@@ -399,8 +418,10 @@ int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, in
     a.tpw = tpw;
     const dim3 grid((unsigned)((ntx + tpw - 1) / tpw), (unsigned)((H2 + 7) / 8), (unsigned)B);
     if (w3 && w3u8 && (dtype != DT_FRAMES_U8 || W % 4 == 0)) {      // split-bf16 form (Policy::s3_conv1); uint8: the kernel reads aligned dwords of the rows
-        if (dtype == DT_FRAMES_U8) hipLaunchKernelGGL(conv1_s3_kernel<true>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(conv1_s3_kernel<false>, grid, dim3(256), 0, st, a);
+        const bool full = H % 16 == 0 && W % 16 == 0;
+        if (dtype == DT_FRAMES_U8 && full) hipLaunchKernelGGL((conv1_s3_kernel<true, true>), grid, dim3(256), 0, st, a);
+        else if (dtype == DT_FRAMES_U8) hipLaunchKernelGGL((conv1_s3_kernel<true, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv1_s3_kernel<false, false>), grid, dim3(256), 0, st, a);
     } else
         hipLaunchKernelGGL(conv1_mfma_kernel, grid, dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
