@@ -217,6 +217,41 @@ def track_extra(device, size, clips, T, boxes, steps=3, env=None, what=None, gra
             "boxes_per_frame": float(res["r"]["counts"].float().mean().item())}
 
 
+def two_partitions_extra(device, size, clips, T, boxes, steps=5):
+    """The headline step twice over, concurrently: two contexts, `clips` clips each, on two streams masked to complementary halves
+    of the CUs (hipExtStreamCreateWithCUMask).  One partition's launch gaps and kernel tails are the other's working time; measured
+    -3 % per frame against one stream (profiles/r04_dual_partition.txt).  An experiment reported beside the headline number, not part
+    of it: the persistent kernels still size their grids for the whole chip."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+        words = (n_cu + 31) // 32
+
+        def masked(lo, hi):
+            mask = (ctypes.c_uint32 * words)()
+            for cu in range(lo, hi):
+                mask[cu // 32] |= 1 << (cu % 32)
+            st = ctypes.c_void_p()
+            if hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), words, mask) != 0:
+                raise RuntimeError("hipExtStreamCreateWithCUMask failed")
+            return torch.cuda.ExternalStream(st.value, device=device)
+        streams = (masked(0, n_cu // 2), masked(n_cu // 2, n_cu))
+        frames = [make_frames(clips, T, size, size, device, seed0=7100 + 50 * i) for i in range(2)]
+        trks = [build_tracker(size, size, T, boxes, f)[0] for f in frames]
+        cap = max(128, 2 * boxes)
+
+        def step():
+            for st, trk, f in zip(streams, trks, frames):
+                with torch.cuda.stream(st):
+                    trk.track_clips(f, cap=cap)
+        sec = _time_steps(step, 2, steps)
+        return {"workload": "2 x (%d clips x %d frames) per step: the headline workload in two half-chip partitions (CU-masked streams, one context each)" % (clips, T),
+                "ms_per_step": 1e3 * sec, "frames_per_s": 2 * clips * T / sec}
+    except Exception as e:      # an experiment: never in the way of the line
+        return {"error": repr(e)}
+
+
 def tiny_extra(device, H, W, seqs, steps=3):
     """BASELINE.json configs[3] on one GPU under the same clock: TinyTracker over `seqs` sequences x 64 frames
     (YOLOv2 C=80 + act_13 global max-pool + decode / top box per frame, LSTM(512) + Dense(4) over T)."""
@@ -630,6 +665,7 @@ def _run():
                             ("track_hipgraph", lambda: track_extra(device, H, args.clips, args.T, args.boxes, steps=args.steps, graphs=True,
                                                                    what="the headline workload (BASELINE.json configs[2], %d clips x %d frames) with dt_graph_enable: the detector trunk "
                                                                         "and the ConvLSTM recurrence replayed as hipGraphs, no per-launch events" % (args.clips, args.T))),
+                            ("track_two_partitions", lambda: two_partitions_extra(device, H, args.clips, args.T, args.boxes, steps=args.steps)),
                             # the headline workload with the split-bf16 GEMMs switched off (DT_S3=0: v_mfma_f32_32x32x2_f32
                             # everywhere), same run, same clock: what the bf16-pipe arithmetic buys
                             ("track_fp32_mfma_only", lambda: track_extra(
