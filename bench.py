@@ -218,34 +218,18 @@ def track_extra(device, size, clips, T, boxes, steps=3, env=None, what=None, gra
 
 
 def two_partitions_extra(device, size, clips, T, boxes, steps=5):
-    """The headline step twice over, concurrently: two contexts, `clips` clips each, on two streams masked to complementary halves
-    of the CUs (hipExtStreamCreateWithCUMask).  One partition's launch gaps and kernel tails are the other's working time; measured
-    -3 % per frame against one stream (profiles/r04_dual_partition.txt).  An experiment reported beside the headline number, not part
-    of it: the persistent kernels still size their grids for the whole chip."""
-    import ctypes
+    """The headline step twice over, concurrently: two trackers (two contexts), `clips` clips each, on two streams masked to
+    complementary halves of the CUs (parallel.cu_partition_streams / track_clips_partitions).  One partition's launch gaps and kernel
+    tails are the other's working time; measured +3-4 % frames per second against one stream (profiles/r04_dual_partition.txt).
+    Reported beside the headline number, not as it: with two concurrent partitions the per-kernel event times sum to twice the step
+    and every launch runs at half the chip's rate, which is not what the roofline block describes."""
+    from object_tracking_amd import parallel
     try:
-        hip = ctypes.CDLL("libamdhip64.so")
-        n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-        words = (n_cu + 31) // 32
-
-        def masked(lo, hi):
-            mask = (ctypes.c_uint32 * words)()
-            for cu in range(lo, hi):
-                mask[cu // 32] |= 1 << (cu % 32)
-            st = ctypes.c_void_p()
-            if hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), words, mask) != 0:
-                raise RuntimeError("hipExtStreamCreateWithCUMask failed")
-            return torch.cuda.ExternalStream(st.value, device=device)
-        streams = (masked(0, n_cu // 2), masked(n_cu // 2, n_cu))
+        streams = parallel.cu_partition_streams(device, 2)
         frames = [make_frames(clips, T, size, size, device, seed0=7100 + 50 * i) for i in range(2)]
         trks = [build_tracker(size, size, T, boxes, f)[0] for f in frames]
         cap = max(128, 2 * boxes)
-
-        def step():
-            for st, trk, f in zip(streams, trks, frames):
-                with torch.cuda.stream(st):
-                    trk.track_clips(f, cap=cap)
-        sec = _time_steps(step, 2, steps)
+        sec = _time_steps(lambda: parallel.track_clips_partitions(trks, frames, streams, cap=cap), 2, steps)
         return {"workload": "2 x (%d clips x %d frames) per step: the headline workload in two half-chip partitions (CU-masked streams, one context each)" % (clips, T),
                 "ms_per_step": 1e3 * sec, "frames_per_s": 2 * clips * T / sec}
     except Exception as e:      # an experiment: never in the way of the line

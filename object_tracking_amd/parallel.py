@@ -306,3 +306,46 @@ def init_from_env(backend=None):
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local
+
+
+# ---------------------------------------------------------------------------
+# Partitions of ONE GPU (throughput mode; no reference counterpart)
+# ---------------------------------------------------------------------------
+def cu_partition_streams(device=None, n=2):
+    """n HIP streams whose kernels are confined to complementary n-ths of the device's CUs (hipExtStreamCreateWithCUMask).
+    Independent clip batches run on them concurrently -- one context (one tracker object) per stream -- and one partition's launch
+    gaps and kernel tails are the other's working time: two partitions of 48 clips each deliver 3-4 % more frames per second than
+    one stream of the same 96 clips (profiles/r04_dual_partition.txt); half-size batches on two partitions deliver less."""
+    import ctypes
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    words = (n_cu + 31) // 32
+    out = []
+    with torch.cuda.device(device):
+        for i in range(n):
+            mask = (ctypes.c_uint32 * words)()
+            for cu in range(i * n_cu // n, (i + 1) * n_cu // n):
+                mask[cu // 32] |= 1 << (cu % 32)
+            st = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), words, mask)
+            if rc != 0:
+                raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
+            out.append(torch.cuda.ExternalStream(st.value, device=device))
+    return out
+
+
+def track_clips_partitions(trackers, frames_list, streams, cap=None):
+    """trackers[i].track_clips(frames_list[i]) on streams[i], all enqueued before any is waited for; the caller's current stream
+    waits for every partition before the results are returned.  Each tracker must own its context (its own MultiObjDetTracker)."""
+    assert len(trackers) == len(frames_list) == len(streams)
+    cur = torch.cuda.current_stream()
+    res = []
+    for trk, fr, st in zip(trackers, frames_list, streams):
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            res.append(trk.track_clips(fr, cap=cap))
+    for st in streams:
+        cur.wait_stream(st)
+    return res
+

@@ -345,3 +345,37 @@ def test_graph_replay_with_caller_owned_rows():
         assert ctx.profile_read("graph_replay")["launches"] > 0
     finally:
         ctx.graph_enable(False)
+
+
+def test_two_cu_partitions_equal_one_stream():
+    """parallel.cu_partition_streams / track_clips_partitions: two trackers (two contexts, the same weights) on two streams masked to
+    complementary halves of the CUs, run concurrently several times over -- every partition's boxes, counts and ids are bit-identical
+    to the same tracker's result on the default stream (no kernel depends on how many CUs it runs on, no workspace is shared)."""
+    import numpy as np
+    import torch
+    from models_tracking.MultiObjDetTracker import MultiObjDetTracker
+    from object_tracking_amd import parallel
+    from utility import synth
+    H = W = 128; T = 6; N = 5; C = 12
+
+    class Trk(MultiObjDetTracker):
+        IMAGE_H, IMAGE_W = H, W
+        GRID_H, GRID_W = 4, 4
+        SEQUENCE_LENGTH = T
+        LOAD_MODEL = False
+        OBJ_THRESHOLD = 1e-4
+    blob, tw = synth.synth_darknet_blob(C), synth.synth_tracker_weights(C)
+    trks = [Trk(detector_weights=blob, tracker_weights=tw) for _ in range(2)]
+    assert trks[0].model.ctx is not trks[1].model.ctx
+    dev = trks[0].model.ctx.device
+    frames = [torch.from_numpy(np.stack([synth.synth_clip(T, H, W, 3, seed=500 + 20 * k + i) for i in range(N)])).to(dev) for k in range(2)]
+    want = [t.track_clips(f) for t, f in zip(trks, frames)]
+    torch.cuda.synchronize()
+    streams = parallel.cu_partition_streams(dev, 2)
+    for _ in range(3):
+        got = parallel.track_clips_partitions(trks, frames, streams)
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            for k in ("boxes", "counts", "ids", "nids", "netout"):
+                assert torch.equal(g[k], w[k]), k
+    assert float(want[0]["netout"].std()) > 0 and not torch.equal(want[0]["netout"], want[1]["netout"])
