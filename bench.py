@@ -229,9 +229,13 @@ def two_partitions_extra(device, size, clips, T, boxes, steps=5):
         frames = [make_frames(clips, T, size, size, device, seed0=7100 + 50 * i) for i in range(2)]
         trks = [build_tracker(size, size, T, boxes, f)[0] for f in frames]
         cap = max(128, 2 * boxes)
-        sec = _time_steps(lambda: parallel.track_clips_partitions(trks, frames, streams, cap=cap), 2, steps)
-        return {"workload": "2 x (%d clips x %d frames) per step: the headline workload in two half-chip partitions (CU-masked streams, one context each)" % (clips, T),
-                "ms_per_step": 1e3 * sec, "frames_per_s": 2 * clips * T / sec}
+        torch.cuda.synchronize()
+        sec = _time_steps(lambda: parallel.track_clips_partitions(trks, frames, streams, cap=cap, join=False), 2, steps)      # _time_steps synchronises the device around the timed steps
+        sec_join = _time_steps(lambda: parallel.track_clips_partitions(trks, frames, streams, cap=cap), 1, steps)
+        return {"workload": "2 x (%d clips x %d frames) per step: the headline workload in two half-chip partitions (CU-masked streams, one context each), "
+                            "batch after batch without a barrier between the partitions" % (clips, T),
+                "ms_per_step": 1e3 * sec, "frames_per_s": 2 * clips * T / sec,
+                "with_a_barrier_per_step": {"ms_per_step": 1e3 * sec_join, "frames_per_s": 2 * clips * T / sec_join}}
     except Exception as e:      # an experiment: never in the way of the line
         return {"error": repr(e)}
 

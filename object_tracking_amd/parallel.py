@@ -335,17 +335,25 @@ def cu_partition_streams(device=None, n=2):
     return out
 
 
-def track_clips_partitions(trackers, frames_list, streams, cap=None):
-    """trackers[i].track_clips(frames_list[i]) on streams[i], all enqueued before any is waited for; the caller's current stream
-    waits for every partition before the results are returned.  Each tracker must own its context (its own MultiObjDetTracker)."""
+def track_clips_partitions(trackers, frames_list, streams, cap=None, join=True):
+    """trackers[i].track_clips(frames_list[i]) on streams[i], all enqueued before any is waited for.  join=True: the caller's current
+    stream waits for every partition before the results are returned (a barrier per call).  join=False: nothing waits -- a pipeline that
+    feeds batch after batch keeps both partitions busy across batch boundaries (that is where most of the gain is: +3-4 % against
+    +1.4 % with the barrier) and synchronises streams[i] before it READS result i.  Each tracker must own its context."""
     assert len(trackers) == len(frames_list) == len(streams)
     cur = torch.cuda.current_stream()
+    # ONE event on the caller's stream, recorded before anything is launched: the CU-masked streams are blocking streams, and an
+    # operation on the legacy default stream between two partitions' launches (an event record is one) orders the second partition
+    # behind the whole of the first
+    ready = cur.record_event() if join else None
     res = []
     for trk, fr, st in zip(trackers, frames_list, streams):
-        st.wait_stream(cur)
+        if join:
+            st.wait_event(ready)
         with torch.cuda.stream(st):
             res.append(trk.track_clips(fr, cap=cap))
-    for st in streams:
-        cur.wait_stream(st)
+    if join:
+        for st in streams:
+            cur.wait_stream(st)
     return res
 
