@@ -490,7 +490,7 @@ def _run():
         "wino_gemm_s3": family("conv_gemm_s3", s3, "wino_gemm_s3_kernel / wino_gemm_s3_half_kernel (F(6x6) / F(4x4) batched GEMMs, 1x1 layers behind them)",
                                "v_mfma_f32_32x32x16_bf16 on 3-term split fp32 operands, six per fp32 multiply-add, fp32 accumulate",
                                PEAK_BF16_MFMA_TFLOPS, "wino_gemm_s3"),
-        "conv_igemm_f32": family("conv_igemm", ig, "conv_igemm_f32 (implicit GEMM: 1x1 layers with short K or N, the K = 128 Winograd GEMMs of conv_6 / conv_8)",
+        "conv_igemm_f32": family("conv_igemm", ig, "conv_igemm_f32 (implicit GEMM: the 1x1 layers with fewer than 128 output channels -- conv_4, conv_21, conv_23, tconv_2)",
                                  "v_mfma_f32_32x32x2_f32", PEAK_F32_MFMA_TFLOPS, "conv_igemm_f32"),
         "wino4s_fused": family("conv_fused", fused, "wino4s_fused_kernel (conv_2 / conv_3 / conv_5: fused F(4x4,3x3))", "v_mfma_f32_16x16x4_f32",
                                PEAK_F32_MFMA_TFLOPS, "wino4s_fused"),

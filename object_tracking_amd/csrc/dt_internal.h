@@ -124,10 +124,6 @@ struct WinoArgs {
     int out_ld;
     float *out2;
     int out2_ld;
-    // non-null: the activation leaves as the split-bf16 A operand of the next (1x1) layer's GEMM instead of `out`:
-    // [3][N/16][out_mp][16], row = pixel index (b*H + h)*W + w  (ts == 6 cooperative kernel, N % 16 == 0)
-    unsigned short *out_s3;
-    int out_mp;
     // gate variant (ConvLSTM2D): xproj / cstate as in ConvArgs
     const float *xproj;
     long long xp_bs;
@@ -158,12 +154,14 @@ int launch_wino4s_fused(hipStream_t st, const Wino4FusedArgs &a, const float *ze
 void wino4s_fused_pack(const float *u36, int npad, int cin, int cout, float *dst);
 // split-bf16 batched GEMM of the F(6x6,3x3) layers (wino_gemm_s3.hip): fp32 operands as three bf16 terms, six MFMAs per product
 struct GemmS3Args {
-    const unsigned short *a;   // V terms  [P][3][K/16][Mp][16]   (winograd.hip split input transform)
+    const unsigned short *a;   // V terms  [P][3][K/16][Mp][16]   (winograd.hip split input transform) -- the Winograd GEMMs; null for a 1x1 layer:
+    const float *a_f32;        // ... whose A operand is the producing layer's fp32 activation as it lies, [Mt][a_ld] (P = 1), split into its terms by the
+    int a_ld;                  //     kernel when a wave reads its fragment
     const unsigned short *b;   // U terms  [P][3][K/16][Np][16]   (wino_s3_pack_weights)
     float *c;                  // M'       [P] planes of [Mt][ldc], plane stride c_ps floats
     long long c_ps;
     int P, Mt, Mp, N, Np, K, ldc;
-    // a 1x1 layer through this kernel: bias as one extra K stage -- ones = [3][256][16] terms of the row (1, 0, .., 0),
+    // a 1x1 layer through this kernel: bias as one extra K stage -- ones = [256][16] FLOATS, rows (1, 0, .., 0),
     // bias_s3 = [3][Np][16] terms of (bias[n], 0, .., 0); both null for the Winograd GEMMs.  act: LeakyReLU(slope) in the epilogue
     const unsigned short *ones, *bias_s3;
     int act;
@@ -290,12 +288,12 @@ struct Policy {
     int s3_half = 0;          // DT_S3_HALF: 128-row tiles / two workgroups per CU in the split GEMM: 0 where it needs fewer rounds (default) / 1 always (N % 256 == 0) / -1 never
     int s3_rec_minrows = 512; // DT_S3_REC_MINROWS: the ConvLSTM recurrent step's F(4x4) GEMM (gate update in its output transform) takes the split
                               //                    kernel from this many GEMM rows (48 clips at 13x13: 588); 0 = never
-    int s3_1x1_mink = 512;   // DT_S3_1X1_MINK: ... only for 1x1 layers with at least this many input channels (conv_10 / 12 / 15 / 17): the producer's
-                             //                  split output transform costs more than fp32 NHWC, which only the long-K GEMMs win back
+    int s3_1x1_mink = 256;   // DT_S3_1X1_MINK: ... only for 1x1 layers with at least this many input channels (conv_7 / 10 / 12 / 15 / 17; 256 since the
+                             //                  kernel reads the fp32 activation itself: conv_7 2.36 -> 1.63 ms per 1440 frames)
     int s3_1x1_minrows = 16384;   // DT_S3_1X1_MINROWS: ... and at least this many pixels: one split GEMM of a 1x1 layer has M / 256 row tiles and no split-K, so at
                                   // batch 8 (conv_10 / 12: 5408 rows = 22 workgroups) the fp32 kernel with split-K is faster (0.035 vs 0.061 ms)
-    int s3_1x1 = 1;          // DT_S3_1X1: a 1x1 layer that follows a Winograd layer takes its input as split-bf16 terms straight from that
-                             //            layer's output transform and runs on wino_gemm_s3.hip (same K / rows thresholds); 0 = fp32 MFMA
+    int s3_1x1 = 1;          // DT_S3_1X1: the 1x1 layers with N % 128 == 0 run on wino_gemm_s3.hip straight from the fp32 activation (the kernel splits
+                             //            its A fragments itself); 0 = fp32 MFMA
     int wino_coop = -1;      // DT_WINO_COOP: lane-cooperative F(6x6) transform kernels: -1 for small launches (default) / 0 never / 1 always
     int persist = 1;         // DT_PERSIST: 0 = one tile per workgroup for the GEMM-shaped launches (A/B runs)
     int xcd_remap = 1;       // DT_XCD_REMAP: 0 = plain tile numbering (L2 traffic experiments)
@@ -316,7 +314,7 @@ struct dt_ctx {
     int dec_anchors_n = 0;
     bool det_loaded = false;
     ConvLayer layers[24];   // 1..23
-    unsigned short *s3_ones = nullptr;   // device, [3][256][16]: split terms of the A rows (1, 0, .., 0) that carry a 1x1 layer's bias through wino_gemm_s3.hip
+    unsigned short *s3_ones = nullptr;   // device, [256][16] FLOATS: the A rows (1, 0, .., 0) that carry a 1x1 layer's bias through wino_gemm_s3.hip
     std::map<const void *, unsigned short *> wino_s3;   // F(6x6) Winograd weights (device pointer) -> their split-bf16 form (wino_gemm_s3.hip), when built
     float *conv1_w = nullptr, *conv1_b = nullptr, *lut255 = nullptr;
     unsigned *conv1_w3 = nullptr, *conv1_w3u8 = nullptr;   // device: split-bf16 weight tables of conv1_s3_kernel: w and w / 255 (conv1.hip:conv1_split_tables)

@@ -306,10 +306,10 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&L.bias_s3), bs.size() * sizeof(unsigned short)));
         HIP_TRY(ctx, hipMemcpy(L.bias_s3, bs.data(), bs.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
         if (!ctx->s3_ones) {
-            std::vector<unsigned short> ones((size_t)3 * 256 * 16, 0);
-            for (int r = 0; r < 256; ++r) ones[(size_t)r * 16] = 0x3f80;      // bf16 1.0 in term 0, column 0
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->s3_ones), ones.size() * sizeof(unsigned short)));
-            HIP_TRY(ctx, hipMemcpy(ctx->s3_ones, ones.data(), ones.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+            std::vector<float> ones((size_t)256 * 16, 0.0f);      // the bias stage's A rows, fp32 like the layer's activation: (1, 0, .., 0)
+            for (int r = 0; r < 256; ++r) ones[(size_t)r * 16] = 1.0f;
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->s3_ones), ones.size() * sizeof(float)));
+            HIP_TRY(ctx, hipMemcpy(ctx->s3_ones, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     }
     if (L.scale) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.scale); L.scale = nullptr; }
@@ -581,7 +581,6 @@ struct WinoIO {
     const float *in; long long in_bs; int in_ld;      // NHWC input
     float *out; long long out_bs; int out_ld;         // full-resolution output (null: pooled only)
     float *out2; int out2_ld;                         // 2x2 pooled output or null
-    unsigned short *out_s3; int out_mp;               // instead of out: split-bf16 rows for the next (1x1) layer's GEMM (winograd.hip)
     const float *xproj; long long xp_bs; int xp_ld;   // gates variant (cstate != null)
     float *cstate; long long c_bs; int c_ld;
 };
@@ -643,7 +642,6 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
     w.in = io.in; w.in_bs = io.in_bs; w.in_ld = io.in_ld; w.C = cin; w.v = V;
     w.m = Mp; w.m_ld = N; w.N = N; w.bias = bias; w.slope = slope;
     w.out = io.out; w.out_bs = io.out_bs; w.out_ld = io.out_ld; w.out2 = io.out2; w.out2_ld = io.out2_ld;
-    w.out_s3 = io.out_s3; w.out_mp = io.out_mp;
     w.xproj = io.xproj; w.xp_bs = io.xp_bs; w.xp_ld = io.xp_ld;
     w.cstate = io.cstate; w.c_bs = io.c_bs; w.c_ld = io.c_ld;
     {
@@ -687,7 +685,7 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
         if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: Winograd GEMM launch failed (rc=%d)", tag, rc);
     }
     {
-        const double outb = (io.out ? (double)B * H * W * N : 0.0) + (io.out_s3 ? 1.5 * B * H * W * N : 0.0) + (io.out2 ? (double)B * H * W * N / 4.0 : 0.0) +
+        const double outb = (io.out ? (double)B * H * W * N : 0.0) + (io.out2 ? (double)B * H * W * N / 4.0 : 0.0) +
                             (io.cstate ? 3.0 * B * H * W * N / 4.0 + (double)B * H * W * N : 0.0);
         ProfScope ps(ctx, "wino_output", 0.0, 4.0 * ((double)P * mt * N + outb), tag);
         const int rc = launch_wino_output(ctx->stream, w, io.cstate != nullptr);
@@ -719,16 +717,9 @@ static int pick_cfg(int M, int cout, int ks)
     return CFG_128x128;
 }
 
-// Split-bf16 hand-over between a Winograd layer and the 1x1 layer behind it (conv_6 -> 7, 9 -> 10, 11 -> 12, 14 -> 15, 16 -> 17):
-// the producer's output transform writes the activation as the three-term A operand of wino_gemm_s3.hip INSTEAD of the
-// fp32 tensor, the consumer runs as one split GEMM with bias + LeakyReLU in its epilogue.
-//   producer call: want = true on entry; rows / mp / buf set; done = true on return if the split tensor was written
-//   consumer call: done = true on entry: `in` is ignored, the rows are read from buf
-struct S3Handoff {
-    bool want = false, done = false;
-    unsigned short *buf = nullptr;
-    int mp = 0;
-};
+// A 1x1 layer with enough channels and pixels (conv_10 / 12 / 15 / 17 at the benched size) runs as ONE split GEMM straight on the
+// producing layer's fp32 activation: the kernel splits its A fragments itself (wino_gemm_s3.hip, VF), bias as an extra K stage,
+// LeakyReLU in the epilogue.  (Rounds 3-4 had the producer's output transform write pre-split rows for it.)
 static bool s3_1x1_eligible(const dt_ctx *ctx, const ConvLayer &L, long long M)
 {
     return L.ks == 1 && L.wt_s3 && ctx->pol.s3 != 0 && ctx->pol.s3_1x1 != 0 && L.cin % 32 == 0 && L.cout % 128 == 0 && M < (1ll << 31) - 256 &&
@@ -736,19 +727,20 @@ static bool s3_1x1_eligible(const dt_ctx *ctx, const ConvLayer &L, long long M)
 }
 
 static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld, int B, int H, int W, float *out,
-                    int out_ld, int order, int epi, float slope, float *out2 = nullptr, int out2_ld = 0, S3Handoff *ho = nullptr)
+                    int out_ld, int order, int epi, float slope, float *out2 = nullptr, int out2_ld = 0)
 {
-    if (ho && ho->done) {      // consumer: the whole layer is one split GEMM over the producer's rows
-        if (L.ks != 1 || !L.wt_s3 || !L.bias_s3 || !ctx->s3_ones || epi != EPI_PLAIN || order != ORD_LINEAR || out_ld % 4) return dt_fail(ctx, DT_ERR_STATE, "conv_%d: split hand-over to a layer that cannot take it", L.idx);
+    if (L.bias_s3 && ctx->s3_ones && epi == EPI_PLAIN && order == ORD_LINEAR && !out2 && out_ld % 4 == 0 && in_ld % 4 == 0 &&
+        s3_1x1_eligible(ctx, L, (long long)B * H * W)) {
         const long long M = (long long)B * H * W;
         GemmS3Args g;
         memset(&g, 0, sizeof(g));
-        g.a = ho->buf; g.b = L.wt_s3; g.c = out; g.c_ps = 0; g.P = 1; g.Mt = (int)M; g.Mp = ho->mp; g.N = L.cout; g.Np = L.npad;
+        g.a_f32 = in; g.a_ld = in_ld; g.b = L.wt_s3; g.c = out; g.c_ps = 0; g.P = 1; g.Mt = (int)M; g.Mp = (int)((M + 255) / 256 * 256); g.N = L.cout; g.Np = L.npad;
         g.half = ctx->pol.s3_half;
-        g.K = L.cin; g.ldc = out_ld; g.ones = ctx->s3_ones; g.bias_s3 = L.bias_s3; g.act = slope != 1.0f; g.slope = slope;
+        g.K = L.cin; g.ldc = out_ld; g.ones = ctx->s3_ones; g.bias_s3 = L.bias_s3; g.act = 1; g.slope = slope;
         char tag[32];
         snprintf(tag, sizeof(tag), "conv_%d", L.idx);
-        ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), 6.0 * M * L.cin + 6.0 * (double)L.cin * L.cout + 4.0 * (double)M * L.cout, tag);
+        // bytes = A (fp32) + U (three bf16 terms) + out
+        ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), 4.0 * M * L.cin + 6.0 * (double)L.cin * L.cout + 4.0 * (double)M * L.cout, tag);
         prof_direct_form(ctx, 2.0 * M * (double)L.cin * L.cout, 4.0 * ((double)M * L.cin + (double)L.cin * L.cout + (double)M * L.cout), DF_S3);
         const int rc = launch_wino_gemm_s3(ctx->stream, g, 0);
         if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: split-bf16 1x1 GEMM launch failed (rc=%d)", tag, rc);
@@ -798,7 +790,6 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
         io.in = in; io.in_ld = in_ld; io.in_bs = a.in_bs;
         if (epi == EPI_POOL) { io.out2 = out; io.out2_ld = out_ld; }
         else { io.out = out; io.out_ld = out_ld; io.out_bs = a.out_bs; io.out2 = out2; io.out2_ld = out2_ld; }
-        const bool hand = ho && ho->want && epi == EPI_PLAIN && order == ORD_LINEAR && !out2 && L.wino_ts == 6 && L.cout % 16 == 0;
         // F(6x6) or F(4x4) for this launch: with many tiles F(6x6)'s fewer multiplies win; with a few frames the choice
         // is about how the positions x row tiles x column tiles spread over the CUs (small_gemm_cost)
         const float *wt = L.wino;
@@ -808,17 +799,6 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
             const WinoGeom q6 = wino_geometry(ctx, 6, B, H, W, pooled), q4 = wino_geometry(ctx, 4, B, H, W, pooled);
             const long long t6 = 64ll * ((q6.Mt + 127) / 128) * ((L.cout + 127) / 128);
             if (t6 <= 4096 && small_gemm_cost(q4.Mt, L.cout, 36, nullptr) < small_gemm_cost(q6.Mt, L.cout, 64, nullptr)) { wt = L.wino_alt; ts = 4; }
-        }
-        if (hand && ts == 6) {      // the consumer reads split rows: write those instead of the fp32 tensor
-            const long long M = (long long)B * H * W;
-            const long long mp = (M + 255) / 256 * 256;
-            unsigned short *rows = reinterpret_cast<unsigned short *>(ws_get(ctx, "act_s3", (size_t)3 * mp * L.cout * sizeof(unsigned short)));
-            if (!rows) return DT_ERR_DEVICE;
-            io.out = nullptr; io.out_s3 = rows; io.out_mp = (int)mp;
-            const int rc = run_wino(ctx, wt, ts, L.bias, L.cin, L.cout, L.npad, B, H, W, io, slope, tag);
-            if (rc) return rc;
-            ho->done = true; ho->buf = rows; ho->mp = (int)mp;
-            return DT_OK;
         }
         return run_wino(ctx, wt, ts, L.bias, L.cin, L.cout, L.npad, B, H, W, io, slope, tag);
     }
@@ -901,7 +881,6 @@ static int run_trunk(dt_ctx *ctx, int B, float *bufA, float *bufB, float *skip, 
     float *cur = bufA, *nxt = bufB;
     int h = H / 2, w = W / 2;
     int rc;
-    S3Handoff hand_in;       // set by the previous layer when this one takes split rows
     for (int li = 1; li < 20; ++li) {   // conv_2 .. conv_20
         const int idx = TRUNK[li][0], pool = TRUNK[li][4];
         const ConvLayer &L = ctx->layers[idx];
@@ -913,15 +892,7 @@ static int run_trunk(dt_ctx *ctx, int B, float *bufA, float *bufB, float *skip, 
         } else if (pool) {
             rc = run_conv(ctx, L, cur, L.cin, B, h, w, nxt, L.cout, ORD_QUAD, EPI_POOL, LEAKY);
         } else {
-            // a Winograd layer in front of an eligible 1x1 layer hands its activation over as split-bf16 rows (never while
-            // extracting: the fp32 tensor is then what the caller wants to see)
-            S3Handoff hand;
-            const int nidx = li + 1 < 20 ? TRUNK[li + 1][0] : 0;
-            hand.want = !ex && nidx != 13 && nidx != 20 && nidx > 0 && !TRUNK[li + 1][4] && s3_1x1_eligible(ctx, ctx->layers[nidx], (long long)B * h * w);
-            rc = run_conv(ctx, L, cur, L.cin, B, h, w, nxt, L.cout, ORD_LINEAR, EPI_PLAIN, LEAKY, nullptr, 0,
-                          hand_in.done ? &hand_in : (hand.want ? &hand : nullptr));
-            hand_in = S3Handoff();
-            if (hand.done) hand_in = hand;
+            rc = run_conv(ctx, L, cur, L.cin, B, h, w, nxt, L.cout, ORD_LINEAR, EPI_PLAIN, LEAKY);
         }
         if (rc) return rc;
         if (pool) { h /= 2; w /= 2; }

@@ -49,6 +49,24 @@ typedef const __attribute__((address_space(1))) void s3_gptr_t;
 #define S3_ABLATE 0      // probes (tools/micro/gemm_s3_bench.hip): 1 no DMA, 2 no operand reads, 4 no barrier, 8 DMA from one tile's panels only
 #endif
 
+// ---- the 1x1 layers' A operand arrives as plain fp32 rows (the producing layer's NHWC activation) and is split here ------------------
+typedef float s3_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 s3_bf2 __attribute__((ext_vector_type(2)));
+typedef unsigned s3_u4 __attribute__((ext_vector_type(4)));
+// The producers' split (winograd.hip:s3_split4: three roundings to nearest even), pair by pair: one v_cvt_pk_bf16_f32 per pair and
+// term, the pair widened again with a shift and a mask, the residual as one packed subtract -- 9 instructions per pair (left to
+// __builtin_convertvector on 8 lanes hipcc converts every element twice: 17 per pair).
+__device__ __forceinline__ unsigned s3_cvt2(const s3_f2 x) { return __builtin_bit_cast(unsigned, __builtin_convertvector(x, s3_bf2)); }
+__device__ __forceinline__ s3_f2 s3_up2(unsigned u) { return s3_f2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+__device__ __forceinline__ void s3_split_pair(const s3_f2 x, unsigned &h, unsigned &m, unsigned &l)
+{
+    h = s3_cvt2(x);
+    const s3_f2 r1 = x - s3_up2(h);
+    m = s3_cvt2(r1);
+    const s3_f2 r2 = r1 - s3_up2(m);
+    l = s3_cvt2(r2);
+}
+
 // vmcnt(N) alone (expcnt / lgkmcnt at their "don't wait" values); N < 64
 template <int N>
 __device__ __forceinline__ void s3_wait_vm() { __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14)); }
@@ -83,9 +101,16 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     constexpr int PV = (BM / 32) / NW;                // 32-row DMA pieces of a BM-row V region per wave
     constexpr int PU = (BN / 32) / NW > 0 ? (BN / 32) / NW : 1;   // ... of a BN-row U region (BN = 128, NW = 8: waves 0..3 only)
     constexpr bool U_HALF = (BN / 32) < NW;           // only the first BN / 32 waves move U rows
-    constexpr int PT = 3 * (PU + PV);                 // DMA instructions per wave per stage
+    // VF (the 1x1 instances, ACT): the A operand is the producing layer's fp32 activation [M][a_ld], read as it lies -- a stage is
+    // BM rows x 16 k x 4 bytes, 16 rows per 1 KiB DMA piece -- and split into its three bf16 terms when a wave reads its fragment
+    // (two ds_read_b128 + 36 VALU instructions per 32-row block and stage instead of three reads): 4 bytes per element from HBM
+    // instead of the 6 of a pre-split operand, and no producer kernel of its own (rounds 3-4 had the output transform in front of a
+    // 1x1 layer write split rows).  Same terms, same products, same order: bit-identical to the pre-split form.
+    constexpr bool VF = ACT;
+    constexpr int PVF = (BM / 16) / NW;               // 16-row pieces of the fp32 A region per wave
+    constexpr int PT = VF ? 3 * PU + PVF : 3 * (PU + PV);   // DMA instructions per wave per stage
     constexpr int OP_A = 3 * BN * 32;                 // bytes of U terms per stage
-    constexpr int STAGE = OP_A + 3 * BM * 32;      // + V terms
+    constexpr int STAGE = OP_A + (VF ? BM * 64 : 3 * BM * 32);      // + V (fp32 | terms)
     extern __shared__ __attribute__((aligned(16))) unsigned char s3_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
@@ -116,6 +141,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     // running DMA sources of this lane (term 0; the other terms sit a_term / b_term elements further): advanced by one
     // K block per stage, recomputed when the issue cursor enters a new tile
     const unsigned short *src_a = nullptr, *src_b = nullptr;
+    const float *src_af[PVF > 0 ? PVF : 1] = {};      // VF: this lane's 16 bytes of each of the wave's pieces: row lane >> 2 of the piece, granule (lane & 3) ^ ((row >> 2) & 3)
     long long ta = a_term, tb = b_term;      // term strides of the stage being issued
     // A 1x1 layer's bias rides in the GEMM as ONE extra K stage: A rows = [1, 0, ..., 0] (p.ones, the same 256 rows for every
     // tile), B rows = [bias[n], 0, ..., 0] as split terms (p.bias_s3) -- the three products b_t x 1.0 are among the six formed,
@@ -126,6 +152,14 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
         ta = a_term; tb = b_term;
         src_b = p.b + ((S3_ABLATE & 8) ? 0 : t.b0) + (long long)(32 * PU * wave + lrow) * 16 + dgran * 8;   // probe 8: every tile streams the same panels (L2 hits only)
         src_a = p.a + ((S3_ABLATE & 8) ? 0 : t.a0) + (long long)(32 * PV * wave + lrow) * 16 + dgran * 8;
+        if (VF) {
+#pragma unroll
+            for (int sp = 0; sp < PVF; ++sp) {
+                int row = t.m0 + 16 * (PVF * wave + sp) + (lane >> 2);
+                row = row < p.Mt ? row : p.Mt - 1;      // rows past the end re-read the last one (their results are never stored)
+                src_af[sp] = p.a_f32 + (long long)row * p.a_ld + ((lane & 3) ^ ((lane >> 4) & 3)) * 4;
+            }
+        }
     };
     // one stage = PT pieces per wave (term 0..2 x {U x PU, V x PV}); pieces [lo, hi) of the stage going to buffer `buf`
     auto issue_pieces = [&](int buf, int lo, int hi) {
@@ -139,16 +173,28 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                 if (k >= lo && k < hi && (!U_HALF || wave < BN / 32))
                     __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_b + t3 * tb + sp * 512),
                                                      (s3_lptr_t *)(dst + t3 * BN * 32 + (wave * PU + sp) * 1024), 16, 0, 0);
+            if (!VF) {
 #pragma unroll
-            for (int sp = 0; sp < PV; ++sp, ++k)
+                for (int sp = 0; sp < PV; ++sp, ++k)
+                    if (k >= lo && k < hi)
+                        __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_a + t3 * ta + sp * 512),
+                                                         (s3_lptr_t *)(dst + OP_A + t3 * BM * 32 + (wave * PV + sp) * 1024), 16, 0, 0);
+            }
+        }
+        if (VF) {
+#pragma unroll
+            for (int sp = 0; sp < PVF; ++sp, ++k)
                 if (k >= lo && k < hi)
-                    __builtin_amdgcn_global_load_lds((s3_gptr_t *)(src_a + t3 * ta + sp * 512),
-                                                     (s3_lptr_t *)(dst + OP_A + t3 * BM * 32 + (wave * PV + sp) * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((s3_gptr_t *)src_af[sp], (s3_lptr_t *)(dst + OP_A + (wave * PVF + sp) * 1024), 16, 0, 0);
         }
     };
     auto issue_done = [&]() {
         src_b += (long long)p.Np * 16;
         src_a += (long long)p.Mp * 16;
+        if (VF) {
+#pragma unroll
+            for (int sp = 0; sp < PVF; ++sp) src_af[sp] += 16;      // the next 16 channels of the same rows
+        }
     };
     // ---- operand read offsets (bytes inside a stage) ----
     const int rl = lane & 31, gl = lane >> 5;
@@ -162,6 +208,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     for (int i = 0; i < MB; ++i) {
         const int row = wm * (MB * 32) + 32 * i + rl;
         offV[i] = OP_A + (2 * row + (gl ^ ((row >> 3) & 1))) * 16;
+        if (VF) offV[i] = OP_A + row * 64 + (((2 * gl) ^ ((row >> 2) & 3)) * 16);      // the first of the lane's two fp32 granules (k = 8 gl .. + 3); the second: offset ^ 16
     }
 
     if (first >= ntiles) return;
@@ -171,6 +218,11 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
         ++c.kb;
         if (c.kb == KB && KBX > KB) {          // next: the bias stage of this tile
             src_a = p.ones + (long long)(32 * PV * wave + lrow) * 16 + dgran * 8; ta = 256 * 16;      // p.ones is [3][256][16] whatever the tile height
+            if (VF) {      // ... and [256][16] floats, rows (1, 0, .., 0), for the fp32 form
+#pragma unroll
+                for (int sp = 0; sp < PVF; ++sp)
+                    src_af[sp] = reinterpret_cast<const float *>(p.ones) + (long long)(16 * (PVF * wave + sp) + (lane >> 2)) * 16 + ((lane & 3) ^ ((lane >> 4) & 3)) * 4;
+            }
             src_b = p.bias_s3 + (long long)(c.t.n0 + 32 * PU * wave + lrow) * 16 + dgran * 8; tb = (long long)p.Np * 16;
         } else if (c.kb == KBX) {
             c.kb = 0; c.L += G;
@@ -206,16 +258,17 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
         }
         return *reinterpret_cast<const s3_bf8 *>(sb + off);
     };
+    auto fragf = [&](const unsigned char *sb, int off) { return *reinterpret_cast<const s3_f4 *>(sb + off); };
     // wait until at most `keep` of this wave's DMA stages are still in flight (PT pieces per stage; 3 PV for the waves
     // that move no U rows when BN = 128 at eight waves)
     auto wait_dma = [&](int keep) {
         if (keep <= 0) s3_wait_vm<0>();
         else if (keep == 1) {
             if (!U_HALF || wave < BN / 32) s3_wait_vm<PT>();
-            else s3_wait_vm<3 * PV>();
+            else s3_wait_vm<(VF ? PVF : 3 * PV)>();
         } else {
             if (!U_HALF || wave < BN / 32) s3_wait_vm<2 * PT>();
-            else s3_wait_vm<6 * PV>();
+            else s3_wait_vm<(VF ? 2 * PVF : 6 * PV)>();
         }
     };
 
@@ -228,12 +281,26 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     {
         const unsigned char *sb = s3_lds;
 #pragma unroll
-        for (int i = 0; i < MB; ++i)
+        for (int i = 0; i < MB; ++i) {
+            if (VF) {
+                const s3_f4 lo = fragf(sb, offV[i]), hi = fragf(sb, offV[i] ^ 16);
+                unsigned t[3][4];
+                s3_split_pair(s3_f2{lo[0], lo[1]}, t[0][0], t[1][0], t[2][0]);
+                s3_split_pair(s3_f2{lo[2], lo[3]}, t[0][1], t[1][1], t[2][1]);
+                s3_split_pair(s3_f2{hi[0], hi[1]}, t[0][2], t[1][2], t[2][2]);
+                s3_split_pair(s3_f2{hi[2], hi[3]}, t[0][3], t[1][3], t[2][3]);
 #pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = frag(sb, offV[i] + t3 * BM * 32);
+                for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = __builtin_bit_cast(s3_bf8, s3_u4{t[t3][0], t[t3][1], t[t3][2], t[t3][3]});
+            } else {
+#pragma unroll
+                for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = frag(sb, offV[i] + t3 * BM * 32);
+            }
+        }
 #pragma unroll
         for (int t3 = 0; t3 < 3; ++t3) ua[t3] = frag(sb, offU[0] + t3 * BN * 32);
     }
+    [[maybe_unused]] s3_f4 vraw[MB][2];             // VF: the next stage's fp32 fragments ...
+    [[maybe_unused]] unsigned vnu[MB][3][4];        // ... and their terms, built pair by pair
     bool drain = false;       // global stores were issued since the last full wait
 #ifdef S3_TIMING
     unsigned long long tm_lgkm = 0, tm_vm = 0, tm_bar = 0, tm_n = 0;
@@ -300,13 +367,16 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                 //   3 MB + 3 reads), then this group's share of the DMA pieces
                 constexpr int per = (PT + NBW - 1) / NBW, ng = (PT + per - 1) / per;   // pieces per group, groups that carry pieces
                 const int g = (j + 1) % NBW;                             // groups since the barrier: 0 = the barrier's own group
-                const int n_reads = (j == NBW - 1) ? 3 * MB + 3 : 3;
+                constexpr int VR = VF ? 2 * MB : 3 * MB;                  // V fragment reads of the next stage (last group)
+                const int n_reads = (j == NBW - 1) ? VR + 3 : 3;
                 const int n_side = n_reads + ((g < ng) ? per : 0);
                 auto side = [&](int k) {
                     if (k < n_reads) {
                         if (j == NBW - 1) {
-                            if (k < 3 * MB) vn[k / 3][k % 3] = frag(sn, offV[k / 3] + (k % 3) * BM * 32);
-                            else (j & 1 ? ua : ub)[k - 3 * MB] = frag(sn, offU[0] + (k - 3 * MB) * BN * 32);
+                            if (k < VR) {
+                                if (VF) vraw[k / 2][k % 2] = fragf(sn, offV[k / 2] ^ ((k % 2) * 16));
+                                else vn[k / 3][k % 3] = frag(sn, offV[k / 3] + (k % 3) * BM * 32);
+                            } else (j & 1 ? ua : ub)[k - VR] = frag(sn, offU[0] + (k - VR) * BN * 32);
                         } else
                             (j & 1 ? ua : ub)[k] = frag(sb, offU[j + 1] + k * BN * 32);
                     } else if (iss_go) {
@@ -317,9 +387,28 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                 };
                 {
                     constexpr int UT[6] = {2, 1, 0, 1, 0, 0}, VT[6] = {0, 1, 2, 0, 1, 0};
+                    // VF, last group: the next stage's fp32 fragments were requested in slots 0 .. 2 MB - 1; their split -- 4 MB pairs of
+                    // 9 VALU instructions, about one MFMA's shadow each -- goes pair by pair into the slots behind the reads, two pairs
+                    // per slot towards the end, the rest behind the group's last MFMA
+                    auto split_pair = [&](int q) {      // pair q % 4 of block q / 4
+                        const int i = q >> 2, e = q & 3;
+                        const s3_f4 &src = vraw[i][e >> 1];
+                        s3_split_pair(s3_f2{src[2 * (e & 1)], src[2 * (e & 1) + 1]}, vnu[i][0][e], vnu[i][1][e], vnu[i][2][e]);
+                    };
+                    constexpr int NPAIR = 4 * MB, SLOT0 = 2 * MB + 3, NSLOT = 6 * MB - 1 - SLOT0;
+                    auto split_slot = [&](int sidx) {
+                        if (!(VF && j == NBW - 1) || sidx < SLOT0) return;
+                        const int r = sidx - SLOT0;
+                        const int lo = r < NSLOT - 2 ? r : (NSLOT - 2) + 2 * (r - (NSLOT - 2));
+                        const int hi = r < NSLOT - 2 ? lo + 1 : lo + 2;
+#pragma unroll
+                        for (int q = 0; q < NPAIR; ++q)
+                            if (q >= lo && q < hi) split_pair(q);
+                    };
 #pragma unroll
                     for (int m = 1; m < 6 * MB; ++m) {
                         if (m - 1 < n_side) side(m - 1);                 // (indices are compile-time constants after unrolling)
+                        split_slot(m - 1);
                         const int pr = m / MB, i = m % MB;
                         s3_mfma(acc[j][i], u[UT[pr]], v[i][VT[pr]]);
                         __builtin_amdgcn_sched_barrier(0);
@@ -327,13 +416,19 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
 #pragma unroll
                     for (int kk = 6 * MB - 1; kk < 3 * MB + 3 + per; ++kk)    // (more side work than MFMA slots: MB = 2, last group)
                         if (kk < n_side) side(kk);
+                    if (VF && j == NBW - 1) {
+#pragma unroll
+                        for (int q = 0; q < NPAIR; ++q)
+                            if (q >= (NSLOT - 2) + 4) split_pair(q);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = vn[i][t3];
+                for (int t3 = 0; t3 < 3; ++t3)
+                    v[i][t3] = VF ? __builtin_bit_cast(s3_bf8, s3_u4{vnu[i][t3][0], vnu[i][t3][1], vnu[i][t3][2], vnu[i][t3][3]}) : vn[i][t3];
         }
 
         if (ACT) {      // a 1x1 layer: LeakyReLU (its bias came in through the extra K stage).  ALL of it before the first store:
@@ -430,7 +525,7 @@ template <int BN, int NW, bool ACT>
 static int s3_launch(hipStream_t st, const GemmS3Args &a, long long grid)
 {
     static PerDeviceOnce attr;
-    const size_t lds = (size_t)3 * (3 * BN * 32 + 3 * 256 * 32);
+    const size_t lds = (size_t)3 * (3 * BN * 32 + (ACT ? 256 * 64 : 3 * 256 * 32));      // ACT: the fp32 A stage
     if (attr.ensure(nullptr, [&](int) {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_kernel<BN, NW, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess;
         }))
@@ -442,7 +537,7 @@ template <int BN, bool ACT>
 static int s3_launch_half(hipStream_t st, const GemmS3Args &a, long long grid)
 {
     static PerDeviceOnce attr;
-    const size_t lds = (size_t)2 * (3 * BN * 32 + 3 * 128 * 32);
+    const size_t lds = (size_t)2 * (3 * BN * 32 + (ACT ? 128 * 64 : 3 * 128 * 32));
     if (attr.ensure(nullptr, [&](int) {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_half_kernel<BN, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess;
         }))
@@ -482,6 +577,9 @@ int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
 {
     if (!wino_gemm_s3_usable(a.Mt, a.K, a.N) || a.Mp % 256 || a.Mp < a.Mt || a.ldc % 4 || a.P <= 0) return 2;
     if ((a.bias_s3 != nullptr) != (a.ones != nullptr)) return 2;
+    // the 1x1 form: A = fp32 rows [Mt][a_ld] (a_f32), P = 1, LeakyReLU(slope) in the epilogue (slope 1 = none); the Winograd form: A = split terms (a)
+    if (a.a_f32 ? (a.P != 1 || a.a_ld % 4 || a.a_ld < a.K || (reinterpret_cast<uintptr_t>(a.a_f32) & 15)) : (a.a == nullptr || a.act)) return 2;
+    const bool act = a.a_f32 != nullptr;
     const bool wide = a.N % 256 == 0 && a.Np % 256 == 0;
     if (!wide && a.Np % 128) return 2;
     const int BN = wide ? 256 : 128;
@@ -499,12 +597,12 @@ int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
     if (half && wide) {
         long long grid = 2ll * cus;
         if (grid > tiles_h) grid = tiles_h;
-        return a.act ? s3_launch_half<256, true>(st, a, grid) : s3_launch_half<256, false>(st, a, grid);
+        return act ? s3_launch_half<256, true>(st, a, grid) : s3_launch_half<256, false>(st, a, grid);
     }
     long long grid = cus;      // one workgroup per CU (108 / 144 KiB of LDS), persistent over the tiles
     if (grid > tiles) grid = tiles;
     const int nw = a.waves == 8 ? 8 : (a.waves == 4 ? 4 : S3_DEFAULT_WAVES);
-    if (a.act) return wide ? s3_launch<256, 8, true>(st, a, grid) : s3_launch<128, 8, true>(st, a, grid);
+    if (act) return wide ? s3_launch<256, 8, true>(st, a, grid) : s3_launch<128, 8, true>(st, a, grid);
 #ifdef S3_WITH_4WAVES      // the one-wave-per-SIMD form (micro-benchmark builds)
     if (nw == 4) {
         static PerDeviceOnce attr4[2];

@@ -672,7 +672,6 @@ if constexpr (ONE) {      // one LDS image, the two channel halves one after the
     }
 }
 
-template <bool S3OUT>      // S3OUT: the activation leaves as split-bf16 rows (p.out_s3) instead of p.out / p.out2
 __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArgs p)
 {
     typedef VecOf<4>::T T;
@@ -693,12 +692,9 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
         T bv = vzero<4>();                       // requested with the M' loads (not inside the divergent part: a second round trip per item)
         if (p.bias) bv = vload<4>(p.bias + c);
 #pragma unroll
-        // S3OUT takes the two passes in the other order (along the rows first), so that the LANES of the second pass are
-        // consecutive pixels of one image row: a store instruction then covers 6 pixels x 32 bytes of a K block contiguously
-        // instead of one 32-byte piece per image row
         for (int i = 0; i < 8; ++i)
-            col[i] = live ? vload_nt<4>(src + (long long)(S3OUT ? 8 * sub + i : 8 * i + sub) * plane) : vzero<4>();   // column nu = sub (S3OUT: row xi = sub)
-        at_1d<6>(col);                           // At m : down the column -> rows 0..5   (S3OUT: m A along the row -> columns 0..5)
+            col[i] = live ? vload_nt<4>(src + (long long)(8 * i + sub) * plane) : vzero<4>();   // column nu = sub
+        at_1d<6>(col);                           // At m : down the column -> rows 0..5
         asm volatile("" ::"v"(bv));
 #pragma unroll
         for (int i = 0; i < 6; ++i) vstore<4>(st + (sub * 9 + i) * 4, col[i]);
@@ -717,28 +713,11 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
                 for (int e = 0; e < 4; ++e) set_lane<4>(v, e, wino_leaky(lane_of<4>(v, e), p.slope));
                 row[j] = v;
                 int b, h, w;
-                if (!S3OUT && live && p.out && vpixel(p, t.grp, 6 * t.ty + sub, 6 * t.tx + j, b, h, w))
+                if (live && p.out && vpixel(p, t.grp, 6 * t.ty + sub, 6 * t.tx + j, b, h, w))
                     vstore_nt<4>(p.out + (long long)b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c, v);
             }
-            if (S3OUT) {      // the next layer's GEMM operand: three bf16 terms, K-blocked, row = pixel; this lane holds image column
-                              // `sub` of the tile, rows j = 0..5.  All splits before the first store, each in its own registers
-                wino_u2 tr[6][3];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) s3_split4(row[j], tr[j]);
-                __builtin_amdgcn_sched_barrier(0);
-                const long long term = (long long)(p.N >> 4) * p.out_mp * 16;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    int b, h, w;
-                    if (live && vpixel(p, t.grp, 6 * t.ty + j, 6 * t.tx + sub, b, h, w)) {
-                        unsigned short *d = p.out_s3 + ((long long)(c >> 4) * p.out_mp + ((long long)b * p.H + h) * p.W + w) * 16 + (c & 15);
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) s3_store<2>(d + k * term, tr[j][k]);
-                    }
-                }
-            }
         }
-        if (!S3OUT && p.out2) {   // MaxPooling2D(2,2) (g == 1: launcher): output rows 2k, 2k+1 sit in neighbouring lanes
+        if (p.out2) {   // MaxPooling2D(2,2) (g == 1: launcher): output rows 2k, 2k+1 sit in neighbouring lanes
             const int H2 = p.H >> 1, W2 = p.W >> 1;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -751,98 +730,6 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
                 const int h2 = 3 * t.ty + (sub >> 1), w2 = 3 * t.tx + k;
                 if (live && sub < 6 && !(sub & 1) && h2 < H2 && w2 < W2)
                     vstore<4>(p.out2 + ((long long)(t.grp * H2 + h2) * W2 + w2) * p.out2_ld + c, mx);
-            }
-        }
-        wino_item_sync();
-    }
-}
-// The split-row output for the 1x1 layer behind this one (p.out_s3), EIGHT channels per lane like wino_input_s3_kernel: along
-// the rows first, transpose, down the columns -- the lanes of the second pass are the 6 pixel columns of a tile, a wavefront holds
-// 4 channel octets x 2 consecutive tiles of a tile row: 128-byte runs of every M' plane on the read side (the larger stream), 12
-// consecutive pixels x 32 bytes of two K blocks per store instruction.  wino_output_coop6_kernel<true> is the 4-channel form (DT_WINO_COOP=0).
-__global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_output_s3_kernel(WinoArgs p)
-{
-    typedef VecOf<4>::T T;
-    constexpr int IPW = WINO_S3IN_THREADS / 8;
-    __shared__ __attribute__((aligned(16))) float s_t[WINO_ONE_IMAGE ? 1 : 2][IPW * WINO_COOP_ITEM];
-    const int mt4 = (p.Mt + 3) & ~3;
-    const long long items = (long long)mt4 * (p.N / 8);
-    const long long plane = (long long)p.Mt * p.m_ld;
-    const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;
-    float *st0 = s_t[0] + slot * WINO_COOP_ITEM;
-    [[maybe_unused]] float *st1 = s_t[WINO_ONE_IMAGE ? 0 : 1] + slot * WINO_COOP_ITEM;
-    const long long term = (long long)(p.N >> 4) * p.out_mp * 16;
-    for (long long base = (long long)blockIdx.x * IPW; base < items; base += (long long)gridDim.x * IPW) {
-        const long long it = base + slot;
-        const long long hi = it >> 4;                    // (k-block pair, tile group of 4), tile group fastest
-        const int tg = (int)(hi % (mt4 >> 2)), kp = (int)(hi / (mt4 >> 2));
-        int tile = tg * 4 + (int)((it >> 2) & 3);          // a wavefront: 4 octets (128 contiguous bytes of every M' plane) x 2 tiles
-        int c = kp * 32 + (int)(it & 3) * 8;
-        const bool live = it < items && tile < p.Mt;
-        if (!live) { tile = 0; c = 0; }
-        const TileId t = tile_id(p, tile);
-        T ca[8], cb[8];
-        const float *src = p.m + (long long)tile * p.m_ld + c;
-        // the bias goes out with the M' loads and is retired with them on the straight path: requested inside the lane-divergent
-        // part below, every store group got a vmcnt(0) -- a wait for the previous group's stores -- in front of it (round 4)
-        T ba = vzero<4>(), bb = vzero<4>();
-        if (p.bias) { ba = vload<4>(p.bias + c); bb = vload<4>(p.bias + c + 4); }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {           // row xi = sub of the 8x8 M' tile, all eight nu
-            ca[i] = live ? vload_nt<4>(src + (long long)(8 * sub + i) * plane) : vzero<4>();
-            cb[i] = live ? vload_nt<4>(src + (long long)(8 * sub + i) * plane + 4) : vzero<4>();
-        }
-        at_1d<6>(ca);                            // m A : along the row -> columns 0..5
-        at_1d<6>(cb);
-        asm volatile("" ::"v"(ba), "v"(bb));
-#if WINO_ONE_IMAGE      // one LDS image, the two channel halves one after the other (lanes 6, 7 read rows that were never written: unused)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]);
-        wino_item_sync();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ca[j] = vload<4>(st0 + (j * 9 + (sub < 6 ? sub : 0)) * 4);
-        wino_item_sync();
-#pragma unroll
-        for (int i = 0; i < 6; ++i) vstore<4>(st0 + (sub * 9 + i) * 4, cb[i]);
-        wino_item_sync();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) cb[j] = vload<4>(st0 + (j * 9 + (sub < 6 ? sub : 0)) * 4);
-#else
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { vstore<4>(st0 + (sub * 9 + i) * 4, ca[i]); vstore<4>(st1 + (sub * 9 + i) * 4, cb[i]); }
-        wino_item_sync();
-#endif
-        if (sub < 6) {
-#if !WINO_ONE_IMAGE
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { ca[j] = vload<4>(st0 + (j * 9 + sub) * 4); cb[j] = vload<4>(st1 + (j * 9 + sub) * 4); }
-#endif
-            at_1d<6>(ca);                        // At (m A) : down the column -> rows 0..5 of pixel column `sub`
-            at_1d<6>(cb);
-            wino_u4 o[6][3];                     // every split before the first store, each in its own registers
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                T va = ca[j] + ba, vb = cb[j] + bb;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    set_lane<4>(va, e, wino_leaky(lane_of<4>(va, e), p.slope));
-                    set_lane<4>(vb, e, wino_leaky(lane_of<4>(vb, e), p.slope));
-                }
-                wino_u2 ta[3], tb[3];
-                s3_split4(va, ta);
-                s3_split4(vb, tb);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) o[j][k] = wino_u4{ta[k][0], ta[k][1], tb[k][0], tb[k][1]};
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                int b, h, w;
-                if (live && vpixel(p, t.grp, 6 * t.ty + j, 6 * t.tx + sub, b, h, w)) {
-                    unsigned short *d = p.out_s3 + ((long long)(c >> 4) * p.out_mp + ((long long)b * p.H + h) * p.W + w) * 16 + (c & 15);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) s3_store<2>(d + k * term, o[j][k]);
-                }
             }
         }
         wino_item_sync();
@@ -935,16 +822,9 @@ int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates)
     } else {
         // vector stores need aligned rows; ragged N (conv_23-like heads) never takes this path
         if (a.N % 4 || (a.out && a.out_ld % 4) || (a.out2 && a.out2_ld % 4)) return 2;
-        if (a.out_s3 && (a.ts != 6 || a.N % 16 || a.out || a.out2 || (long long)a.B * a.H * a.W > a.out_mp)) return 2;
-        if (a.ts == 6 && (a.out_s3 || wino_coop_wanted(a, (long long)a.Mt * (a.N / 2)))) {
+        if (a.ts == 6 && wino_coop_wanted(a, (long long)a.Mt * (a.N / 2))) {
             const long long wgs = ((long long)a.Mt * (a.N / 4) + WINO_THREADS / 8 - 1) / (WINO_THREADS / 8);
-            // 8 channels per lane pays on the 26x26 layers (conv_9 / conv_11: 1.94 -> 1.64 ms per 1440 frames); on the 13x13 mosaics the
-            // 4-channel form at twice the occupancy is ahead (conv_14 / conv_16: 0.71 vs 0.85 ms)
-            if (a.out_s3 && a.coop != 0 && a.N % 32 == 0 && a.H * a.W >= 400) {
-                const long long wg8 = ((long long)((a.Mt + 3) & ~3) * (a.N / 8) + WINO_S3IN_THREADS / 8 - 1) / (WINO_S3IN_THREADS / 8);
-                hipLaunchKernelGGL(wino_output_s3_kernel, dim3((unsigned)(wg8 < 262144 ? wg8 : 262144)), dim3(WINO_S3IN_THREADS), 0, st, a);
-            } else if (a.out_s3) hipLaunchKernelGGL(wino_output_coop6_kernel<true>, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
-            else hipLaunchKernelGGL(wino_output_coop6_kernel<false>, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
+            hipLaunchKernelGGL(wino_output_coop6_kernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
         } else if (a.ts == 6)
             hipLaunchKernelGGL((wino_output_kernel<6, 2>), dim3(wino_blocks((long long)a.Mt * (a.N / 2))), dim3(wino_threads((long long)a.Mt * (a.N / 2))),
                                0, st, a);

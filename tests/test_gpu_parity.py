@@ -1449,17 +1449,17 @@ def test_split_bf16_default_policy_engages_on_deep_layers(ctx, monkeypatch):
 
 
 def test_split_bf16_handover_to_1x1_layers(ctx, monkeypatch):
-    """conv_6 -> 7, 9 -> 10, 11 -> 12, 14 -> 15, 16 -> 17: the Winograd layer's output transform writes the split-bf16 rows
-    the 1x1 layer's GEMM reads (DT_S3_1X1=1, the default) instead of the fp32 tensor.  Same network output as with the
-    hand-over off (fp32 MFMA 1x1 layers), and the oracle's on the frames the oracle is run on."""
+    """conv_7, 10, 12, 15, 17 as split GEMMs straight on the producing layer's fp32 activation (DT_S3_1X1=1, the default: the kernel
+    splits its A fragments itself, bias as an extra K stage, LeakyReLU in its epilogue) against the same network with those layers
+    on the fp32 MFMA kernel, and against the oracle on the frames the oracle is run on."""
     B, H, W, C = 16, 416, 416, 12
     frames = np.random.RandomState(3).randint(0, 256, (B, H, W, 3)).astype(np.uint8)
     outs = {}
     layers = None
     for mode in ("1", "0"):
         monkeypatch.setenv("DT_S3_1X1", mode)          # read when the context is created (dt_create)
-        monkeypatch.setenv("DT_S3_1X1_MINK", "256")    # every eligible pair (the default policy: K >= 512 -- conv_10 / 12 / 15 / 17 --
-        monkeypatch.setenv("DT_S3_1X1_MINROWS", "0")   # and from 16384 pixels per launch)
+        monkeypatch.setenv("DT_S3_1X1_MINK", "256")    # (the default)
+        monkeypatch.setenv("DT_S3_1X1_MINROWS", "0")   # (the default policy takes these layers from 16384 pixels per launch)
         det, layers, _ = _detector(ctx, H, W, C, seed=77)
         c = det.model.ctx
         c.profile_reset(); c.profile_enable(True)
