@@ -279,7 +279,8 @@ DT_API int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int W, 
  * tests can check the kernel against float64 AT THE SHAPES bench.py runs (P = 64, Mt = 7840, K = 1024 / 1280, ...):
  *   d_v [P][Mt][K], d_u [P][N][K] float32  ->  d_m [P][Mt][N] = sum_k v * u     (K % 32 == 0, N % 128 == 0)
  * Both operands are split into three bf16 terms on the device by the production pack kernel, then the production
- * launcher runs.  half: 0 = the launcher's own choice of row tile, 1 = 128-row tiles (two workgroups per CU), -1 = 256. */
+ * launcher runs.  half: 0 = the launcher's own choice of row tile, 1 = 128-row tiles (two workgroups per CU), -1 = 256;
+ * 2 = the 1x1 layers' form (P = 1): d_v is read as fp32 rows by the kernel itself, which splits its A fragments in registers. */
 DT_API int dt_gemm_split_bf16(dt_ctx *ctx, const float *d_v, const float *d_u, int P, int Mt, int K, int N, int half,
                               float *d_m);
 

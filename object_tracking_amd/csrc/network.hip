@@ -1788,6 +1788,9 @@ extern "C" int dt_gemm_split_bf16(dt_ctx *ctx, const float *d_v, const float *d_
     if (!ctx || !d_v || !d_u || !d_m) return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (P <= 0 || Mt <= 0 || K <= 0 || N <= 0 || K % 32 || N % 128 || !wino_gemm_s3_usable(Mt, K, N))
         return dt_fail(ctx, DT_ERR_ARG, "dt_gemm_split_bf16: unsupported shape P=%d Mt=%d K=%d N=%d", P, Mt, K, N);
+    const bool rows_form = half == 2;      // the 1x1 layers' form: the kernel reads d_v as fp32 rows and splits its fragments itself
+    if (rows_form && P != 1) return dt_fail(ctx, DT_ERR_ARG, "dt_gemm_split_bf16: the fp32-rows form is one GEMM (P = 1)");
+    if (rows_form) half = 0;
     const size_t Mp = ((size_t)Mt + 255) / 256 * 256, Np = ((size_t)N + 255) / 256 * 256;
     DevTemps tmp(ctx->stream);
     tmp.p.reserve(4);
@@ -1808,6 +1811,7 @@ extern "C" int dt_gemm_split_bf16(dt_ctx *ctx, const float *d_v, const float *d_
     GemmS3Args g;
     memset(&g, 0, sizeof(g));
     g.a = reinterpret_cast<unsigned short *>(*vs); g.b = reinterpret_cast<unsigned short *>(*us); g.c = d_m;
+    if (rows_form) { g.a = nullptr; g.a_f32 = d_v; g.a_ld = K; g.act = 1; g.slope = 1.0f; }      // (no bias stage, no activation)
     g.c_ps = (long long)Mt * N; g.P = P; g.Mt = Mt; g.Mp = (int)Mp; g.N = N; g.Np = (int)Np; g.K = K; g.ldc = N; g.half = half;
     ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), (double)P * (6.0 * Mt * K + 6.0 * (double)K * N + 4.0 * (double)Mt * N), "test_gemm");
     if (ctx->prof && !ctx->capturing) ctx->prof_tab[wino_gemm_s3_half_chosen(g, 0) ? "s3_tile:128x2" : "s3_tile:256"].launches += 1;

@@ -1373,7 +1373,9 @@ def test_split_bf16_gemm_error_against_float64(ctx, monkeypatch):
     (64, 29160, 256, 512, -1, "conv_9 / conv_11 (26x26 on 2x2 mosaics)"),
     (36, 588, 512, 2048, 1, "convlstm_step at 48 clips: F(4x4), 128-row tiles, two workgroups per CU"),
     (36, 588, 512, 2048, -1, "convlstm_step, 256-row tiles"),
-    (1, 243360, 1024, 512, -1, "conv_15 / conv_17 as one split GEMM over 1440 x 169 pixels"),
+    (1, 243360, 1024, 512, 2, "conv_15 / conv_17 as one split GEMM over 1440 x 169 pixels: A read as fp32 rows, split in the kernel"),
+    (1, 973440, 512, 256, 2, "conv_10 / conv_12 over 1440 x 676 pixels, the same form"),
+    (1, 500000, 256, 128, 2, "conv_7's shape (K = 256, 128-column tile), the same form"),
 ])
 def test_split_bf16_gemm_benched_shapes_against_float64(ctx, P, Mt, K, N, half, what):
     """wino_gemm_s3.hip AT THE SHAPES THE BENCH STEP LAUNCHES (48 clips x 30 frames x 416x416), through the production
@@ -1390,7 +1392,7 @@ def test_split_bf16_gemm_benched_shapes_against_float64(ctx, P, Mt, K, N, half, 
     ctx.profile_reset(); ctx.profile_enable(True)
     got = ctx.gemm_split_bf16(v, u, half=half)
     ctx.profile_enable(False)
-    assert ctx.profile_read("s3_tile:128x2" if half > 0 else "s3_tile:256")["launches"] == 1
+    assert ctx.profile_read("s3_tile:128x2" if half == 1 else "s3_tile:256")["launches"] == 1
     se = sf = 0.0
     me = mf = 0.0
     n = 0
