@@ -717,7 +717,7 @@ static int pick_cfg(int M, int cout, int ks)
     return CFG_128x128;
 }
 
-// A 1x1 layer with enough channels and pixels (conv_10 / 12 / 15 / 17 at the benched size) runs as ONE split GEMM straight on the
+// A 1x1 layer with enough channels and pixels (conv_7 / 10 / 12 / 15 / 17 at the benched size) runs as ONE split GEMM straight on the
 // producing layer's fp32 activation: the kernel splits its A fragments itself (wino_gemm_s3.hip, VF), bias as an extra K stage,
 // LeakyReLU in the epilogue.  (Rounds 3-4 had the producer's output transform write pre-split rows for it.)
 static bool s3_1x1_eligible(const dt_ctx *ctx, const ConvLayer &L, long long M)

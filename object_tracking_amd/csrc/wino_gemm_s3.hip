@@ -1,8 +1,8 @@
 // wino_gemm_s3.hip -- the batched GEMMs  M'[p] = V[p] (Mt x K)  *  U[p]^T (N x K)  of the Winograd-form layers on the BF16
 // matrix pipe at fp32 accuracy: the arithmetic of the reference's Conv2D layers conv_9 .. conv_22
 // (models_detection/KerasYOLO.py:323-396), of ConvLSTM2D's input and recurrent convolutions
-// (models_tracking/MultiObjDetTracker.py:160-189) once they are in F(6x6,3x3) / F(4x4,3x3) form, and of four 1x1 Conv2D layers
-// (conv_10 / 12 / 15 / 17) as plain GEMMs (P = 1).  DESIGN.md section 4.2f.
+// (models_tracking/MultiObjDetTracker.py:160-189) once they are in F(6x6,3x3) / F(4x4,3x3) form, and of five 1x1 Conv2D layers
+// (conv_7 / 10 / 12 / 15 / 17) as plain GEMMs (P = 1) straight on their fp32 input.  DESIGN.md section 4.4.
 //
 // gfx950 has no fp32-rate shortcut (v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate, no xf32), so each fp32
 // operand is carried as THREE bf16 terms   x = x1 + x2 + x3   (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2):
@@ -13,10 +13,10 @@
 // cycles instead of eight fp32 MFMAs of 64 (2.67x fewer matrix-pipe cycles), with errors at the level of fp32's own product
 // rounding (tests/test_gpu_parity.py::test_split_bf16_gemm_error_against_float64: not above the fp32 MFMA path's).
 //
-// Operands arrive ALREADY split, from their producers: V from the input transforms (winograd.hip: wino_input_s3_kernel,
-// wino_input_kernel<4,4,S3>), the 1x1 layers' activations from the producing layer's output transform
-// (wino_output_s3_kernel), U split on the device at load time (wino_s3_pack_kernel).  All are K-blocked so that the 16-deep
-// stage of a 256-row tile is ONE contiguous 8 KiB run per term:     [p][term 3][K/16][rows][16] bf16.
+// The Winograd operands arrive ALREADY split, from their producers: V from the input transforms (winograd.hip:
+// wino_input_s3_kernel, wino_input_kernel<4,4,S3>), U split on the device at load time (wino_s3_pack_kernel); both K-blocked so
+// that the 16-deep stage of a 256-row tile is ONE contiguous 8 KiB run per term:     [p][term 3][K/16][rows][16] bf16.
+// A 1x1 layer's activation is NOT pre-split: the kernel reads the fp32 NHWC tensor and splits its fragments in registers (VF below).
 //
 // Kernel: persistent; tile = BM rows of V x BN (256 | 128) rows of U; k in stages of 16 through an LDS ring filled by
 // global_load_lds_dwordx4 in 1 KiB pieces, the next tile's first stages in flight during a tile's epilogue.  Two forms:

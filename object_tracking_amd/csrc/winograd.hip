@@ -187,9 +187,8 @@ __device__ __forceinline__ void s3_split4(const VecOf<4>::T x, wino_u2 t[3])
 }
 
 #ifndef WINO_S3_NT
-#define WINO_S3_NT 1      // bit 0: the V terms of the input transforms, bit 1: the split rows of the output transforms, as nontemporal stores.
-#endif                    // Measured (profiles/r04_experiments.txt): V terms 11.6 -> 11.1 ms per step, split rows 14.6 -> 15.0-15.4 (the 1x1 GEMM
-                          // behind reads the rows at once: they want to stay in L2) -> default: V terms only
+#define WINO_S3_NT 1      // bit 0: the V terms of the input transforms as nontemporal stores (measured, profiles/r04_experiments.txt: 11.6 -> 11.1 ms per step)
+#endif
 template <int BIT, typename T> __device__ __forceinline__ void s3_store(unsigned short *p, const T &v)
 {
     if (WINO_S3_NT & BIT) __builtin_nontemporal_store(v, reinterpret_cast<T *>(p));
