@@ -288,8 +288,9 @@ struct Policy {
     int s3_half = 0;          // DT_S3_HALF: 128-row tiles / two workgroups per CU in the split GEMM: 0 where it needs fewer rounds (default) / 1 always (N % 256 == 0) / -1 never
     int s3_rec_minrows = 512; // DT_S3_REC_MINROWS: the ConvLSTM recurrent step's F(4x4) GEMM (gate update in its output transform) takes the split
                               //                    kernel from this many GEMM rows (48 clips at 13x13: 588); 0 = never
-    int s3_1x1_mink = 256;   // DT_S3_1X1_MINK: ... only for 1x1 layers with at least this many input channels (conv_7 / 10 / 12 / 15 / 17; 256 since the
-                             //                  kernel reads the fp32 activation itself: conv_7 2.36 -> 1.63 ms per 1440 frames)
+    int s3_1x1_mink = 256;   // DT_S3_1X1_MINK: ... only for 1x1 layers with at least this many input channels (conv_7 / 10 / 12 / 15 / 17 / 23; 512 while the
+                             //                  producer had to write split rows -- the kernel reads the fp32 activation itself since round 4; conv_4 at
+                             //                  K = 128, N = 64 measured 3.55 ms there against 2.85 on the fp32 kernel)
     int s3_1x1_minrows = 16384;   // DT_S3_1X1_MINROWS: ... and at least this many pixels: one split GEMM of a 1x1 layer has M / 256 row tiles and no split-K, so at
                                   // batch 8 (conv_10 / 12: 5408 rows = 22 workgroups) the fp32 kernel with split-K is faster (0.035 vs 0.061 ms)
     int s3_1x1 = 1;          // DT_S3_1X1: the 1x1 layers with N % 128 == 0 run on wino_gemm_s3.hip straight from the fp32 activation (the kernel splits

@@ -291,7 +291,7 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
     if (rc) return rc;
     if (L.wt_s3) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wt_s3); L.wt_s3 = nullptr; }
     if (L.bias_s3) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.bias_s3); L.bias_s3 = nullptr; }
-    if (ks == 1 && ctx->pol.s3 != 0 && ctx->pol.s3_1x1 != 0 && cin % 32 == 0 && L.npad % 128 == 0 && cout % 128 == 0) {
+    if (ks == 1 && ctx->pol.s3 != 0 && ctx->pol.s3_1x1 != 0 && cin % 32 == 0 && L.npad % 128 == 0 && cout >= 64) {
         // a 1x1 layer's weights are a plain [npad][cin] matrix: also as the split-bf16 B operand of wino_gemm_s3.hip
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&L.wt_s3), packed.size() * 3 * sizeof(unsigned short)));
         if (launch_wino_s3_pack(ctx->stream, L.wt, 1, L.npad, cin, L.wt_s3)) return dt_fail(ctx, DT_ERR_DEVICE, "split-bf16 weight pack launch failed");
@@ -722,7 +722,7 @@ static int pick_cfg(int M, int cout, int ks)
 // LeakyReLU in the epilogue.  (Rounds 3-4 had the producer's output transform write pre-split rows for it.)
 static bool s3_1x1_eligible(const dt_ctx *ctx, const ConvLayer &L, long long M)
 {
-    return L.ks == 1 && L.wt_s3 && ctx->pol.s3 != 0 && ctx->pol.s3_1x1 != 0 && L.cin % 32 == 0 && L.cout % 128 == 0 && M < (1ll << 31) - 256 &&
+    return L.ks == 1 && L.wt_s3 && ctx->pol.s3 != 0 && ctx->pol.s3_1x1 != 0 && L.cin % 32 == 0 && L.cout >= 64 && M < (1ll << 31) - 256 &&
            (ctx->pol.s3 == 2 || (L.cin >= ctx->pol.s3_mink && L.cin >= ctx->pol.s3_1x1_mink && M >= ctx->pol.s3_minrows && M >= ctx->pol.s3_1x1_minrows));
 }
 

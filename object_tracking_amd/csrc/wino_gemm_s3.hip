@@ -115,7 +115,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int KB = p.K >> 4;
-    const int MT = (p.Mt + BM - 1) / BM, NT = p.N / BN;
+    const int MT = (p.Mt + BM - 1) / BM, NT = (p.N + BN - 1) / BN;      // (a ragged N only in the 1x1 form: its columns past N meet zero rows of U and are not stored)
     const int ntiles = p.P * MT * NT;              // < 2^31 (launcher)
     // XCD-aware order: workgroup w runs on XCD w % 8; each XCD walks a contiguous range of the n-fastest tile order, so
     // the 32 tiles resident on an XCD share their V / U panels through that XCD's L2
@@ -444,6 +444,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
 #if S3_EPI_ROWS
         // ---- epilogue: lane holds, per block, column n = n0 + (lane & 31) of rows m = m0 + 8 (r / 4) + 4 (lane >> 5) + r % 4 ----
         float *cz = p.c + (long long)cur.pz * p.c_ps + cur.n0 + wn * (BN / 2) + rl;
+        const int ncol = ACT ? p.N - (cur.n0 + wn * (BN / 2) + rl) : BN;      // columns of this lane's 32-column blocks that exist: 32 j < ncol
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             const int mb = cur.m0 + wm * (MB * 32) + 32 * i + 4 * gl;
@@ -453,7 +454,8 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                 if (m < p.Mt) {
                     float *row = cz + (long long)m * p.ldc;
 #pragma unroll
-                    for (int j = 0; j < NBW; ++j) __builtin_nontemporal_store(acc[j][i][r], row + 32 * j);
+                    for (int j = 0; j < NBW; ++j)
+                        if (!ACT || 32 * j < ncol) __builtin_nontemporal_store(acc[j][i][r], row + 32 * j);
                 }
             }
         }
@@ -575,7 +577,9 @@ bool wino_gemm_s3_half_chosen(const GemmS3Args &a, int cus)
 
 int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
 {
-    if (!wino_gemm_s3_usable(a.Mt, a.K, a.N) || a.Mp % 256 || a.Mp < a.Mt || a.ldc % 4 || a.P <= 0) return 2;
+    // the Winograd form needs whole 128-column tiles; the 1x1 form (a_f32) any N >= 64 up to its padded weight rows Np
+    if (a.a_f32 ? (a.Mt <= 0 || a.K < 32 || a.K % 16 || a.N < 64 || a.N > a.Np) : !wino_gemm_s3_usable(a.Mt, a.K, a.N)) return 2;
+    if (a.Mp % 256 || a.Mp < a.Mt || a.ldc % 4 || a.P <= 0) return 2;
     if ((a.bias_s3 != nullptr) != (a.ones != nullptr)) return 2;
     // the 1x1 form: A = fp32 rows [Mt][a_ld] (a_f32), P = 1, LeakyReLU(slope) in the epilogue (slope 1 = none); the Winograd form: A = split terms (a)
     if (a.a_f32 ? (a.P != 1 || a.a_ld % 4 || a.a_ld < a.K || (reinterpret_cast<uintptr_t>(a.a_f32) & 15)) : (a.a == nullptr || a.act)) return 2;
@@ -583,8 +587,8 @@ int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
     const bool wide = a.N % 256 == 0 && a.Np % 256 == 0;
     if (!wide && a.Np % 128) return 2;
     const int BN = wide ? 256 : 128;
-    const long long tiles = (long long)a.P * ((a.Mt + 255) / 256) * (a.N / BN);
-    const long long tiles_h = (long long)a.P * ((a.Mt + 127) / 128) * (a.N / BN);
+    const long long tiles = (long long)a.P * ((a.Mt + 255) / 256) * ((a.N + BN - 1) / BN);
+    const long long tiles_h = (long long)a.P * ((a.Mt + 127) / 128) * ((a.N + BN - 1) / BN);
     if (tiles_h >= (1ll << 31) - 65536) return 2;
     cus = s3_cus(cus);
     if (cus <= 0) return 1;
