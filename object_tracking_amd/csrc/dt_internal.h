@@ -152,6 +152,10 @@ struct Wino4FusedArgs {
 // U staged through LDS by DMA, in-register output transform, persistent over (block pair, 64-channel slice) items
 int launch_wino4s_fused(hipStream_t st, const Wino4FusedArgs &a, const float *zeros);
 void wino4s_fused_pack(const float *u36, int npad, int cin, int cout, float *dst);
+// the same layers on the BF16 matrix pipe with three-term split operands and an accumulated output transform (wino4b_fused.hip): items of
+// 64 tiles x 64 channels, a.u = the bf16 stage images of wino4b_fused_pack (36 * cin * cout * 3 unsigned shorts)
+int launch_wino4b_fused(hipStream_t st, const Wino4FusedArgs &a, const float *zeros);
+void wino4b_fused_pack(const float *u36, int npad, int cin, int cout, unsigned short *dst);
 // split-bf16 batched GEMM of the F(6x6,3x3) layers (wino_gemm_s3.hip): fp32 operands as three bf16 terms, six MFMAs per product
 struct GemmS3Args {
     const unsigned short *a;   // V terms  [P][3][K/16][Mp][16]   (winograd.hip split input transform) -- the Winograd GEMMs; null for a 1x1 layer:
@@ -261,6 +265,7 @@ struct ConvLayer {
     int wino_ts = 0;                     // their output tile size (2, 4 or 6)
     float *wino_alt = nullptr;           // device, F(4x4) weights kept next to F(6x6) ones for small-batch launches, or null
     float *fused4s = nullptr;            // device, fused F(4x4,3x3) weights (wino4s_fused.hip: conv_2 / 3 / 5 / 6 / 8's shapes) or null
+    unsigned short *fused4b = nullptr;   // device, the same as bf16 terms in wino4b_fused.hip's stage images, or null
     float *bias = nullptr;               // device, [npad]
     float *scale = nullptr;              // device, [cout]: folded BatchNorm scale (dt_detector_extract un-folds with it) or null
     bool scale_has_zero = false;
@@ -277,6 +282,7 @@ struct Policy {
     int mosaic = -1;         // DT_WINO_MOSAIC: 1 never, 2/3/4 force, -1 = fewest tiles
     int fused4 = 1;          // DT_WINO_FUSED4: the fused F(4x4) kernel (wino4s_fused.hip): 0 never / 1 conv_2 / 3 / 5 (Cin <= 64) from 1024
                              //                 blocks / 3 also conv_6 / 8 (Cin 128) / 2 any eligible layer at any size.  Read at weight load (0) and per launch
+    int f4b = 0;             // DT_F4B: the fused layers run wino4b_fused.hip (bf16 pipe, split operands): 1 / 0 = wino4s_fused.hip (fp32 MFMA; default while the new kernel is slower)
     int wino_cfg = -1, wino_gn = -1;   // DT_WINO_CFG / DT_WINO_GN (A/B runs)
     int ksplit = 0;          // DT_KSPLIT
     int conv_cfg = -1;       // DT_CONV_CFG

@@ -210,6 +210,7 @@ extern "C" void dt_destroy(dt_ctx *ctx)
         if (ctx->layers[i].wino) (void)hipFree(ctx->layers[i].wino);
         if (ctx->layers[i].wino_alt) (void)hipFree(ctx->layers[i].wino_alt);
         if (ctx->layers[i].fused4s) (void)hipFree(ctx->layers[i].fused4s);
+        if (ctx->layers[i].fused4b) (void)hipFree(ctx->layers[i].fused4b);
         if (ctx->layers[i].scale) (void)hipFree(ctx->layers[i].scale);
     }
     float *singles[] = {ctx->conv1_w, ctx->conv1_b, ctx->lut255, ctx->anchors_dev, ctx->trk_wx, ctx->trk_bx,
@@ -322,6 +323,7 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
     if (L.wino) { (void)hipStreamSynchronize(ctx->stream); s3_drop(ctx, L.wino); (void)hipFree(L.wino); L.wino = nullptr; }
     if (L.wino_alt) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino_alt); L.wino_alt = nullptr; }
     if (L.fused4s) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused4s); L.fused4s = nullptr; }
+    if (L.fused4b) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused4b); L.fused4b = nullptr; }
     const bool f4_shape = ((cin == 64 || cin == 128) && cout % 128 == 0 && cout <= 256) || (cin == 32 && cout == 64);
     if (ks == 3 && f4_shape && ctx->pol.wino != 0 && ctx->pol.fused4 != 0) {
         // conv_2 / conv_3 / conv_5 / conv_6 / conv_8's shapes: the fused F(4x4,3x3) kernel (wino4s_fused.hip)
@@ -329,6 +331,13 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
         wino_pack_weights(4, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale, u36.data());
         wino4s_fused_pack(u36.data(), L.npad, cin, cout, uf.data());
         if ((rc = upload(ctx, &L.fused4s, uf))) return rc;
+        if (ctx->pol.f4b != 0) {
+            // ... and as bf16 terms in the stage images of wino4b_fused.hip (the kernel that runs them by default)
+            std::vector<unsigned short> ub((size_t)36 * cin * cout * 3);
+            wino4b_fused_pack(u36.data(), L.npad, cin, cout, ub.data());
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&L.fused4b), ub.size() * sizeof(unsigned short)));
+            HIP_TRY(ctx, hipMemcpy(L.fused4b, ub.data(), ub.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        }
     }
     if (wino_wanted(ctx, ks, cin, cout)) {
         L.wino_ts = wino_tile(ctx, false);
@@ -448,6 +457,7 @@ void policy_from_env(Policy &p)
     { const char *e = getenv("DT_WINO_WS_GB"); p.wino_ws_gb = e ? atof(e) : d.wino_ws_gb; }
     p.mosaic = geti("DT_WINO_MOSAIC", d.mosaic);
     p.fused4 = geti("DT_WINO_FUSED4", d.fused4);
+    p.f4b = geti("DT_F4B", d.f4b);
     p.wino_cfg = geti("DT_WINO_CFG", d.wino_cfg);
     p.wino_gn = geti("DT_WINO_GN", d.wino_gn);
     p.ksplit = geti("DT_KSPLIT", d.ksplit);
@@ -779,7 +789,10 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
             prof_direct_form(ctx, flops, bytes, DF_FUSED);
             float *zeros = ws_get(ctx, "zeros256", 256, /*zero_on_grow=*/true);
             if (!zeros) return DT_ERR_DEVICE;
-            const int rc = launch_wino4s_fused(ctx->stream, f, zeros);
+            const bool f4b = L.fused4b && ctx->pol.f4b != 0;
+            if (f4b) f.u = reinterpret_cast<const float *>(L.fused4b);
+            if (ctx->prof) ctx->prof_tab[f4b ? "conv_fused_kernel:bf16_split" : "conv_fused_kernel:fp32"].launches += 1;
+            const int rc = f4b ? launch_wino4b_fused(ctx->stream, f, zeros) : launch_wino4s_fused(ctx->stream, f, zeros);
             if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused F(4x4) launch failed", tag);
             return DT_OK;
         }
