@@ -73,7 +73,44 @@ template <int R> __device__ __forceinline__ constexpr bool b4_needs(int a)
     return R == 0 ? (a == 0 || a == 2 || a == 4) : (R == 5 ? (a == 1 || a == 3 || a == 5) : (a >= 1 && a <= 4));
 }
 
+#ifdef DT_B4_TIMING
+// debug build only (tools/b4_timing.py): per workgroup / wave / item cycle sums of the stage phases
+#define B4_TT_WG 64
+#define B4_TT_ITEMS 8
+#define B4_TT_SLOTS 8      // 0 item start, 1 stage loop end, 2 epilogue end, 3 sum(dma issue), 4 sum(input transform), 5 sum(mfma phase), 6 sum(Y accumulation), 7 sum(vmcnt + barrier wait)
+__device__ unsigned long long g_b4_times[B4_TT_WG * 8 * B4_TT_ITEMS * B4_TT_SLOTS];
+extern "C" __attribute__((visibility("default"))) int dt_debug_b4_times(unsigned long long *dst, int clear)
+{
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_b4_times)) != hipSuccess) return 1;
+        return hipMemset(p, 0, sizeof(g_b4_times)) == hipSuccess ? 0 : 1;
+    }
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_b4_times), sizeof(g_b4_times)) == hipSuccess ? 0 : 1;
+}
+#define B4_NOW() __builtin_readcyclecounter()
+#define B4_PUT(k, v)                                                                                              \
+    do {                                                                                                          \
+        if (lane == 0 && blockIdx.x < B4_TT_WG && tt_i < B4_TT_ITEMS)                                             \
+            g_b4_times[((blockIdx.x * 8 + wave) * B4_TT_ITEMS + tt_i) * B4_TT_SLOTS + (k)] = (v);                 \
+    } while (0)
+#else
+#define B4_NOW() 0ull
+#define B4_PUT(k, v) do { } while (0)
+#endif
+
 #define B4_INL __attribute__((always_inline))
+// an opaque copy of a lane constant: addresses formed from it are recomputed where they are used (3-5 VALU instructions) instead of being
+// hoisted out of the stage loop into registers the loop does not have -- hipcc spilled them to scratch and reloaded them in every stage
+// behind s_waitcnt vmcnt(0), i.e. behind the DMA in flight
+__device__ __forceinline__ int b4_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+// the lane id, recomputed where it is needed (two VALU instructions, volatile: never hoisted, never spilled)
+__device__ __forceinline__ int b4_lane()
+{
+    int x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
 template <int... Is, class F>
 __device__ __forceinline__ void b4_for(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>()), ...); }
 
@@ -84,8 +121,8 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
     unsigned char *const Pb = b4_lds;                                       // [2 classes][39 KiB]: even patch rows | odd patch rows
     unsigned char *const Ub = b4_lds + B4_PATCH_BYTES;                      // [2][stage]
     unsigned char *const Vb = b4_lds + B4_PATCH_BYTES + 2 * B4_STAGE_BYTES; // [2][stage]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    [[maybe_unused]] const int lane = threadIdx.x & 63;      // (timing build only: every phase below derives its lane constants from b4_lane())
     const int wm = wave & 3, wn = wave >> 2;            // MFMA role: 16-tile row block, 32-channel half.  Waves w and w + 4 share a SIMD
     const int set = wn;                                 // set 1 transforms at the head of a stage, set 0 at its tail
     const int NS = p.Cin >> 4;                          // 16-channel slices
@@ -109,63 +146,85 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
         return I;
     };
 
-    // ---- DMA ----
-    // U of one stage: 18 KiB contiguous in the packed image, 18 pieces over the 8 waves
-    auto u_issue = [&](int nq, int s, int k, int buf) B4_INL {
+    // ---- DMA: raw buffer loads into LDS -- the descriptor and the stage's offset are scalars, the lane contributes ONE 32-bit offset
+    // (with flat pointers every piece's 64-bit lane address was a register pair hipcc hoisted, spilled and reloaded behind vmcnt(0));
+    // an offset past num_records reads zeros: out-of-image pixels and unused slots need no second source ----
+    constexpr unsigned B4_OOB = 0x7fff0000u;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(ug), 0, (unsigned)(36 * 6) * (unsigned)(p.Cin * p.N), 0x00020000);
+    // U of one stage: 18 KiB contiguous in the packed image.  Waves 0-5 take three contiguous pieces each (slot < 0: all; else the wave's piece `slot`)
+    auto u_issue = [&](int nq, int s, int k, int buf, int slot) B4_INL {
         if (B4_ABLATE & 1) return;
-        const unsigned char *src = ug + ((long long)(nq * NS + s) * 12 + k) * B4_STAGE_BYTES + lane * 16;
-        unsigned char *dst = Ub + buf * B4_STAGE_BYTES;
+        if (wave >= 6) return;
+        const int soff = ((nq * NS + s) * 12 + k) * B4_STAGE_BYTES + wave * 3072;
+        const int voff = b4_lane() * 16;
+        unsigned char *dst = Ub + buf * B4_STAGE_BYTES + wave * 3072;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int pc = wave + 8 * i;
-            if (pc < 18) __builtin_amdgcn_global_load_lds((b4_gptr_t *)(src + pc * 1024), (b4_lptr_t *)(dst + pc * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < 3; ++i)
+            if (slot < 0 || slot == i) __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (b4_lptr_t *)(dst + i * 1024), 16, voff, soff + i * 1024, 0, 0);
     };
+    const unsigned frame_bytes = (unsigned)(((long long)(p.H - 1) * p.W + p.W - 1) * p.in_ld + p.Cin) * 4u;   // the last pixel's channels end here
     // pieces [lo, hi) of one row class (0: even patch rows, 1: odd) of the 16-channel slice s of item I: slot = (row * 36 + px') * 4 + g with
-    // px' = px ^ ((px >> 2) & 3); out-of-image and unused slots read a block of zeros
-    auto patch_issue = [&](const Item &I, int s, int cls, int lo, int hi) B4_INL {
+    // px' = px ^ ((px >> 2) & 3)
+    auto patch_issue = [&](const Item &I, int s, int cls, int lo, int hi, int slot) B4_INL {
         if (B4_ABLATE & 2) return;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(I.frame), 0, frame_bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int pc = lo + wave + 8 * i;
-            if (pc < hi) {
-                const unsigned slot = (unsigned)pc * 64u + (unsigned)lane;
-                const unsigned row = slot / 144u, rem = slot - row * 144u;
+            if ((slot < 0 || slot == i) && pc < hi) {
+                const unsigned sl = (unsigned)pc * 64u + (unsigned)b4_lane();
+                const unsigned row = sl / 144u, rem = sl - row * 144u;
                 const unsigned pxs = rem >> 2, g = rem & 3u;
                 const unsigned px = pxs ^ ((pxs >> 2) & 3u);
                 const int y = I.y0 - 1 + (int)(2u * row) + cls, x = I.x0 - 1 + (int)px;
                 const bool ok = row < 17u && px < 34u && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-                const float *src = ok ? I.frame + ((long long)y * p.W + x) * p.in_ld + 16 * s + 4 * (int)g : p.zeros;
-                __builtin_amdgcn_global_load_lds((b4_gptr_t *)src, (b4_lptr_t *)(Pb + cls * B4_CLS_BYTES + pc * 1024), 16, 0, 0);
+                const unsigned voff = ok ? (unsigned)((y * p.W + x) * p.in_ld + 4 * (int)g) * 4u : B4_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (b4_lptr_t *)(Pb + cls * B4_CLS_BYTES + pc * 1024), 16, (int)voff, 64 * s, 0, 0);
             }
         }
     };
 
     // ---- input transform: this wave's tile row (ty = wave), lane = (tx = lane >> 3, channel pair q = lane & 7) ----
-    const int ptx = lane >> 3, pq = lane & 7;
-    const unsigned char *const pl = Pb + wave * (2 * B4_ROWPITCH) + pq * 8;        // patch row 4 ty + a: class a & 1, row index 2 ty + (a >> 1)
-    int colb[6];                                                                   // byte offset of window column b (swizzled pixel)
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-        const int px = 4 * ptx + b;
-        colb[b] = (px ^ ((px >> 2) & 3)) * 64;
-    }
-    unsigned char *const vw = Vb + (8 * wave + ptx) * 32 + pq * 4;                 // + stage buffer + (j * 3 + term) * 2048
-    // half-row (R, HF) = positions (R, 3 HF + j), j = 0..2, into V buffer vbuf
+    // half-row (R, HF) = positions (R, 3 HF + j), j = 0..2, into V buffer vbuf.  The column sums t[1..4] of the first half are kept in
+    // registers for the second (eight VGPRs across one stage): it reads window column 5 only
+#ifndef B4_TKEEP
+#define B4_TKEEP 0       // 1: keep t[1..4] from the first half of a row for the second (saves 14 window reads and 13 packed operations per row; the
+#endif                   //    eight registers it holds across the MFMA phase spill there -- scratch traffic behind vmcnt waits: not kept)
+    [[maybe_unused]] b4_f2 tk[4];
     auto produce_rh = [&](auto Rtag, auto HFtag, int vbuf) B4_INL {
         constexpr int R = decltype(Rtag)::value, HF = decltype(HFtag)::value;
         if (B4_ABLATE & 4) return;
-        b4_f2 t[6];
+        const int ln = b4_lane();
+        const int tx = ln >> 3, q = ln & 7;
+        const unsigned char *const pl = Pb + wave * (2 * B4_ROWPITCH) + q * 8;    // patch row 4 ty + a: class a & 1, row index 2 ty + (a >> 1)
+        auto colb = [&](int b) B4_INL {                     // byte offset of window column b (swizzled pixel)
+            const int px = 4 * tx + b;
+            return (px ^ ((px >> 2) & 3)) * 64;
+        };
+        // all window reads first (one LDS round trip), then the arithmetic
+        b4_f2 d[6][6], t[6];
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-            if (b < HF || b > HF + 4) continue;             // HF 0: columns 0..4, HF 1: columns 1..5
-            b4_f2 d[6];
+            if (B4_TKEEP ? (HF == 0 ? b > 4 : b != 5) : (b < HF || b > HF + 4)) continue;         // HF 0: columns 0..4; HF 1: columns 1..5 (B4_TKEEP: 5 only)
+            const int cb = colb(b);
 #pragma unroll
             for (int a = 0; a < 6; ++a)
-                if (b4_needs<R>(a)) d[a] = *reinterpret_cast<const b4_f2 *>(pl + (a & 1) * B4_CLS_BYTES + (a >> 1) * B4_ROWPITCH + colb[b]);
-            t[b] = b4_bt<R>(d);
+                if (b4_needs<R>(a)) d[b][a] = *reinterpret_cast<const b4_f2 *>(pl + (a & 1) * B4_CLS_BYTES + (a >> 1) * B4_ROWPITCH + cb);
         }
-        unsigned char *o = vw + vbuf * B4_STAGE_BYTES;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            if (B4_TKEEP ? (HF == 0 ? b > 4 : b != 5) : (b < HF || b > HF + 4)) continue;
+            t[b] = b4_bt<R>(d[b]);
+        }
+        if (B4_TKEEP && HF == 0) {
+#pragma unroll
+            for (int b = 1; b < 5; ++b) tk[b - 1] = t[b];
+        } else if (B4_TKEEP) {
+#pragma unroll
+            for (int b = 1; b < 5; ++b) t[b] = tk[b - 1];
+        }
+        unsigned char *o = Vb + (8 * wave + tx) * 32 + q * 4 + vbuf * B4_STAGE_BYTES;       // + (j * 3 + term) * 2048
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             b4_f2 v;
@@ -187,38 +246,60 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
     };
 
     // ---- MFMA operands: lane (row = lane & 15, kg = lane >> 4): kg 0, 1 = channels 0-7 / 8-15 of the FIRST term slot, kg 2, 3 of the second ----
-    const int kg = lane >> 4, r16 = lane & 15;
-    const bool lo = kg < 2;
-    const int a_row = ((16 * wm + r16) * 32 + (kg & 1) * 16), b_row = ((32 * wn + r16) * 32 + (kg & 1) * 16);
-    const unsigned char *const a12 = Vb + a_row + (lo ? 0 : 1) * 2048;      // (v1 | v2)
-    const unsigned char *const a21 = Vb + a_row + (lo ? 1 : 0) * 2048;      // (v2 | v1)
-    const unsigned char *const a13 = Vb + a_row + (lo ? 0 : 2) * 2048;      // (v1 | v3)
-    const unsigned char *const b12 = Ub + b_row + (lo ? 0 : 1) * 2048;      // (u1 | u2)
-    const unsigned char *const b31 = Ub + b_row + (lo ? 2 : 0) * 2048;      // (u3 | u1)
-
     f32x4 tmp[6][2];                    // M' of the position row in flight: [column c][16-channel block]
     b4_f2 Y[2][2][4][4];                // accumulated outputs: [block][tile pair (accumulator registers 2 ip, 2 ip + 1)][row a][column j]
     auto ld16 = [&](const unsigned char *q) B4_INL {
         if (B4_ABLATE & 8) return __builtin_bit_cast(b4_bf8, b4_u4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
         return __builtin_bit_cast(b4_bf8, *reinterpret_cast<const b4_u4 *>(q));
     };
-    auto mfma_stage = [&](auto Ktag) B4_INL {      // positions (k >> 1, 3 (k & 1) + j)
+    auto mfma_stage = [&](auto Ktag, auto &&dma) B4_INL {      // positions (k >> 1, 3 (k & 1) + j); dma(j): the data movement issued behind position j's MFMAs
         constexpr int k = decltype(Ktag)::value;
         const int so = (k & 1) * B4_STAGE_BYTES;
+        const int ln = b4_lane();
+        const int kg = ln >> 4, r16 = ln & 15;
+        const int a_row = (16 * wm + r16) * 32 + (kg & 1) * 16, b_row = (32 * wn + r16) * 32 + (kg & 1) * 16;
+        const int t0 = kg < 2 ? 0 : 2048;                                  // term plane of the second slot, relative to the first's
+        const unsigned char *const a12 = Vb + a_row + t0;                   // (v1 | v2)
+        const unsigned char *const a21 = Vb + a_row + 2048 - t0;            // (v2 | v1)
+        const unsigned char *const a13 = Vb + a_row + 2 * t0;               // (v1 | v3)
+        const unsigned char *const b12 = Ub + b_row + t0;                   // (u1 | u2)
+        const unsigned char *const b31 = Ub + b_row + 4096 - 2 * t0;        // (u3 | u1)
+        // the A fragments of position j + 1 are requested BEFORE the MFMAs of position j are issued, its B fragments right behind them (into
+        // the registers those MFMAs have just read: 40 operand registers instead of 56 -- the phase also holds 128 of Y and 48 of M');
+        // pinned with sched_barrier: left alone hipcc requests a fragment right in front of its first use and waits with lgkmcnt(0)
+#ifndef B4_BDBL
+#define B4_BDBL 0        // 1: the B fragments double-buffered too (56 operand registers)
+#endif
+        b4_bf8 A[2][3], B[2][2][2];
+        auto request_a = [&](int j, int buf) B4_INL {
+            const int o = so + j * B4_POS_BYTES;
+            A[buf][0] = ld16(a13 + o); A[buf][1] = ld16(a21 + o); A[buf][2] = ld16(a12 + o);
+        };
+        auto request_b = [&](int j, int buf) B4_INL {
+            const int o = so + j * B4_POS_BYTES;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) { B[buf][blk][0] = ld16(b31 + o + blk * 512); B[buf][blk][1] = ld16(b12 + o + blk * 512); }
+        };
+        request_a(0, 0); request_b(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int o = so + j * B4_POS_BYTES;
-            const b4_bf8 A13 = ld16(a13 + o), A21 = ld16(a21 + o), A12 = ld16(a12 + o);
+            const int cb = j & 1, bb = B4_BDBL ? cb : 0;
+            if (j < 2) { request_a(j + 1, cb ^ 1); if (B4_BDBL) request_b(j + 1, cb ^ 1); }
+            __builtin_amdgcn_sched_barrier(0);
             const int c = 3 * (k & 1) + j;
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
-                const b4_bf8 B31 = ld16(b31 + o + blk * 512), B12 = ld16(b12 + o + blk * 512);
                 f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A13, B31, acc, 0, 0, 0);      // u3 v1 + u1 v3
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A21, B12, acc, 0, 0, 0);      // u1 v2 + u2 v1
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A12, B12, acc, 0, 0, 0);      // u1 v1 + u2 v2
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[cb][0], B[bb][blk][0], acc, 0, 0, 0);      // (v1|v3).(u3|u1): u3 v1 + u1 v3
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[cb][1], B[bb][blk][1], acc, 0, 0, 0);      // (v2|v1).(u1|u2): u1 v2 + u2 v1
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[cb][2], B[bb][blk][1], acc, 0, 0, 0);      // (v1|v2).(u1|u2): u1 v1 + u2 v2
                 tmp[c][blk] = acc;
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (j < 2 && !B4_BDBL) request_b(j + 1, 0);
+            dma(j);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // Y += At[:, R] (x) (M'[R][0..5] A) for the finished position row R
@@ -257,14 +338,17 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
     // ---- prologue of the workgroup's first item: whole patch of slice 0, U of stage 0, V of stage 0 ----
     int item = blockIdx.x;
     Item cur = item_of(item);
-    patch_issue(cur, 0, 0, 0, 24); patch_issue(cur, 0, 0, 24, B4_CLS_PIECES);
-    patch_issue(cur, 0, 1, 0, 24); patch_issue(cur, 0, 1, 24, B4_CLS_PIECES);
-    u_issue(cur.nq, 0, 0, 0);
+    patch_issue(cur, 0, 0, 0, 24, -1); patch_issue(cur, 0, 0, 24, B4_CLS_PIECES, -1);
+    patch_issue(cur, 0, 1, 0, 24, -1); patch_issue(cur, 0, 1, 24, B4_CLS_PIECES, -1);
+    u_issue(cur.nq, 0, 0, 0, -1);
     __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
     __syncthreads();
     produce(std::integral_constant<int, 0>(), 0);
     __syncthreads();
     bool first = true;
+#ifdef DT_B4_TIMING
+    int tt_i = 0;
+#endif
 
 #pragma unroll 1
     for (;;) {
@@ -280,6 +364,10 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
 #pragma unroll
                     for (int j = 0; j < 4; ++j) Y[blk][ip][a][j] = b4_f2{0.0f, 0.0f};
 
+#ifdef DT_B4_TIMING
+        unsigned long long tt_dm = 0, tt_tr = 0, tt_mm = 0, tt_ya = 0, tt_wt = 0;
+        B4_PUT(0, B4_NOW());
+#endif
 #pragma unroll 1
         for (int s = 0; s < NS; ++s) {
             const bool last_slice = s + 1 == NS;
@@ -291,32 +379,46 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
                 constexpr int k = decltype(Ktag)::value;
                 constexpr int k1 = (k + 1) % 12;
                 const bool more = k < 11 || up_exists;              // a stage follows this one
-                // ---- data movement for what follows ----
-                if (more) {
-                    if (k < 11) u_issue(cur.nq, s, k + 1, (k + 1) & 1);
-                    else u_issue(up.nq, up_s, 0, 0);
-                }
-                if (k == 9 && up_exists) patch_issue(up, up_s, 0, 0, 24);
-                if (k == 10 && up_exists) patch_issue(up, up_s, 0, 24, B4_CLS_PIECES);
-                if (k == 11 && up_exists) patch_issue(up, up_s, 1, 0, 24);
-                if (k == 0 && !(first && s == 0)) patch_issue(cur, s, 1, 24, B4_CLS_PIECES);
+                [[maybe_unused]] const unsigned long long c0 = B4_NOW();
+                // ---- data movement for what follows: one piece slot behind each position of the MFMA phase ----
+                auto dma = [&](int slot) B4_INL {
+                    if (more) {
+                        if (k < 11) u_issue(cur.nq, s, k + 1, (k + 1) & 1, slot);
+                        else u_issue(up.nq, up_s, 0, 0, slot);
+                    }
+                    if (k == 9 && up_exists) patch_issue(up, up_s, 0, 0, 24, slot);
+                    if (k == 10 && up_exists) patch_issue(up, up_s, 0, 24, B4_CLS_PIECES, slot);
+                    if (k == 11 && up_exists) patch_issue(up, up_s, 1, 0, 24, slot);
+                    if (k == 0 && !(first && s == 0)) patch_issue(cur, s, 1, 24, B4_CLS_PIECES, slot);
+                };
                 __builtin_amdgcn_sched_barrier(0);
+                [[maybe_unused]] const unsigned long long c1 = B4_NOW();
                 if (set == 1 && more) produce(std::integral_constant<int, k1>(), k1 & 1);
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_stage(Ktag);
+                [[maybe_unused]] const unsigned long long c2 = B4_NOW();
+                mfma_stage(Ktag, dma);
                 __builtin_amdgcn_sched_barrier(0);
+                [[maybe_unused]] const unsigned long long c3 = B4_NOW();
                 if (k & 1) yacc(std::integral_constant<int, (k >> 1)>());
                 __builtin_amdgcn_sched_barrier(0);
+                [[maybe_unused]] const unsigned long long c4 = B4_NOW();
                 if (set == 0 && more) produce(std::integral_constant<int, k1>(), k1 & 1);
+                [[maybe_unused]] const unsigned long long c5 = B4_NOW();
                 __builtin_amdgcn_s_waitcnt(0x0f70);     // this wave's DMA pieces have landed
                 __syncthreads();
+#ifdef DT_B4_TIMING
+                tt_dm += c1 - c0; tt_tr += (c2 - c1) + (c5 - c4); tt_mm += c3 - c2; tt_ya += c4 - c3; tt_wt += B4_NOW() - c5;
+#endif
             });
         }
         first = false;
+        B4_PUT(1, B4_NOW());
 
         // ---- epilogue: bias + LeakyReLU [+ 2x2 max] on the accumulated outputs.  D row 4 (lane >> 4) + i = tile of this wave's 16
         // (two tile rows of the block), D column = channel ----
         {
+            const int ln = b4_lane();
+            const int kg = ln >> 4, r16 = ln & 15;
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 const int ch = cur.nq * 64 + wn * 32 + blk * 16 + r16;
@@ -366,6 +468,10 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
                 }
             }
         }
+#ifdef DT_B4_TIMING
+        B4_PUT(2, B4_NOW()); B4_PUT(3, tt_dm); B4_PUT(4, tt_tr); B4_PUT(5, tt_mm); B4_PUT(6, tt_ya); B4_PUT(7, tt_wt);
+        ++tt_i;
+#endif
         if (!has_next) break;
         item = nxt_it;
         cur = nx;
