@@ -41,7 +41,9 @@ typedef __bf16 b4_bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b4_bf2 __attribute__((ext_vector_type(2)));
 typedef unsigned b4_u4 __attribute__((ext_vector_type(4)));
 
-#define B4_THREADS 512
+#ifndef B4_NB
+#define B4_NB 1                          // 16-channel blocks per wave: 1 = sixteen waves per workgroup, 2 = eight (see the kernel's comment)
+#endif
 #define B4_ROWPITCH 2304                 // bytes per patch row: 36 pixels x 4 slots x 16 B (34 pixels used; the XOR stays inside groups of 4)
 #define B4_CLS_PIECES 39                 // 17 rows x 144 slots = 2448 slots -> 39 DMA pieces of 64 slots
 #define B4_CLS_BYTES (B4_CLS_PIECES * 1024)
@@ -78,7 +80,7 @@ template <int R> __device__ __forceinline__ constexpr bool b4_needs(int a)
 #define B4_TT_WG 64
 #define B4_TT_ITEMS 8
 #define B4_TT_SLOTS 8      // 0 item start, 1 stage loop end, 2 epilogue end, 3 sum(dma issue), 4 sum(input transform), 5 sum(mfma phase), 6 sum(Y accumulation), 7 sum(vmcnt + barrier wait)
-__device__ unsigned long long g_b4_times[B4_TT_WG * 8 * B4_TT_ITEMS * B4_TT_SLOTS];
+__device__ unsigned long long g_b4_times[B4_TT_WG * 16 * B4_TT_ITEMS * B4_TT_SLOTS];
 extern "C" __attribute__((visibility("default"))) int dt_debug_b4_times(unsigned long long *dst, int clear)
 {
     if (clear) {
@@ -92,7 +94,7 @@ extern "C" __attribute__((visibility("default"))) int dt_debug_b4_times(unsigned
 #define B4_PUT(k, v)                                                                                              \
     do {                                                                                                          \
         if (lane == 0 && blockIdx.x < B4_TT_WG && tt_i < B4_TT_ITEMS)                                             \
-            g_b4_times[((blockIdx.x * 8 + wave) * B4_TT_ITEMS + tt_i) * B4_TT_SLOTS + (k)] = (v);                 \
+            g_b4_times[((blockIdx.x * 16 + wave) * B4_TT_ITEMS + tt_i) * B4_TT_SLOTS + (k)] = (v);                 \
     } while (0)
 #else
 #define B4_NOW() 0ull
@@ -114,17 +116,23 @@ __device__ __forceinline__ int b4_lane()
 template <int... Is, class F>
 __device__ __forceinline__ void b4_for(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>()), ...); }
 
-template <bool POOL>
-__global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs p)
+// NB: 16-channel blocks per wave.  2: eight waves of 16 tiles x 32 channels (two per SIMD, 256 registers each, every wave transforms in every
+// stage); 1: SIXTEEN waves of 16 tiles x 16 channels (four per SIMD, 128 registers each): the per-wave chain transform -> MFMAs -> Y update
+// is half as long and four waves per SIMD cover each other's LDS / DMA latencies; the two wave sets alternate between transforming the
+// next stage's V and issuing the next stage's DMA
+template <bool POOL, int NB>
+__global__ __launch_bounds__(1024 / NB) void wino4b_fused_kernel(Wino4FusedArgs p)
 {
+    constexpr bool YH = NB == 1;                        // Y is updated after every half-row (12 M' registers per block) instead of every row (24)
     extern __shared__ __attribute__((aligned(16))) unsigned char b4_lds[];
     unsigned char *const Pb = b4_lds;                                       // [2 classes][39 KiB]: even patch rows | odd patch rows
     unsigned char *const Ub = b4_lds + B4_PATCH_BYTES;                      // [2][stage]
     unsigned char *const Vb = b4_lds + B4_PATCH_BYTES + 2 * B4_STAGE_BYTES; // [2][stage]
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     [[maybe_unused]] const int lane = threadIdx.x & 63;      // (timing build only: every phase below derives its lane constants from b4_lane())
-    const int wm = wave & 3, wn = wave >> 2;            // MFMA role: 16-tile row block, 32-channel half.  Waves w and w + 4 share a SIMD
-    const int set = wn;                                 // set 1 transforms at the head of a stage, set 0 at its tail
+    const int wm = wave & 3, wn = wave >> 2;            // MFMA role: 16-tile row block, block of 16 NB channels.  Waves w, w + 4, .. share a SIMD
+    const int set = NB == 2 ? wn : (wn & 1);            // NB 2: set 1 transforms at the head of a stage, set 0 at its tail.  NB 1: set (k + 1) & 1 transforms V(k + 1)
+    const int i8 = NB == 2 ? wave : (wave & 3) + 4 * (wave >> 3);      // index within the set (NB 1): tile row it transforms, DMA pieces it issues
     const int NS = p.Cin >> 4;                          // 16-channel slices
     const int NQ = p.N >> 6;                            // 64-channel output slices
     const int nblk = p.B * p.nby * p.nbx;
@@ -154,10 +162,10 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
     // U of one stage: 18 KiB contiguous in the packed image.  Waves 0-5 take three contiguous pieces each (slot < 0: all; else the wave's piece `slot`)
     auto u_issue = [&](int nq, int s, int k, int buf, int slot) B4_INL {
         if (B4_ABLATE & 1) return;
-        if (wave >= 6) return;
-        const int soff = ((nq * NS + s) * 12 + k) * B4_STAGE_BYTES + wave * 3072;
+        if (i8 >= 6) return;
+        const int soff = ((nq * NS + s) * 12 + k) * B4_STAGE_BYTES + i8 * 3072;
         const int voff = b4_lane() * 16;
-        unsigned char *dst = Ub + buf * B4_STAGE_BYTES + wave * 3072;
+        unsigned char *dst = Ub + buf * B4_STAGE_BYTES + i8 * 3072;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (slot < 0 || slot == i) __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (b4_lptr_t *)(dst + i * 1024), 16, voff, soff + i * 1024, 0, 0);
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(I.frame), 0, frame_bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int pc = lo + wave + 8 * i;
+            const int pc = lo + i8 + 8 * i;
             if ((slot < 0 || slot == i) && pc < hi) {
                 const unsigned sl = (unsigned)pc * 64u + (unsigned)b4_lane();
                 const unsigned row = sl / 144u, rem = sl - row * 144u;
@@ -196,26 +204,33 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
         if (B4_ABLATE & 4) return;
         const int ln = b4_lane();
         const int tx = ln >> 3, q = ln & 7;
-        const unsigned char *const pl = Pb + wave * (2 * B4_ROWPITCH) + q * 8;    // patch row 4 ty + a: class a & 1, row index 2 ty + (a >> 1)
+        const unsigned char *const pl = Pb + i8 * (2 * B4_ROWPITCH) + q * 8;      // patch row 4 ty + a: class a & 1, row index 2 ty + (a >> 1); ty = i8
         auto colb = [&](int b) B4_INL {                     // byte offset of window column b (swizzled pixel)
             const int px = 4 * tx + b;
             return (px ^ ((px >> 2) & 3)) * 64;
         };
-        // all window reads first (one LDS round trip), then the arithmetic
-        b4_f2 d[6][6], t[6];
+        // the window reads of a batch of columns first (one LDS round trip), then their column sums.  NB 2: all five columns in one batch
+        // (40 registers in flight); NB 1 (128 registers per wave): three, then two
+        b4_f2 t[6];
+        constexpr int PB = NB == 2 ? 6 : 3;
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            if (B4_TKEEP ? (HF == 0 ? b > 4 : b != 5) : (b < HF || b > HF + 4)) continue;         // HF 0: columns 0..4; HF 1: columns 1..5 (B4_TKEEP: 5 only)
-            const int cb = colb(b);
+        for (int b0 = 0; b0 < 6; b0 += PB) {
+            b4_f2 d[6][6];
 #pragma unroll
-            for (int a = 0; a < 6; ++a)
-                if (b4_needs<R>(a)) d[b][a] = *reinterpret_cast<const b4_f2 *>(pl + (a & 1) * B4_CLS_BYTES + (a >> 1) * B4_ROWPITCH + cb);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int b = b0; b < b0 + PB && b < 6; ++b) {
+                if (B4_TKEEP ? (HF == 0 ? b > 4 : b != 5) : (b < HF || b > HF + 4)) continue;         // HF 0: columns 0..4; HF 1: columns 1..5 (B4_TKEEP: 5 only)
+                const int cb = colb(b);
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            if (B4_TKEEP ? (HF == 0 ? b > 4 : b != 5) : (b < HF || b > HF + 4)) continue;
-            t[b] = b4_bt<R>(d[b]);
+                for (int a = 0; a < 6; ++a)
+                    if (b4_needs<R>(a)) d[b][a] = *reinterpret_cast<const b4_f2 *>(pl + (a & 1) * B4_CLS_BYTES + (a >> 1) * B4_ROWPITCH + cb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = b0; b < b0 + PB && b < 6; ++b) {
+                if (B4_TKEEP ? (HF == 0 ? b > 4 : b != 5) : (b < HF || b > HF + 4)) continue;
+                t[b] = b4_bt<R>(d[b]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (B4_TKEEP && HF == 0) {
 #pragma unroll
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
 #pragma unroll
             for (int b = 1; b < 5; ++b) t[b] = tk[b - 1];
         }
-        unsigned char *o = Vb + (8 * wave + tx) * 32 + q * 4 + vbuf * B4_STAGE_BYTES;       // + (j * 3 + term) * 2048
+        unsigned char *o = Vb + (8 * i8 + tx) * 32 + q * 4 + vbuf * B4_STAGE_BYTES;         // + (j * 3 + term) * 2048
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             b4_f2 v;
@@ -246,8 +261,8 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
     };
 
     // ---- MFMA operands: lane (row = lane & 15, kg = lane >> 4): kg 0, 1 = channels 0-7 / 8-15 of the FIRST term slot, kg 2, 3 of the second ----
-    f32x4 tmp[6][2];                    // M' of the position row in flight: [column c][16-channel block]
-    b4_f2 Y[2][2][4][4];                // accumulated outputs: [block][tile pair (accumulator registers 2 ip, 2 ip + 1)][row a][column j]
+    f32x4 tmp[6][NB];                   // M' of the position row (YH: half-row, columns 0..2 used) in flight: [column c][16-channel block]
+    b4_f2 Y[NB][2][4][4];               // accumulated outputs: [block][tile pair (accumulator registers 2 ip, 2 ip + 1)][row a][column j]
     auto ld16 = [&](const unsigned char *q) B4_INL {
         if (B4_ABLATE & 8) return __builtin_bit_cast(b4_bf8, b4_u4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
         return __builtin_bit_cast(b4_bf8, *reinterpret_cast<const b4_u4 *>(q));
@@ -257,7 +272,7 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
         const int so = (k & 1) * B4_STAGE_BYTES;
         const int ln = b4_lane();
         const int kg = ln >> 4, r16 = ln & 15;
-        const int a_row = (16 * wm + r16) * 32 + (kg & 1) * 16, b_row = (32 * wn + r16) * 32 + (kg & 1) * 16;
+        const int a_row = (16 * wm + r16) * 32 + (kg & 1) * 16, b_row = (16 * NB * wn + r16) * 32 + (kg & 1) * 16;
         const int t0 = kg < 2 ? 0 : 2048;                                  // term plane of the second slot, relative to the first's
         const unsigned char *const a12 = Vb + a_row + t0;                   // (v1 | v2)
         const unsigned char *const a21 = Vb + a_row + 2048 - t0;            // (v2 | v1)
@@ -270,7 +285,7 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
 #ifndef B4_BDBL
 #define B4_BDBL 0        // 1: the B fragments double-buffered too (56 operand registers)
 #endif
-        b4_bf8 A[2][3], B[2][2][2];
+        b4_bf8 A[2][3], B[2][NB][2];
         auto request_a = [&](int j, int buf) B4_INL {
             const int o = so + j * B4_POS_BYTES;
             A[buf][0] = ld16(a13 + o); A[buf][1] = ld16(a21 + o); A[buf][2] = ld16(a12 + o);
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
         auto request_b = [&](int j, int buf) B4_INL {
             const int o = so + j * B4_POS_BYTES;
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) { B[buf][blk][0] = ld16(b31 + o + blk * 512); B[buf][blk][1] = ld16(b12 + o + blk * 512); }
+            for (int blk = 0; blk < NB; ++blk) { B[buf][blk][0] = ld16(b31 + o + blk * 512); B[buf][blk][1] = ld16(b12 + o + blk * 512); }
         };
         request_a(0, 0); request_b(0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -287,9 +302,9 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
             const int cb = j & 1, bb = B4_BDBL ? cb : 0;
             if (j < 2) { request_a(j + 1, cb ^ 1); if (B4_BDBL) request_b(j + 1, cb ^ 1); }
             __builtin_amdgcn_sched_barrier(0);
-            const int c = 3 * (k & 1) + j;
+            const int c = YH ? j : 3 * (k & 1) + j;
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
+            for (int blk = 0; blk < NB; ++blk) {
                 f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[cb][0], B[bb][blk][0], acc, 0, 0, 0);      // (v1|v3).(u3|u1): u3 v1 + u1 v3
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[cb][1], B[bb][blk][1], acc, 0, 0, 0);      // (v2|v1).(u1|u2): u1 v2 + u2 v1
@@ -302,20 +317,29 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // Y += At[:, R] (x) (M'[R][0..5] A) for the finished position row R
-    auto yacc = [&](auto Rtag) B4_INL {
-        constexpr int R = decltype(Rtag)::value;
+    // Y += At[:, R] (x) (M'[R][0..5] A) for the finished position row R; HALF < 0: the whole row from tmp[0..5]; HALF 0 / 1: the contribution of
+    // columns 0..2 / 3..5 alone from tmp[0..2] (the transform is linear in the columns too)
+    auto yacc = [&](auto Rtag, auto Htag) B4_INL {
+        constexpr int R = decltype(Rtag)::value, HALF = decltype(Htag)::value;
         if (B4_ABLATE & 16) return;
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+        for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
             for (int ip = 0; ip < 2; ++ip) {
                 b4_f2 m[6];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) m[c] = b4_f2{tmp[c][blk][2 * ip], tmp[c][blk][2 * ip + 1]};
-                const b4_f2 a = m[1] + m[2], b = m[1] - m[2], cc = m[3] + m[4], e = m[3] - m[4];
+                for (int c = 0; c < (HALF < 0 ? 6 : 3); ++c) m[c] = b4_f2{tmp[c][blk][2 * ip], tmp[c][blk][2 * ip + 1]};
                 b4_f2 T[4];
-                T[0] = m[0] + a + cc; T[1] = b + 2.0f * e; T[2] = a + 4.0f * cc; T[3] = b + 8.0f * e + m[5];
+                if (HALF < 0) {
+                    const b4_f2 a = m[1] + m[2], b = m[1] - m[2], cc = m[3] + m[4], e = m[3] - m[4];
+                    T[0] = m[0] + a + cc; T[1] = b + 2.0f * e; T[2] = a + 4.0f * cc; T[3] = b + 8.0f * e + m[5];
+                } else if (HALF == 0) {
+                    const b4_f2 a = m[1] + m[2], b = m[1] - m[2];
+                    T[0] = m[0] + a; T[1] = b; T[2] = a; T[3] = b;
+                } else {
+                    const b4_f2 cc = m[0] + m[1], e = m[0] - m[1];       // m[0..2] = columns 3, 4, 5
+                    T[0] = cc; T[1] = 2.0f * e; T[2] = 4.0f * cc; T[3] = 8.0f * e + m[2];
+                }
                 auto &y = Y[blk][ip];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -327,7 +351,7 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
                     else { y[0][j] += T[j]; y[1][j] -= 2.0f * T[j]; y[2][j] += 4.0f * T[j]; y[3][j] -= 8.0f * T[j]; }
                 }
                 // pin the updated sums HERE: nothing reads Y before the epilogue, and left alone LLVM sinks every update of an item (and
-                // the 48 M' registers of each row with it, through scratch) into the last stage
+                // the M' registers of each row with it, through scratch) into the last stage
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -338,12 +362,14 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
     // ---- prologue of the workgroup's first item: whole patch of slice 0, U of stage 0, V of stage 0 ----
     int item = blockIdx.x;
     Item cur = item_of(item);
-    patch_issue(cur, 0, 0, 0, 24, -1); patch_issue(cur, 0, 0, 24, B4_CLS_PIECES, -1);
-    patch_issue(cur, 0, 1, 0, 24, -1); patch_issue(cur, 0, 1, 24, B4_CLS_PIECES, -1);
-    u_issue(cur.nq, 0, 0, 0, -1);
+    if (NB == 2 || set == 0) {
+        patch_issue(cur, 0, 0, 0, 24, -1); patch_issue(cur, 0, 0, 24, B4_CLS_PIECES, -1);
+        patch_issue(cur, 0, 1, 0, 24, -1); patch_issue(cur, 0, 1, 24, B4_CLS_PIECES, -1);
+        u_issue(cur.nq, 0, 0, 0, -1);
+    }
     __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
     __syncthreads();
-    produce(std::integral_constant<int, 0>(), 0);
+    if (NB == 2 || set == 0) produce(std::integral_constant<int, 0>(), 0);
     __syncthreads();
     bool first = true;
 #ifdef DT_B4_TIMING
@@ -356,7 +382,7 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
         const bool has_next = nxt_it < nitems;
         const Item nx = item_of(has_next ? nxt_it : item);
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+        for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
             for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
@@ -381,7 +407,10 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
                 const bool more = k < 11 || up_exists;              // a stage follows this one
                 [[maybe_unused]] const unsigned long long c0 = B4_NOW();
                 // ---- data movement for what follows: one piece slot behind each position of the MFMA phase ----
+                // NB 2: every wave issues its share; NB 1: the set that does not transform in this stage (set k & 1) issues all of it
+                const bool dma_role = NB == 2 || set == (k & 1);
                 auto dma = [&](int slot) B4_INL {
+                    if (!dma_role) return;
                     if (more) {
                         if (k < 11) u_issue(cur.nq, s, k + 1, (k + 1) & 1, slot);
                         else u_issue(up.nq, up_s, 0, 0, slot);
@@ -393,16 +422,17 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
                 };
                 __builtin_amdgcn_sched_barrier(0);
                 [[maybe_unused]] const unsigned long long c1 = B4_NOW();
-                if (set == 1 && more) produce(std::integral_constant<int, k1>(), k1 & 1);
+                if ((NB == 2 ? set == 1 : !dma_role) && more) produce(std::integral_constant<int, k1>(), k1 & 1);
                 __builtin_amdgcn_sched_barrier(0);
                 [[maybe_unused]] const unsigned long long c2 = B4_NOW();
                 mfma_stage(Ktag, dma);
                 __builtin_amdgcn_sched_barrier(0);
                 [[maybe_unused]] const unsigned long long c3 = B4_NOW();
-                if (k & 1) yacc(std::integral_constant<int, (k >> 1)>());
+                if (YH) yacc(std::integral_constant<int, (k >> 1)>(), std::integral_constant<int, (k & 1)>());
+                else if (k & 1) yacc(std::integral_constant<int, (k >> 1)>(), std::integral_constant<int, -1>());
                 __builtin_amdgcn_sched_barrier(0);
                 [[maybe_unused]] const unsigned long long c4 = B4_NOW();
-                if (set == 0 && more) produce(std::integral_constant<int, k1>(), k1 & 1);
+                if (NB == 2 && set == 0 && more) produce(std::integral_constant<int, k1>(), k1 & 1);
                 [[maybe_unused]] const unsigned long long c5 = B4_NOW();
                 __builtin_amdgcn_s_waitcnt(0x0f70);     // this wave's DMA pieces have landed
                 __syncthreads();
@@ -420,8 +450,8 @@ __global__ __launch_bounds__(B4_THREADS) void wino4b_fused_kernel(Wino4FusedArgs
             const int ln = b4_lane();
             const int kg = ln >> 4, r16 = ln & 15;
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                const int ch = cur.nq * 64 + wn * 32 + blk * 16 + r16;
+            for (int blk = 0; blk < NB; ++blk) {
+                const int ch = cur.nq * 64 + wn * 16 * NB + blk * 16 + r16;
                 const float bias = p.bias[ch];
                 asm volatile("" ::"v"(bias));          // retire the load on the straight path (wino4s_fused.hip's note)
 #pragma unroll
@@ -496,8 +526,8 @@ int launch_wino4b_fused(hipStream_t st, const Wino4FusedArgs &a_in, const float 
     static int cus[64];
     int dev = 0;
     if (attr.ensure(&dev, [&](int d) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino4b_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void *>(wino4b_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino4b_fused_kernel<false, B4_NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(wino4b_fused_kernel<true, B4_NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return 1;
             int n = 0;
             if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
@@ -507,8 +537,8 @@ int launch_wino4b_fused(hipStream_t st, const Wino4FusedArgs &a_in, const float 
         return 1;
     long long grid = cus[dev];                      // one 8-wave workgroup per CU, persistent over the items
     if (grid > items) grid = items;
-    if (pool) hipLaunchKernelGGL(wino4b_fused_kernel<true>, dim3((unsigned)grid), dim3(B4_THREADS), lds, st, a);
-    else hipLaunchKernelGGL(wino4b_fused_kernel<false>, dim3((unsigned)grid), dim3(B4_THREADS), lds, st, a);
+    if (pool) hipLaunchKernelGGL((wino4b_fused_kernel<true, B4_NB>), dim3((unsigned)grid), dim3(1024 / B4_NB), lds, st, a);
+    else hipLaunchKernelGGL((wino4b_fused_kernel<false, B4_NB>), dim3((unsigned)grid), dim3(1024 / B4_NB), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

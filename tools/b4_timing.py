@@ -29,10 +29,10 @@ ctx.profile_reset(); ctx.profile_enable(True)
 ctx.conv2d(x, w, b, leaky_slope=0.1, pool=pool)
 ctx.profile_enable(False)
 ms = ctx.profile_read("conv_fused")["ms"]
-WG, NI, NSL = 64, 8, 8
-buf = np.zeros(WG * 8 * NI * NSL, dtype=np.uint64)
+WG, NI, NSL, NWV = 64, 8, 8, 16
+buf = np.zeros(WG * NWV * NI * NSL, dtype=np.uint64)
 assert lib.dt_debug_b4_times(buf.ctypes.data_as(ctypes.c_void_p), 0) == 0
-t = buf.reshape(WG, 8, NI, NSL).astype(np.int64)
+t = buf.reshape(WG, NWV, NI, NSL).astype(np.int64)
 nst = 12 * (Cin // 16)
 items = B * ((H + 31) // 32) ** 2 * (Cout // 64)
 print("%s %d frames: launch %.3f ms = %.0f ns per item per CU; %d stages per item; MFMA-only bound per stage %d cycles" % (
@@ -45,7 +45,7 @@ print("  item total %7.0f cycles | loop %7.0f (per stage %5.0f) | epilogue %6.0f
     m(tt[..., 2] - tt[..., 0]), m(tt[..., 1] - tt[..., 0]), m(tt[..., 1] - tt[..., 0]) / nst, m(tt[..., 2] - tt[..., 1])))
 print("  per stage, mean over waves: dma issue %5.0f | input transform %5.0f | mfma phase %5.0f | Y accumulation %5.0f | vmcnt + barrier wait %5.0f" % (
     m(tt[..., 3]) / nst, m(tt[..., 4]) / nst, m(tt[..., 5]) / nst, m(tt[..., 6]) / nst, m(tt[..., 7]) / nst))
-for wv in range(8):
+for wv in range(NWV):
     sel = tt[:, wv]
     o = sel[..., 0] > 0
     print("    wave %d: dma %5.0f transform %5.0f mfma %5.0f yacc %5.0f wait %5.0f | epilogue %6.0f" % (
