@@ -282,6 +282,10 @@ struct Policy {
     int mosaic = -1;         // DT_WINO_MOSAIC: 1 never, 2/3/4 force, -1 = fewest tiles
     int fused4 = 1;          // DT_WINO_FUSED4: the fused F(4x4) kernel (wino4s_fused.hip): 0 never / 1 conv_2 / 3 / 5 (Cin <= 64) from 1024
                              //                 blocks / 3 also conv_6 / 8 (Cin 128) / 2 any eligible layer at any size.  Read at weight load (0) and per launch
+    int pin = 0;             // DT_PIN: 1 = kernel selection independent of the batch a call happens to carry (the frame-sharded tracker runs the same
+                             //         frame in batches of other sizes for other world sizes): Winograd wherever defined, no frame mosaics, the fused kernel
+                             //         and the split GEMM at any size, one tile form, no split-K, no F(4x4)/F(6x6) choice by tile count.  Slower at small
+                             //         batch; results -- and track ids -- then do not depend on the number of ranks (parallel.py: deterministic=True)
     int f4b = 0;             // DT_F4B: the fused layers run wino4b_fused.hip (bf16 pipe, split operands): 1 / 0 = wino4s_fused.hip (fp32 MFMA; default while the new kernel is slower)
     int wino_cfg = -1, wino_gn = -1;   // DT_WINO_CFG / DT_WINO_GN (A/B runs)
     int ksplit = 0;          // DT_KSPLIT

@@ -237,7 +237,21 @@ extern "C" const char *dt_last_error(dt_ctx *ctx) { return ctx ? ctx->err.c_str(
 extern "C" int dt_set_stream(dt_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return DT_ERR_ARG;
-    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    hipStream_t next = static_cast<hipStream_t>(hip_stream);
+    if (next != ctx->stream) {
+        // work already queued on the old stream may still use the library's workspaces, and a replayed graph may be in flight there:
+        // order the new stream behind it (an event, no host wait), and drop the captured graphs -- graphs_clear() and the workspace
+        // grow path synchronise ctx->stream only, which from now on is the new one
+        graphs_clear(ctx);                              // (synchronises the OLD stream if any graph exists)
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+            if (hipEventRecord(ev, ctx->stream) == hipSuccess) (void)hipStreamWaitEvent(next, ev, 0);
+            (void)hipEventDestroy(ev);
+        } else {
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+        ctx->stream = next;
+    }
     return DT_OK;
 }
 
@@ -475,6 +489,11 @@ void policy_from_env(Policy &p)
     p.persist = geti("DT_PERSIST", d.persist);
     p.xcd_remap = geti("DT_XCD_REMAP", d.xcd_remap);
     p.tile_gn = geti("DT_TILE_GN", d.tile_gn);
+    p.pin = geti("DT_PIN", d.pin);
+    if (p.pin) {      // every choice below otherwise looks at the number of frames / rows / tiles of the launch
+        p.wino = 2; p.mosaic = 1; p.fused4 = 2; p.s3_half = -1; p.ksplit = 1;
+        if (p.s3) p.s3 = 2;
+    }
 }
 
 static bool wino_wanted(const dt_ctx *ctx, int ks, int cin, int cout)
@@ -807,7 +826,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
         // is about how the positions x row tiles x column tiles spread over the CUs (small_gemm_cost)
         const float *wt = L.wino;
         int ts = L.wino_ts;
-        if (L.wino_alt) {
+        if (L.wino_alt && !ctx->pol.pin) {
             const bool pooled = io.out2 != nullptr;
             const WinoGeom q6 = wino_geometry(ctx, 6, B, H, W, pooled), q4 = wino_geometry(ctx, 4, B, H, W, pooled);
             const long long t6 = 64ll * ((q6.Mt + 127) / 128) * ((L.cout + 127) / 128);
@@ -1838,6 +1857,7 @@ extern "C" int dt_gemm_split_bf16(dt_ctx *ctx, const float *d_v, const float *d_
 extern "C" int dt_policy_reload(dt_ctx *ctx)
 {
     if (!ctx) return DT_ERR_ARG;
+    graphs_clear(ctx);        // a captured graph holds the launches of the OLD kernel selection
     policy_from_env(ctx->pol);
     return DT_OK;
 }

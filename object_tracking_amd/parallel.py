@@ -15,6 +15,8 @@ global ids.  Messages are a few KB per frame (latency-bound, not xGMI-bandwidth
 bound): one collective per step for all frames of all local clips, never one
 per frame.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -87,9 +89,10 @@ def gather_detections(res, n_clips_max=None, group=None, ctx=None, clip_ids=None
     """Cross-stream exchange.  `res` is MultiObjDetTracker.track_clips output for
     this rank's clips (device tensors).  Returns the dict for ALL clips of all ranks in global clip
     order with an extra `gids` tensor of globally unique track ids.  Shards may be uneven: rows are padded to
-    `n_clips_max` clips per rank (pass it when known, e.g. ceil(total / world) -- otherwise one extra scalar
-    all-reduce finds it).  ONE all-gather of one packed buffer per step.  Without an initialised process group
-    (single process) only the id globalisation is applied.
+    `n_clips_max` clips per rank.  n_clips_max=None (the default) means EQUAL shards -- every rank holds as many clips as this one, the
+    clip-shard's normal case -- and no rank issues anything but the ONE all-gather of one packed buffer per step; uneven shards pass
+    their maximum (ceil(total / world)), or n_clips_max="max" to let one extra scalar all-reduce find it.  Without an initialised
+    process group (single process) only the id globalisation is applied.
       ctx       a mi355_dt.Context: pack / unpack / id globalisation run as the library's kernels
                 (dt_pack_detections / dt_unpack_detections) instead of torch indexing -- the path a C-ABI caller has;
       clip_ids  global clip index of every gathered row in rank-major order (block partition: omit; round-robin
@@ -102,6 +105,8 @@ def gather_detections(res, n_clips_max=None, group=None, ctx=None, clip_ids=None
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
         if n_clips_max is None:
+            n_clips_max = n_local          # equal shards (documented precondition): no scalar collective on the default path
+        elif n_clips_max == "max":
             m = torch.tensor([n_local], dtype=torch.int64, device=boxes.device if dist.get_backend(group) == "nccl" else "cpu")
             dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
             n_clips_max = int(m.item())
@@ -157,7 +162,31 @@ def _all_to_all_rows(send, group, async_op):
     return out, work
 
 
-def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=2, stats=None, rows=None):
+class pinned_policy(object):
+    """DT_PIN=1 on a live context (csrc/network.hip:policy_from_env): the library's kernel selection no longer looks at the batch a
+    call carries, so a frame is the same rounding of the network whatever batch it travels in -- for any world size / `chunks`.
+    The previous policy is restored on exit."""
+
+    def __init__(self, ctx, on=True):
+        self.ctx, self.on = ctx, on
+
+    def __enter__(self):
+        if self.on:
+            self.saved = os.environ.get("DT_PIN")
+            os.environ["DT_PIN"] = "1"
+            self.ctx.reload_policy()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            if self.saved is None:
+                os.environ.pop("DT_PIN", None)
+            else:
+                os.environ["DT_PIN"] = self.saved
+            self.ctx.reload_policy()
+
+
+def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=2, stats=None, rows=None, deterministic=False):
     """MultiObjDetTracker on clips whose frames are spread over the ranks of `group`: ONE stream can use all GPUs.
       1. detector (the 74 % of a frame's FLOPs) on this rank's time steps {t : t mod N = rank} of EVERY clip
          (dt_track_detect).  `frames` is either the whole [n_clips,T,H,W,3] batch (a rank then touches only its own
@@ -180,8 +209,13 @@ def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=
     same frame is a different rounding of the same network for another world size or `chunks`.  Everything discrete --
     counts, cells, labels, track ids -- is identical unless a score / IoU lies within that rounding (~1e-4) of its
     threshold.  A deployment that needs ids that do not vary with the number of ranks pins the selection with the
-    DT_* policy knobs (e.g. DT_S3_MINROWS=1 DT_S3_REC_MINROWS=1: the split GEMM at any row count; DT_WINO_MOSAIC=1).
+    threshold.  deterministic=True runs the call under DT_PIN=1 (`pinned_policy`): the selection then ignores the batch, every frame is
+    computed by the same kernels in the same order for any world size, and boxes and ids are BIT-IDENTICAL between 1, 2, 4, 8 ranks
+    (tests/test_gpu_multi.py::test_frame_shard_world_sizes_agree) -- at the price of the small-batch optimisations.
     `stats` (dict) receives bytes_received (rows + detection records from other ranks) for this call."""
+    if deterministic:
+        with pinned_policy(trk.model.ctx):
+            return track_clips_frame_sharded(trk, frames, cap=cap, group=group, T=T, chunks=chunks, stats=stats, rows=rows)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return gather_detections(trk.track_clips(frames, cap=cap))
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -336,24 +370,30 @@ def cu_partition_streams(device=None, n=2):
 
 
 def track_clips_partitions(trackers, frames_list, streams, cap=None, join=True):
-    """trackers[i].track_clips(frames_list[i]) on streams[i], all enqueued before any is waited for.  join=True: the caller's current
-    stream waits for every partition before the results are returned (a barrier per call).  join=False: nothing waits -- a pipeline that
-    feeds batch after batch keeps both partitions busy across batch boundaries (that is where most of the gain is: +3-4 % against
-    +1.4 % with the barrier) and synchronises streams[i] before it READS result i.  Each tracker must own its context."""
+    """trackers[i].track_clips(frames_list[i]) on streams[i], all enqueued before any is waited for.  Every partition stream first waits for
+    ONE event recorded on the caller's current stream (whatever produced frames_list[i] there -- an H2D copy, a preprocessing kernel -- is
+    complete before a partition reads it), and every result tensor is recorded on the caller's stream (`record_stream`: the caching
+    allocator will not hand its block to another stream while the caller may still use it).  join=True: the caller's stream also waits
+    for every partition before the results are returned (a barrier per call).  join=False: that trailing wait is skipped -- a pipeline
+    that feeds batch after batch keeps both partitions busy across batch boundaries (that is where most of the gain is: +3-4 % against
+    +1.4 % with the barrier) and synchronises streams[i] (or waits on an event of it) before it READS result i.  Each tracker must own
+    its context."""
     assert len(trackers) == len(frames_list) == len(streams)
     cur = torch.cuda.current_stream()
     # ONE event on the caller's stream, recorded before anything is launched: the CU-masked streams are blocking streams, and an
     # operation on the legacy default stream between two partitions' launches (an event record is one) orders the second partition
     # behind the whole of the first
-    ready = cur.record_event() if join else None
+    ready = cur.record_event()
     res = []
     for trk, fr, st in zip(trackers, frames_list, streams):
-        if join:
-            st.wait_event(ready)
+        st.wait_event(ready)
         with torch.cuda.stream(st):
-            res.append(trk.track_clips(fr, cap=cap))
+            r = trk.track_clips(fr, cap=cap)
+        for v in (r.values() if isinstance(r, dict) else ()):
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+        res.append(r)
     if join:
         for st in streams:
             cur.wait_stream(st)
     return res
-

@@ -379,9 +379,9 @@ def test_frame_sharded_tracker_gloo(tmp_path, world):
 
 
 def test_gather_detections_finds_padding_itself(tmp_path):
-    """uneven shards without n_clips_max: one scalar all-reduce finds the padding"""
+    """uneven shards with n_clips_max="max": one scalar all-reduce finds the padding (the default, None, means equal shards and no extra collective)"""
     script = tmp_path / "worker_auto.py"
-    script.write_text(_WORKER.replace("out = gather_detections(res, n_clips_max=n_max)", "out = gather_detections(res)"))
+    script.write_text(_WORKER.replace("out = gather_detections(res, n_clips_max=n_max)", "out = gather_detections(res, n_clips_max=\"max\")"))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29737", WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
