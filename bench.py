@@ -308,7 +308,9 @@ def _run():
     ap.add_argument("--clips", type=int, default=48, help="clips per GPU per step (track)")
     ap.add_argument("--T", type=int, default=30)
     ap.add_argument("--size", type=int, default=416)
-    ap.add_argument("--graphs", action="store_true", help="dt_graph_enable: hipGraph replay of the detector trunk / recurrences")
+    ap.add_argument("--graphs", dest="graphs", action="store_true", default=True,
+                    help="dt_graph_enable for the timed steps: hipGraph replay of the detector trunk / recurrences (default; the instrumented pass behind them runs plain launches)")
+    ap.add_argument("--no-graphs", dest="graphs", action="store_false", help="plain launches in the timed steps too")
     ap.add_argument("--boxes", type=int, default=32, help="boxes/frame the synthetic tracker head is calibrated to (track)")
     ap.add_argument("--batch", type=int, default=8, help="frames per step (detect)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -445,6 +447,8 @@ def _run():
     # ---- a SEPARATE instrumented pass for the per-kernel table and the roofline: HIP events around every launch, on the launch
     # stream (with --graphs: none -- profiling bypasses the replayed graphs, so the table then describes plain launches) ----
     prof_steps = max(1, min(args.prof_steps, args.steps))
+    if args.graphs:
+        ctx.graph_enable(False)       # per-launch events need plain launches
     ctx.profile_reset()
     ctx.profile_enable(True)
     sync_all()
@@ -606,7 +610,8 @@ def _run():
                        "tiny": "frames/sec detect + single-object LSTM track @416x416"}[args.workload],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "timing": {"headline": "%d steps without per-launch events (profile off)" % args.steps,
+            "timing": {"headline": "%d steps without per-launch events (profile off)%s" % (args.steps, ", detector trunk and recurrences replayed as hipGraphs (dt_graph_enable)" if args.graphs else ", plain launches"),
+                       "hipgraph": bool(args.graphs),
                        "ms_per_step_instrumented": 1e3 * elapsed_prof / prof_steps, "instrumented_steps": prof_steps,
                        "note": "kernels / roofline come from the separate instrumented pass (a HIP event pair around each of ~280 launches per step)"},
             "scaling": "strong" if (args.workload == "tiny" or (args.workload == "track" and args.shard == "frame" and world > 1)) else "weak",
@@ -676,9 +681,11 @@ def _run():
                             ("tiny_T64", lambda: tiny_extra(device, H, W, 32)),
                             # the headline workload with hipGraph replay of the detector trunk and the recurrence (dt_graph_enable): no
                             # per-launch events are possible inside a replayed graph, so the headline number (which carries them) runs without
-                            ("track_hipgraph", lambda: track_extra(device, H, args.clips, args.T, args.boxes, steps=args.steps, graphs=True,
-                                                                   what="the headline workload (BASELINE.json configs[2], %d clips x %d frames) with dt_graph_enable: the detector trunk "
-                                                                        "and the ConvLSTM recurrence replayed as hipGraphs, no per-launch events" % (args.clips, args.T))),
+                            ("track_plain_launches" if args.graphs else "track_hipgraph",
+                             lambda: track_extra(device, H, args.clips, args.T, args.boxes, steps=args.steps, graphs=not args.graphs,
+                                                 what="the headline workload (BASELINE.json configs[2], %d clips x %d frames) %s" % (
+                                                     args.clips, args.T, "with plain launches instead of hipGraph replay" if args.graphs else
+                                                     "with dt_graph_enable: the detector trunk and the ConvLSTM recurrence replayed as hipGraphs"))),
                             ("track_two_partitions", lambda: two_partitions_extra(device, H, args.clips, args.T, args.boxes, steps=args.steps)),
                             # the headline workload with the split-bf16 GEMMs switched off (DT_S3=0: v_mfma_f32_32x32x2_f32
                             # everywhere), same run, same clock: what the bf16-pipe arithmetic buys
