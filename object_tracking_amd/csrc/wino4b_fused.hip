@@ -42,7 +42,7 @@ typedef __bf16 b4_bf2 __attribute__((ext_vector_type(2)));
 typedef unsigned b4_u4 __attribute__((ext_vector_type(4)));
 
 #ifndef B4_NB
-#define B4_NB 1                          // 16-channel blocks per wave: 1 = sixteen waves per workgroup, 2 = eight (see the kernel's comment)
+#define B4_NB 2                          // 16-channel blocks per wave: 2 = eight waves per workgroup (default: 10.5 / 14.5 / 13.5 ms), 1 = sixteen (11.0 / 15.0 / 14.0)
 #endif
 #define B4_ROWPITCH 2304                 // bytes per patch row: 36 pixels x 4 slots x 16 B (34 pixels used; the XOR stays inside groups of 4)
 #define B4_CLS_PIECES 39                 // 17 rows x 144 slots = 2448 slots -> 39 DMA pieces of 64 slots

@@ -7,4 +7,4 @@ timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "fused or conv2_s
 grep -E "^E  |^FAILED|Error" $O/pytest.txt | cut -c1-300 | head -30
 fi
 timeout 600 python tools/fused4_bench.py ${FRAMES:-1440} 2>&1 | grep -E "conv_[235] " | grep "fused4=2" | tee $O/bench.txt
-for v in ${VARS:-tt0}; do for L in ${LAYERS:-conv_2}; do echo "== variant $v"; MI355_DT_LIB=$R/tools/_probe_builds/libmi355_dt_b4$v.so timeout 300 python tools/b4_timing.py $L ${FRAMES:-1440} 2>&1 | grep -v amdgpu.ids | head -${LINES:-5}; done; done | tee $O/timing.txt
+for v in ${VARS:-tt0}; do for L in ${LAYERS:-conv_2}; do echo "== variant $v"; MI355_DT_LIB=$R/tools/_probe_builds/libmi355_dt_b4$v.so timeout 300 python tools/b4_timing.py $L ${FRAMES:-1440} 2>&1 | grep -v "amdgpu.ids\|Warning\|wv, sel\|ret = ret\|sel\[" | head -${LINES:-5}; done; done | tee $O/timing.txt
