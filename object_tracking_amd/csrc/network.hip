@@ -758,8 +758,9 @@ static bool s3_1x1_eligible(const dt_ctx *ctx, const ConvLayer &L, long long M)
 static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld, int B, int H, int W, float *out,
                     int out_ld, int order, int epi, float slope, float *out2 = nullptr, int out2_ld = 0)
 {
-    if (L.bias_s3 && ctx->s3_ones && epi == EPI_PLAIN && order == ORD_LINEAR && !out2 && out_ld % 4 == 0 && in_ld % 4 == 0 &&
-        s3_1x1_eligible(ctx, L, (long long)B * H * W)) {
+    // (the split 1x1 form reads its A rows with 16-byte DMA pieces: a caller tensor at a 4 / 8 / 12-byte offset takes the fp32 kernel instead of failing)
+    if (L.bias_s3 && ctx->s3_ones && epi == EPI_PLAIN && order == ORD_LINEAR && !out2 && in_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 3) == 0 && s3_1x1_eligible(ctx, L, (long long)B * H * W)) {
         const long long M = (long long)B * H * W;
         GemmS3Args g;
         memset(&g, 0, sizeof(g));

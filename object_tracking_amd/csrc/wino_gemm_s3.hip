@@ -579,7 +579,7 @@ int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
 {
     // the Winograd form needs whole 128-column tiles; the 1x1 form (a_f32) any N >= 64 up to its padded weight rows Np
     if (a.a_f32 ? (a.Mt <= 0 || a.K < 32 || a.K % 16 || a.N < 64 || a.N > a.Np) : !wino_gemm_s3_usable(a.Mt, a.K, a.N)) return 2;
-    if (a.Mp % 256 || a.Mp < a.Mt || a.ldc % 4 || a.P <= 0) return 2;
+    if (a.Mp % 256 || a.Mp < a.Mt || (!S3_EPI_ROWS && a.ldc % 4) || a.P <= 0) return 2;      // (the row-form epilogue stores 4 bytes per lane: any ldc)
     if ((a.bias_s3 != nullptr) != (a.ones != nullptr)) return 2;
     // the 1x1 form: A = fp32 rows [Mt][a_ld] (a_f32), P = 1, LeakyReLU(slope) in the epilogue (slope 1 = none); the Winograd form: A = split terms (a)
     if (a.a_f32 ? (a.P != 1 || a.a_ld % 4 || a.a_ld < a.K || (reinterpret_cast<uintptr_t>(a.a_f32) & 15)) : (a.a == nullptr || a.act)) return 2;
