@@ -3,7 +3,7 @@
 # loads, 4 no LDS stores, 8 no fragment reads).  Results are numerically wrong by design;
 # the variants are selected with MI355_DT_LIB and only ever timed (tools/ablate_run.sh).
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 D=tools/_probe_builds; mkdir -p $D
 C=object_tracking_amd/csrc
 for m in "$@"; do

@@ -2,7 +2,7 @@
 """Per-launch HIP-event times of BASELINE.json configs[1] (YOLOv2 C=80, batch 8, 416x416): where a 1.8 ms batch goes.
    python tools/batch8_layers.py [batch]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import bench

@@ -3,7 +3,7 @@
    rocprofv3 --kernel-trace --stats to compare the kernels' own durations with the wall time per batch (launch gaps).
    python tools/batch8_trace.py [batch] [iters] [graphs 0|1]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import bench

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Single-layer timing through dt_conv2d (HIP events inside the library): python tools/conv_ab.py B H W Cin k Cout [pool]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

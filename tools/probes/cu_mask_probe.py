@@ -2,7 +2,7 @@
 """Probe: CU-masked HIP streams (hipExtStreamCreateWithCUMask) -- can an HBM-bound kernel on a few CUs run next to
 the persistent MFMA GEMM on the rest, and at what rates?   python tools/cu_mask_probe.py [n_mem_cus]"""
 import ctypes, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -2,7 +2,7 @@
 """diagnostic: the boosted-decode box comparison of tests/test_gpu_parity.py::test_detector_full_size_one_frame_vs_oracle under
 DT_WINO=2 / DT_WINO_TILE=6, for conv_1 on the split-bf16 kernel (DT_S3_CONV1=1) and on the fp32 MFMA kernel (0)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["DT_WINO"] = "2"; os.environ["DT_WINO_TILE"] = "6"
 import numpy as np, torch

@@ -3,7 +3,7 @@
 workgroup uses 64 VGPRs x 4 waves per SIMD and ~147 KB of LDS: half the register file and four wave slots per SIMD stay
 free for a kernel without LDS.   python tools/overlap_probe.py"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -3,7 +3,7 @@
 libmi355_dt_tt.so).  Runs one 1x1 GEMM-shaped launch and prints where a tile's time goes.
    MI355_DT_LIB=.../libmi355_dt_tt.so DT_CONV_CFG=3 python tools/tile_timing.py B H W Cin Cout"""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -2,7 +2,7 @@
 """Probe: do two half-batches on two HIP streams (two contexts) overlap the HBM-bound and the MFMA-bound phases?
    python tools/two_stream_probe.py [clips_total]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

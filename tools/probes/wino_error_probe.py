@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end error of the detector output against the float32 CPU oracle, per Winograd policy (4 frames 416x416)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import object_tracking_amd  # noqa: F401
