@@ -1149,11 +1149,16 @@ def test_graph_replay_lstm_sequence(ctx):
 
 
 # ---- conv_2's shape (32 -> 64 channels, pooled) through the fused F(4x4,3x3) kernel (csrc/wino4s_fused.hip) ---------
+F4_KERNELS = [("0", "conv_fused_kernel:fp32"), ("1", "conv_fused_kernel:bf16_split")]      # DT_F4B: wino4s_fused.hip (default) / wino4b_fused.hip
+
+
+@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma", "bf16_split"])
 @pytest.mark.parametrize("B,H,W", [(2, 16, 16), (3, 32, 48), (1, 18, 34), (2, 2, 2), (5, 104, 104)])
-def test_conv2_fused_winograd_vs_oracle(ctx, monkeypatch, B, H, W):
-    """32 -> 64 channels with the 2x2 pooling epilogue through the fused kernel (forced at any size): whole and
-    partial 16x16-pixel blocks, image borders, several frames; against the oracle and against the direct form."""
+def test_conv2_fused_winograd_vs_oracle(ctx, monkeypatch, B, H, W, f4b, ktag):
+    """32 -> 64 channels with the 2x2 pooling epilogue through the fused kernels (forced at any size): whole and
+    partial blocks, image borders, several frames; against the oracle and against the direct form."""
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
+    monkeypatch.setenv("DT_F4B", f4b)
     rs = np.random.RandomState(B * 100 + H + W)
     x = rs.randn(B, H, W, 32).astype(np.float32)
     w = (rs.randn(3, 3, 32, 64) * np.sqrt(2.0 / (9 * 32))).astype(np.float32)
@@ -1163,7 +1168,7 @@ def test_conv2_fused_winograd_vs_oracle(ctx, monkeypatch, B, H, W):
     ctx.profile_reset(); ctx.profile_enable(True)
     got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=1)
     ctx.profile_enable(False)
-    assert ctx.profile_read("conv_fused")["launches"] == 1
+    assert ctx.profile_read("conv_fused")["launches"] == 1 and ctx.profile_read(ktag)["launches"] == 1
     assert relerr(got.cpu().numpy(), ref) < 1e-4            # F(4x4,3x3): ~15x the direct form's rounding error
     monkeypatch.setenv("DT_WINO_FUSED4", "0")
     ctx.profile_reset(); ctx.profile_enable(True)
@@ -1173,9 +1178,11 @@ def test_conv2_fused_winograd_vs_oracle(ctx, monkeypatch, B, H, W):
     assert relerr(got.cpu().numpy(), direct.cpu().numpy()) < 1e-4
 
 
-def test_conv2_fused_winograd_one_hot(ctx, monkeypatch):
+@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma", "bf16_split"])
+def test_conv2_fused_winograd_one_hot(ctx, monkeypatch, f4b, ktag):
     """one-hot taps on small integers: any misplaced tile / channel / position is off by >= 1"""
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
+    monkeypatch.setenv("DT_F4B", f4b)
     B, H, W = 2, 20, 12
     x = (np.arange(B * H * W * 32, dtype=np.float32).reshape(B, H, W, 32) % 251)
     w = np.zeros((3, 3, 32, 64), dtype=np.float32)
@@ -1185,18 +1192,24 @@ def test_conv2_fused_winograd_one_hot(ctx, monkeypatch):
     assert np.abs(got - orc.maxpool2(orc.conv2d(x, w))).max() < 0.05
 
 
-@pytest.mark.parametrize("mode", ["default", "all_winograd"])
+@pytest.mark.parametrize("mode", ["default", "all_winograd", "bf16_fused"])
 def test_detector_non_square_odd_grid_vs_oracle(ctx, monkeypatch, mode):
     """352x288 frames (grid 11x9: odd, non-square, not a multiple of any Winograd tile), 5 frames (ragged mosaic
     groups, partial 16x16-pixel blocks of the fused kernel at 176x144 / 88x72 pixels): whole detector vs oracle."""
-    if mode == "all_winograd":
+    if mode != "default":
         monkeypatch.setenv("DT_WINO", "2")
         monkeypatch.setenv("DT_WINO_FUSED4", "2")
+    if mode == "bf16_fused":
+        monkeypatch.setenv("DT_F4B", "1")            # conv_2 / 3 / 5 (and 6 / 8 under DT_WINO_FUSED4=2) on wino4b_fused.hip inside the whole network
     det, layers, _ = _detector(ctx, 352, 288, 12)
     frames = synth.synth_clip(5, 352, 288, 3, seed=21)
     ref_net, ref_feat, _ = orc.yolov2_forward(orc.normalize_u8(frames), layers)
     c = det.model.ctx
+    c.profile_reset(); c.profile_enable(True)
     net, feat = c.detect_forward(dev(frames, c), want_feat=True)
+    c.profile_enable(False)
+    if mode == "bf16_fused":
+        assert c.profile_read("conv_fused_kernel:bf16_split")["launches"] >= 3 and c.profile_read("conv_fused_kernel:fp32")["launches"] == 0
     assert net.shape == (5, 11, 9, 5, 17)
     assert chan_err(flat_c(net.cpu().numpy()), flat_c(ref_net)) < NET_TOL
     assert chan_err(feat.cpu().numpy(), ref_feat) < NET_TOL
@@ -1245,8 +1258,10 @@ def test_winograd_randomized_shapes_vs_oracle(ctx, monkeypatch):
     (1, 13, 13, 128, 256, 0),     # odd size, smaller than a block
     (5, 104, 104, 64, 128, 0),    # conv_3's real geometry (6.5 blocks per side)
 ])
-def test_conv_fused_f4x4_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool):
+@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma", "bf16_split"])
+def test_conv_fused_f4x4_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool, f4b, ktag):
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
+    monkeypatch.setenv("DT_F4B", f4b)
     rs = np.random.RandomState(B * 100 + H + W + Cin)
     x = rs.randn(B, H, W, Cin).astype(np.float32)
     w = (rs.randn(3, 3, Cin, Cout) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
@@ -1258,17 +1273,19 @@ def test_conv_fused_f4x4_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool):
     ctx.profile_reset(); ctx.profile_enable(True)
     got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=pool)
     ctx.profile_enable(False)
-    assert ctx.profile_read("conv_fused")["launches"] == 1 and ctx.profile_read("wino_input")["launches"] == 0
+    assert ctx.profile_read("conv_fused")["launches"] == 1 and ctx.profile_read("wino_input")["launches"] == 0 and ctx.profile_read(ktag)["launches"] == 1
     assert relerr(got.cpu().numpy(), ref) < 1e-4            # F(4x4,3x3): ~15x the direct form's rounding error
     monkeypatch.setenv("DT_WINO_FUSED4", "0")
     other = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=pool)
     assert relerr(got.cpu().numpy(), other.cpu().numpy()) < 2e-4
 
 
+@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma", "bf16_split"])
 @pytest.mark.parametrize("B,H,W,pool", [(3, 32, 48, 1), (2, 208, 208, 1), (1, 26, 22, 0)])
-def test_conv2_shape_through_staged_f4x4_kernel(ctx, monkeypatch, B, H, W, pool):
-    """conv_2's shape (32 -> 64 channels) through the fused F(4x4) kernel: pooled and plain epilogue, the real 208x208 geometry"""
+def test_conv2_shape_through_staged_f4x4_kernel(ctx, monkeypatch, B, H, W, pool, f4b, ktag):
+    """conv_2's shape (32 -> 64 channels) through the fused F(4x4) kernels: pooled and plain epilogue, the real 208x208 geometry"""
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
+    monkeypatch.setenv("DT_F4B", f4b)
     rs = np.random.RandomState(B + H + W)
     x = rs.randn(B, H, W, 32).astype(np.float32)
     w = (rs.randn(3, 3, 32, 64) * np.sqrt(2.0 / (9 * 32))).astype(np.float32)
@@ -1284,9 +1301,11 @@ def test_conv2_shape_through_staged_f4x4_kernel(ctx, monkeypatch, B, H, W, pool)
     assert relerr(got.cpu().numpy(), ref) < 1e-4
 
 
-def test_conv_fused_f4x4_one_hot(ctx, monkeypatch):
-    """one-hot taps on small integers: every position / tile offset / channel slot of the fused kernel must line up"""
+@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma", "bf16_split"])
+def test_conv_fused_f4x4_one_hot(ctx, monkeypatch, f4b, ktag):
+    """one-hot taps on small integers: every position / tile offset / channel slot of the fused kernels must line up"""
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
+    monkeypatch.setenv("DT_F4B", f4b)
     B, H, W, Cin, Cout = 2, 20, 36, 64, 128
     x = (np.arange(B * H * W * Cin, dtype=np.float32).reshape(B, H, W, Cin) % 251)
     w = np.zeros((3, 3, Cin, Cout), dtype=np.float32)
