@@ -1100,6 +1100,34 @@ def test_winograd_default_policy_engages_on_wide_layers(ctx):
     assert relerr(got[:2].cpu().numpy(), ref) < 1e-4
 
 
+# ---- DT_PIN: kernel selection independent of the batch a call carries -----------------------
+def test_pinned_policy_is_batch_independent(ctx):
+    """Under parallel.pinned_policy (DT_PIN=1) a frame / a clip gets the same bits whatever batch it travels in: the detector on 12 frames
+    against the same frames in calls of 5 + 7 and one by one, the tracker on 4 clips against 3 + 1 -- torch.equal.  (Under the default
+    policy the same comparison differs at rounding level: other kernels are selected for other batch sizes -- also checked, so that the
+    test would notice if it stopped exercising anything.)"""
+    from parallel import pinned_policy
+    H, W, T, C = 96, 128, 3, 12
+    trk, blob, tw = _tracker(H, W, T, C)
+    c = trk.model.ctx
+    frames = np.stack([synth.synth_clip(T, H, W, 2, seed=90 + i) for i in range(4)])
+    d = dev(frames, c)                                    # [4, T, H, W, 3]
+    flat = d.reshape(4 * T, H, W, 3).contiguous()
+    with pinned_policy(c):
+        whole = c.detect_forward(flat)
+        parts = torch.cat([c.detect_forward(flat[:5].contiguous()), c.detect_forward(flat[5:].contiguous())])
+        singles = torch.cat([c.detect_forward(flat[i:i + 1].contiguous()) for i in range(4 * T)])
+        assert torch.equal(whole, parts) and torch.equal(whole, singles)
+        t_whole, _ = c.track_forward(d)
+        t_parts = torch.cat([c.track_forward(d[:3].contiguous())[0], c.track_forward(d[3:].contiguous())[0]])
+        assert torch.equal(t_whole, t_parts)
+    # the policy is restored on exit; under it the single-frame calls take other kernels than the 12-frame call
+    plain_whole = c.detect_forward(flat)
+    plain_singles = torch.cat([c.detect_forward(flat[i:i + 1].contiguous()) for i in range(4 * T)])
+    assert chan_err(flat_c(plain_whole.cpu().numpy()), flat_c(plain_singles.cpu().numpy())) < 1e-4
+    assert chan_err(flat_c(plain_whole.cpu().numpy()), flat_c(whole.cpu().numpy())) < 1e-4
+
+
 # ---- hipGraph replay of the launch-bound inner sequences (dt_graph_enable) ------------------
 def test_graph_replay_is_bit_identical(ctx):
     """Detector trunk, ConvLSTM recurrence and LSTM sequence captured on the second call with a shape and
