@@ -118,6 +118,9 @@ struct WinoArgs {
     const float *m;
     int m_ld, N;
     const float *bias;
+    const float *bias16;    // non-null (plain epilogue, slope 1): a CORRECTION to `bias` for pixels on the image border, [16][N] indexed by
+                            // (h == 0) | (h == H - 1) << 1 | (w == 0) << 2 | (w == W - 1) << 3 (entry 0 unused: interior pixels take `bias` alone) -- the
+                            // merged ConvLSTM input projection: conv_23's bias reaches the projection through the taps that lie inside the image only
     float slope;
     float *out;
     long long out_bs;
@@ -282,6 +285,9 @@ struct Policy {
     int mosaic = -1;         // DT_WINO_MOSAIC: 1 never, 2/3/4 force, -1 = fewest tiles
     int fused4 = 1;          // DT_WINO_FUSED4: the fused F(4x4) kernel (wino4s_fused.hip): 0 never / 1 conv_2 / 3 / 5 (Cin <= 64) from 1024
                              //                 blocks / 3 also conv_6 / 8 (Cin 128) / 2 any eligible layer at any size.  Read at weight load (0) and per launch
+    int trk_merge = 1;       // DT_TRK_MERGE: the ConvLSTM2D input projection reads conv_feat only -- conv_23 (1x1, linear: x_bbox = W23 feat + b23) is folded into the
+                             //               projection's weights at load (W' = Wx[feat] + W23 Wx[bbox] in float64, b23 through a border-aware bias): K 1120 -> 1024 and no
+                             //               conv_23 launch when the caller does not ask for the detector's grid; 0 = the two-step form.  Winograd path only (large batches)
     int pin = 0;             // DT_PIN: 1 = kernel selection independent of the batch a call happens to carry (the frame-sharded tracker runs the same
                              //         frame in batches of other sizes for other world sizes): Winograd wherever defined, no frame mosaics, the fused kernel
                              //         and the split GEMM at any size, one tile form, no split-K, no F(4x4)/F(6x6) choice by tile count.  Slower at small
@@ -336,6 +342,10 @@ struct dt_ctx {
     float *trk_wx = nullptr, *trk_bx = nullptr;   // input conv, N gate-interleaved
     float *trk_wh = nullptr;                      // recurrent conv
     float *trk_wx_wino = nullptr, *trk_wh_wino = nullptr;   // their Winograd-domain forms
+    float *trk_wxm_wino = nullptr;                // F(6x6) weights of the MERGED input projection (conv_23 folded in; 1024 input channels) or null
+    float *trk_bx16 = nullptr;                    // its bias: [17][4U] gate-interleaved -- row 0 the interior bias, rows 1 + k the correction of border case k
+    std::vector<float> conv23_hwio, conv23_bias;  // host copies of conv_23 ([1024][cb], [cb]) and of the ConvLSTM input kernel / bias (Keras HWIO, x_bbox first):
+    std::vector<float> trk_hkernel, trk_hbias;    // what the merge is computed from, whichever of the two loaders runs second
     int trk_wino_ts = 0, trk_wh_ts = 0;   // tile of the input / recurrent convolution's Winograd weights
     float *trk_wo = nullptr, *trk_bo = nullptr;   // tconv_2 1x1
     int trk_wo_npad = 0;

@@ -213,6 +213,8 @@ extern "C" void dt_destroy(dt_ctx *ctx)
         if (ctx->layers[i].fused4b) (void)hipFree(ctx->layers[i].fused4b);
         if (ctx->layers[i].scale) (void)hipFree(ctx->layers[i].scale);
     }
+    if (ctx->trk_wxm_wino) { s3_drop(ctx, ctx->trk_wxm_wino); (void)hipFree(ctx->trk_wxm_wino); }
+    if (ctx->trk_bx16) (void)hipFree(ctx->trk_bx16);
     float *singles[] = {ctx->conv1_w, ctx->conv1_b, ctx->lut255, ctx->anchors_dev, ctx->trk_wx, ctx->trk_bx,
                         ctx->trk_wh,  ctx->trk_wo,  ctx->trk_bo, ctx->trk_wx_wino, ctx->trk_wh_wino, ctx->tiny_wx,     ctx->tiny_bx, ctx->tiny_ur,
                         ctx->tiny_wd, ctx->tiny_bd};
@@ -367,6 +369,65 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
     return upload(ctx, &L.bias, bias);
 }
 
+// The ConvLSTM2D input projection with conv_23 folded in (Policy::trk_merge).  z = [x_bbox | conv_feat] with x_bbox = W23 feat + b23 inside
+// the image (conv_23 is a 1x1 convolution with a LINEAR activation, KerasYOLO.py:396-400) and zero in the 'same' padding, so
+//     Wx * z + b  =  (Wx[feat] + W23 Wx[bbox]) * feat  +  b  +  sum over the taps INSIDE the image of  b23 . Wx[bbox][tap]
+// -- one 3x3 convolution of conv_feat alone (K = 1024 instead of 1109 -> 1120) with a bias that depends on which of its nine taps lie
+// inside the image (16 border cases).  Merged in float64 on the host whenever both weight sets are present; used by the Winograd path
+// of the projection (convlstm_sequence), the two-step form stays for the small-batch direct path and for DT_TRK_MERGE=0.
+static void gate_interleave_map(int U, std::vector<int> &n_map);
+static int build_merged_xproj(dt_ctx *ctx)
+{
+    if (ctx->trk_wxm_wino) { (void)hipStreamSynchronize(ctx->stream); s3_drop(ctx, ctx->trk_wxm_wino); (void)hipFree(ctx->trk_wxm_wino); ctx->trk_wxm_wino = nullptr; }
+    if (ctx->trk_bx16) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->trk_bx16); ctx->trk_bx16 = nullptr; }
+    const int Cb = ctx->cb, U = ctx->trk_units, N4 = 4 * U, Csrc = Cb + 1024;
+    if (!ctx->pol.trk_merge || !U || ctx->conv23_hwio.size() != (size_t)1024 * Cb || ctx->trk_hkernel.size() != (size_t)9 * Csrc * N4) return DT_OK;
+    if (!wino_wanted(ctx, 3, 1024, N4) || wino_tile(ctx, false) != 6 || ctx->trk_wino_ts != 6) return DT_OK;
+    const float *wk = ctx->trk_hkernel.data(), *w23 = ctx->conv23_hwio.data();
+    std::vector<float> merged((size_t)9 * 1024 * N4);
+    std::vector<double> row(N4);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int c = 0; c < 1024; ++c) {
+            const float *src = wk + ((size_t)tap * Csrc + Cb + c) * N4;           // Keras input order: x_bbox first, then conv_feat
+            for (int n = 0; n < N4; ++n) row[n] = src[n];
+            for (int j = 0; j < Cb; ++j) {
+                const double a = w23[(size_t)c * Cb + j];
+                const float *wb = wk + ((size_t)tap * Csrc + j) * N4;
+                for (int n = 0; n < N4; ++n) row[n] += a * wb[n];
+            }
+            float *dst = merged.data() + ((size_t)tap * 1024 + c) * N4;
+            for (int n = 0; n < N4; ++n) dst[n] = (float)row[n];
+        }
+    std::vector<int> n_map;
+    gate_interleave_map(U, n_map);
+    // bias of border case k: b + sum over the taps (dy, dx) whose pixel exists: dy = 0 needs h > 0, dy = 2 needs h < H - 1, likewise dx
+    std::vector<double> tapb((size_t)9 * N4, 0.0);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int j = 0; j < Cb; ++j) {
+            const double bj = ctx->conv23_bias[j];
+            const float *wb = wk + ((size_t)tap * Csrc + j) * N4;
+            for (int n = 0; n < N4; ++n) tapb[(size_t)tap * N4 + n] += bj * wb[n];
+        }
+    // row 0: the interior bias (all nine taps); row 1 + k: what border case k takes away from it (the taps outside the image), as a correction
+    std::vector<float> b16((size_t)17 * N4);
+    for (int k = 0; k < 16; ++k)
+        for (int np = 0; np < N4; ++np) {
+            const int n = n_map[np];
+            double all = ctx->trk_hbias[n], out = 0.0;
+            for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx) {
+                    const bool in = !(dy == 0 && (k & 1)) && !(dy == 2 && (k & 2)) && !(dx == 0 && (k & 4)) && !(dx == 2 && (k & 8));
+                    all += tapb[(size_t)(dy * 3 + dx) * N4 + n];
+                    if (!in) out += tapb[(size_t)(dy * 3 + dx) * N4 + n];
+                }
+            if (k == 0) b16[np] = (float)all;
+            b16[(size_t)(1 + k) * N4 + np] = (float)(-out);
+        }
+    int rc = upload_wino(ctx, &ctx->trk_wxm_wino, 6, merged.data(), 1024, N4, nullptr, 1024, n_map.data(), N4, nullptr, true);
+    if (rc) return rc;
+    return upload(ctx, &ctx->trk_bx16, b16);
+}
+
 extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t n_floats, size_t *consumed)
 {
     if (!ctx || !h_blob) return DT_ERR_ARG;
@@ -431,11 +492,13 @@ extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t 
         oihw_to_hwio(kern, co, 1024, 1, hwio);
         int rc = load_conv_layer(ctx, 23, 1, 1024, co, hwio.data(), nullptr, bias);
         if (rc) return rc;
+        ctx->conv23_hwio.assign(hwio.begin(), hwio.begin() + (size_t)1024 * co);      // [1024][co]
+        ctx->conv23_bias.assign(bias, bias + co);
     }
     if (consumed) *consumed = off;
     graphs_clear(ctx);
     ctx->det_loaded = true;
-    return DT_OK;
+    return build_merged_xproj(ctx);
 }
 
 // Direct-form FLOPs (2*M*K*N of the reference's convolution) and bytes (in + weights + out, fp32) of every layer, booked
@@ -489,6 +552,7 @@ void policy_from_env(Policy &p)
     p.persist = geti("DT_PERSIST", d.persist);
     p.xcd_remap = geti("DT_XCD_REMAP", d.xcd_remap);
     p.tile_gn = geti("DT_TILE_GN", d.tile_gn);
+    p.trk_merge = geti("DT_TRK_MERGE", d.trk_merge);
     p.pin = geti("DT_PIN", d.pin);
     if (p.pin) {      // every choice below otherwise looks at the number of frames / rows / tiles of the launch
         p.wino = 2; p.mosaic = 1; p.fused4 = 2; p.s3_half = -1; p.ksplit = 1;
@@ -612,6 +676,7 @@ struct WinoIO {
     float *out2; int out2_ld;                         // 2x2 pooled output or null
     const float *xproj; long long xp_bs; int xp_ld;   // gates variant (cstate != null)
     float *cstate; long long c_bs; int c_ld;
+    const float *bias16;                              // border-aware bias [16][N] instead of `bias` (WinoArgs::bias16) or null
 };
 
 // Tile geometry of a Winograd launch.  Mosaic factor g: g x g frames with zero separators share one virtual image
@@ -669,7 +734,7 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
     if (!V || !Mp) return DT_ERR_DEVICE;
     if (u_s3) { w.v_s3 = reinterpret_cast<unsigned short *>(V); w.Mp = (int)mp; }
     w.in = io.in; w.in_bs = io.in_bs; w.in_ld = io.in_ld; w.C = cin; w.v = V;
-    w.m = Mp; w.m_ld = N; w.N = N; w.bias = bias; w.slope = slope;
+    w.m = Mp; w.m_ld = N; w.N = N; w.bias = bias; w.bias16 = io.bias16; w.slope = slope;
     w.out = io.out; w.out_bs = io.out_bs; w.out_ld = io.out_ld; w.out2 = io.out2; w.out2_ld = io.out2_ld;
     w.xproj = io.xproj; w.xp_bs = io.xp_bs; w.xp_ld = io.xp_ld;
     w.cstate = io.cstate; w.c_bs = io.c_bs; w.c_ld = io.c_ld;
@@ -954,7 +1019,7 @@ static int run_trunk(dt_ctx *ctx, int B, float *bufA, float *bufB, float *skip, 
 }
 
 // Runs conv_1 .. conv_23.  feat/netout destinations may alias caller buffers.
-static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, Dest feat, Dest netout)
+static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, Dest feat, Dest netout, bool skip23 = false)
 {
     if (!ctx->det_loaded) return dt_fail(ctx, DT_ERR_STATE, "detector weights not loaded");
     if (B <= 0) return dt_fail(ctx, DT_ERR_ARG, "batch must be positive");
@@ -996,7 +1061,8 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
     // conv_22 -> 'conv_feat'
     rc = run_conv(ctx, ctx->layers[22], cat, 1280, B, h, w, feat.p, feat.ld, ORD_LINEAR, EPI_PLAIN, LEAKY);
     if (rc) return rc;
-    // conv_23 (bias, linear)
+    // conv_23 (bias, linear) -- unless nobody reads it: the tracker's merged input projection (build_merged_xproj) carries it in its weights
+    if (skip23) { ctx->tap_netout = false; return DT_OK; }
     rc = run_conv(ctx, ctx->layers[23], feat.p, feat.ld, B, h, w, netout.p, netout.ld, ORD_LINEAR, EPI_PLAIN, 1.0f);
     return rc;
 }
@@ -1286,9 +1352,19 @@ extern "C" int dt_tracker_load(dt_ctx *ctx, int units, const float *h_kernel, co
                           nullptr, ctx->trk_wh_ts == 4)))
         return rc;
     ctx->trk_units = U; ctx->trk_cx = Cx; ctx->trk_wo_npad = npad;
+    ctx->trk_hkernel.assign(h_kernel, h_kernel + (size_t)9 * Csrc * 4 * U);
+    ctx->trk_hbias.assign(h_bias, h_bias + (size_t)4 * U);
     graphs_clear(ctx);
     ctx->trk_loaded = true;
-    return DT_OK;
+    return build_merged_xproj(ctx);
+}
+
+// does the input projection of F frames take the merged form (conv_23 folded in)?  The same predicate decides whether dt_track_forward
+// may skip conv_23 when the caller does not ask for the detector's grid.
+static bool xproj_merged(const dt_ctx *ctx, int F, int gh, int gw)
+{
+    return ctx->pol.trk_merge && ctx->trk_wxm_wino && ctx->trk_bx16 && ctx->trk_wino_ts == 6 &&
+           wino_runs(ctx, ctx->trk_wxm_wino, 6, F, gh, gw, 1024, 4 * ctx->trk_units);
 }
 
 // xproj = conv3x3(z, Wx) + b for all frames; then the sequential recurrence.
@@ -1315,7 +1391,18 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
     }
     const std::string shape = std::to_string(n_clips) + "x" + std::to_string(T);
     auto input_projection = [&]() -> int {
-    if (wino_runs(ctx, wx_wino, ctx->trk_wino_ts, F, gh, gw, Cx, N4)) {
+    if (z_owned && xproj_merged(ctx, F, gh, gw) && wx_wino == ctx->trk_wx_wino) {
+        // conv_23 folded into the projection (build_merged_xproj): the 1024 conv_feat channels of z only, border-aware bias -- for the library's OWN z
+        // rows only (dt_track_forward, dt_track_detect_xproj): a caller's rows (dt_track_recurrent) may carry any x_bbox and get the two-step form
+        WinoIO io;
+        memset(&io, 0, sizeof(io));
+        io.in = z; io.in_ld = Cx; io.in_bs = (long long)GG * Cx;
+        io.out = xproj; io.out_ld = N4; io.out_bs = (long long)GG * N4;
+        io.bias16 = ctx->trk_bx16 + N4;         // corrections of the 16 border cases; row 0 of the table is the interior bias
+        if (ctx->prof && !ctx->capturing) ctx->prof_tab["convlstm_xproj:merged_conv23"].launches += 1;
+        const int rc = run_wino(ctx, ctx->trk_wxm_wino, 6, ctx->trk_bx16, 1024, N4, N4, F, gh, gw, io, 1.0f, "convlstm_xproj", ctx->cb + 1024);
+        if (rc) return rc;
+    } else if (wino_runs(ctx, wx_wino, ctx->trk_wino_ts, F, gh, gw, Cx, N4)) {
         WinoIO io;
         memset(&io, 0, sizeof(io));
         io.in = z; io.in_ld = Cx; io.in_bs = (long long)GG * Cx;
@@ -1420,7 +1507,7 @@ extern "C" int dt_track_forward(dt_ctx *ctx, const void *d_frames, int frames_dt
     const int F = n_clips * T, Cx = ctx->trk_cx, Cb = ctx->cb;
     float *z = ws_get(ctx, "trk_z", (size_t)F * GG * Cx * sizeof(float), /*zero_on_grow=*/true);
     if (!z) return DT_ERR_DEVICE;
-    int rc = detect_internal(ctx, d_frames, frames_dtype, F, Dest{z, Cx}, Dest{z + 1024, Cx});
+    int rc = detect_internal(ctx, d_frames, frames_dtype, F, Dest{z, Cx}, Dest{z + 1024, Cx}, /*skip23=*/!d_det && xproj_merged(ctx, F, gh, gw));
     if (rc) return rc;
     rc = track_recurrent_internal(ctx, z, n_clips, T, d_trk);
     if (rc) return rc;
@@ -1484,7 +1571,7 @@ extern "C" int dt_track_detect_xproj(dt_ctx *ctx, const void *d_frames, int fram
     const int Cx = ctx->trk_cx, Cb = ctx->cb;
     float *z = ws_get(ctx, "trk_z", (size_t)n_frames * GG * Cx * sizeof(float), /*zero_on_grow=*/true);
     if (!z) return DT_ERR_DEVICE;
-    int rc = detect_internal(ctx, d_frames, frames_dtype, n_frames, Dest{z, Cx}, Dest{z + 1024, Cx});
+    int rc = detect_internal(ctx, d_frames, frames_dtype, n_frames, Dest{z, Cx}, Dest{z + 1024, Cx}, /*skip23=*/!d_det && xproj_merged(ctx, n_frames, gh, gw));
     if (rc) return rc;
     rc = convlstm_sequence(ctx, z, Cx, n_frames, 1, gh, gw, ctx->trk_units, ctx->trk_wx, ctx->trk_bx, ctx->trk_wh, nullptr,
                            ctx->trk_wx_wino, ctx->trk_wh_wino, d_xp);

@@ -325,6 +325,12 @@ __device__ __forceinline__ void wino_at_m_a(const float *src, long long plane, t
     for (int i = 0; i < TS; ++i) at_1d<TS>(m[i]);   // (At m) A : along the rows
 }
 
+// which of the 16 border cases pixel (h, w) of an H x W frame is (WinoArgs::bias16)
+__device__ __forceinline__ int wino_border_case(const WinoArgs &p, int h, int w)
+{
+    return (h == 0 ? 1 : 0) | (h == p.H - 1 ? 2 : 0) | (w == 0 ? 4 : 0) | (w == p.W - 1 ? 8 : 0);
+}
+
 // ---- output transform, conv block epilogue -------------------------------------------------------
 // One work item = (tile, V output channels): bias + LeakyReLU, optional full-resolution output and
 // optional 2x2-pooled output.
@@ -358,8 +364,14 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
 #pragma unroll
                 for (int j = 0; j < TS; ++j) {
                     int b, h, w;
-                    if (vpixel(p, t.grp, TS * t.ty + i, TS * t.tx + j, b, h, w))
-                        vstore_nt<V>(p.out + (long long)b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c, m[i][j]);
+                    if (vpixel(p, t.grp, TS * t.ty + i, TS * t.tx + j, b, h, w)) {
+                        T v = m[i][j];
+                        if (p.bias16) {    // (slope 1: launcher) border pixels add their case's correction to the interior bias already in v
+                            const int k = wino_border_case(p, h, w);
+                            if (k) v = v + vload<V>(p.bias16 + (long long)k * p.N + c);
+                        }
+                        vstore_nt<V>(p.out + (long long)b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c, v);
+                    }
                 }
         }
         if (p.out2) {   // MaxPooling2D(2,2): H and W are even whenever the reference pools; g == 1 (launcher)
@@ -712,8 +724,13 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
                 for (int e = 0; e < 4; ++e) set_lane<4>(v, e, wino_leaky(lane_of<4>(v, e), p.slope));
                 row[j] = v;
                 int b, h, w;
-                if (live && p.out && vpixel(p, t.grp, 6 * t.ty + sub, 6 * t.tx + j, b, h, w))
+                if (live && p.out && vpixel(p, t.grp, 6 * t.ty + sub, 6 * t.tx + j, b, h, w)) {
+                    if (p.bias16) {
+                        const int k = wino_border_case(p, h, w);
+                        if (k) v = v + vload<4>(p.bias16 + (long long)k * p.N + c);
+                    }
                     vstore_nt<4>(p.out + (long long)b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c, v);
+                }
             }
         }
         if (p.out2) {   // MaxPooling2D(2,2) (g == 1: launcher): output rows 2k, 2k+1 sit in neighbouring lanes
@@ -821,6 +838,7 @@ int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates)
     } else {
         // vector stores need aligned rows; ragged N (conv_23-like heads) never takes this path
         if (a.N % 4 || (a.out && a.out_ld % 4) || (a.out2 && a.out2_ld % 4)) return 2;
+        if (a.bias16 && (a.slope != 1.0f || a.out2 || !a.out)) return 2;      // the border corrections: linear, full-resolution epilogue only
         if (a.ts == 6 && wino_coop_wanted(a, (long long)a.Mt * (a.N / 2))) {
             const long long wgs = ((long long)a.Mt * (a.N / 4) + WINO_THREADS / 8 - 1) / (WINO_THREADS / 8);
             hipLaunchKernelGGL(wino_output_coop6_kernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);

@@ -120,6 +120,8 @@ d = trk.detector.model.to_device(frames)
 z = ctx.track_detect(d.reshape(N * T, H, W, 3))
 halves = ctx.track_recurrent(z.reshape(N, T, 3, 3, -1))
 whole = ctx.track_forward(d, want_det=False)
+# (caller-owned z rows take the two-step input projection, dt_track_forward the one with conv_23 folded into its weights when its Winograd form
+#  runs: equal bit for bit at this size, where both take the direct form; the merged form is compared in test_tracker_merged_input_projection)
 flags["halves_z"] = torch.equal(halves, whole)
 flags["halves_z_err"] = float((halves - whole).abs().max())
 flags["deterministic"] = torch.equal(whole, ctx.track_forward(d, want_det=False))

@@ -1100,6 +1100,38 @@ def test_winograd_default_policy_engages_on_wide_layers(ctx):
     assert relerr(got[:2].cpu().numpy(), ref) < 1e-4
 
 
+# ---- conv_23 folded into the ConvLSTM input projection (DT_TRK_MERGE, network.hip:build_merged_xproj) ----------------
+@pytest.mark.parametrize("H,W,n_clips,T", [(96, 128, 6, 5), (32, 32, 40, 3), (416, 416, 2, 4)])
+def test_tracker_merged_input_projection(ctx, monkeypatch, H, W, n_clips, T):
+    """x_bbox = conv_23(conv_feat) is linear, so Wx * [x_bbox | conv_feat] + b is ONE 3x3 convolution of conv_feat with merged weights and a bias
+    that knows which taps lie inside the image.  The merged form (default where the projection's Winograd path runs; conv_23 is not launched when
+    the detector's grid is not asked for) against the two-step form (DT_TRK_MERGE=0) and against the oracle, with and without want_det, on grids
+    with every border case (3x4), with one cell (1x1: all four borders at once) and at 13x13."""
+    monkeypatch.setenv("DT_WINO", "2")                     # the projection's Winograd path at any size
+    trk, blob, tw = _tracker(H, W, T, 12)
+    c = trk.model.ctx
+    frames = np.stack([synth.synth_clip(T, H, W, 2, seed=40 + i) for i in range(n_clips)])
+    d = dev(frames, c)
+    outs = {}
+    for merge in ("1", "0"):
+        monkeypatch.setenv("DT_TRK_MERGE", merge)
+        c.reload_policy()
+        c.profile_reset(); c.profile_enable(True)
+        t_only = c.track_forward(d, want_det=False)
+        n23 = c.profile_read("conv_gemm_s3:conv_23")["launches"] + c.profile_read("conv_igemm:conv_23")["launches"]
+        t_both, det = c.track_forward(d, want_det=True)
+        c.profile_enable(False)
+        assert c.profile_read("convlstm_xproj:merged_conv23")["launches"] == (2 if merge == "1" else 0)
+        assert n23 == (0 if merge == "1" else 1)           # merged and nobody reads x_bbox: conv_23 is not launched
+        assert torch.equal(t_only, t_both)
+        outs[merge] = (t_both.cpu().numpy(), det.cpu().numpy())
+    assert np.array_equal(outs["1"][1], outs["0"][1])      # the detector's grid itself is conv_23's output either way
+    assert chan_err(flat_c(outs["1"][0]), flat_c(outs["0"][0])) < 1e-4         # two roundings of the same network through T recurrent steps (measured 5e-5)
+    layers, used = orc.parse_darknet_blob(blob, 12)
+    ref = np.stack([orc.tracker_forward(orc.normalize_u8(frames[i]), layers, tw)[0] for i in range(min(2, n_clips))])
+    assert chan_err(flat_c(outs["1"][0][:ref.shape[0]]), flat_c(ref)) < 3e-4
+
+
 # ---- DT_PIN: kernel selection independent of the batch a call carries -----------------------
 def test_pinned_policy_is_batch_independent(ctx):
     """Under parallel.pinned_policy (DT_PIN=1) a frame / a clip gets the same bits whatever batch it travels in: the detector on 12 frames
