@@ -183,6 +183,14 @@ __device__ __forceinline__ float c1_bf16_f32(unsigned short h) { return __uint_a
 #else
 #define C1_SYNC() __syncthreads()
 #endif
+#ifndef C1_NTS
+#define C1_NTS 1             // 1: the output rows as nontemporal stores (A/B builds)
+#endif
+#if C1_NTS
+#define C1_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define C1_STORE(ptr, val) (*(ptr) = (val))
+#endif
 #ifndef C1_ABLATE
 #define C1_ABLATE 0          // timing-only builds (results WRONG): 1 no output stores, 2 no frame loads, 4 no fragment reads + MFMAs, 8 no staging
 #endif
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
                     const float mx = fmaxf(fmaxf(acc[gi][4 * j], acc[gi][4 * j + 1]), fmaxf(acc[gi][4 * j + 2], acc[gi][4 * j + 3])) + bias;
                     const float v = mx > 0.0f ? mx : mx * p.slope;
                     const int ox = bx * 8 + h + 2 * j;
-                    if ((C1_ABLATE & 1) ? v == 12345.678f : (FULL || (oy < H2 && ox < W2))) p.out[(((long long)b * H2 + oy) * W2 + ox) * 32 + n] = v;
+                    if ((C1_ABLATE & 1) ? v == 12345.678f : (FULL || (oy < H2 && ox < W2))) C1_STORE(&p.out[(((long long)b * H2 + oy) * W2 + ox) * 32 + n], v);
                 }
             }
         }

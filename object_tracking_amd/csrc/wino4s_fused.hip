@@ -132,6 +132,14 @@ __device__ __forceinline__ void s4_transform_half(const float (&w5)[5][6], float
     }
 }
 
+#ifndef S4_NTS
+#define S4_NTS 1            // 1: the epilogue's activation stores as nontemporal stores (A/B builds)
+#endif
+#if S4_NTS
+#define S4_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define S4_STORE(ptr, val) (*(ptr) = (val))
+#endif
 #ifndef S4_ABLATE
 #define S4_ABLATE 0         // timing-only ablation builds (results WRONG): 1 no U DMA, 2 no patch DMA, 4 no input transform, 8 no operand reads,
                             // 16 patch addresses as for a channel-blocked input, 32 patch pieces from a contiguous source
@@ -451,13 +459,13 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
 #pragma unroll
                             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) ob[a * rs + c * p.out_ld] = m[6 * a + c][h];
+                                for (int c = 0; c < 4; ++c) S4_STORE(&ob[a * rs + c * p.out_ld], m[6 * a + c][h]);
                         } else {
 #pragma unroll
                             for (int a = 0; a < 4; ++a)
 #pragma unroll
                                 for (int c = 0; c < 4; ++c)
-                                    if (y0 + a < p.H && x0 + 4 * e + c < p.W) ob[a * rs + c * p.out_ld] = m[6 * a + c][h];
+                                    if (y0 + a < p.H && x0 + 4 * e + c < p.W) S4_STORE(&ob[a * rs + c * p.out_ld], m[6 * a + c][h]);
                         }
                     } else {
                         const int H2 = p.H >> 1, W2 = p.W >> 1;
@@ -474,13 +482,13 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
 #pragma unroll
                             for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-                                for (int c2 = 0; c2 < 2; ++c2) ob[a2 * rs + c2 * p.out2_ld] = mx[a2][c2];
+                                for (int c2 = 0; c2 < 2; ++c2) S4_STORE(&ob[a2 * rs + c2 * p.out2_ld], mx[a2][c2]);
                         } else {
 #pragma unroll
                             for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
                                 for (int c2 = 0; c2 < 2; ++c2)
-                                    if ((y0 >> 1) + a2 < H2 && (x0 >> 1) + 2 * e + c2 < W2) ob[a2 * rs + c2 * p.out2_ld] = mx[a2][c2];
+                                    if ((y0 >> 1) + a2 < H2 && (x0 >> 1) + 2 * e + c2 < W2) S4_STORE(&ob[a2 * rs + c2 * p.out2_ld], mx[a2][c2]);
                         }
                     }
                 }
