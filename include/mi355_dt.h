@@ -48,7 +48,7 @@ DT_API int dt_create(dt_ctx **out);
 DT_API void dt_destroy(dt_ctx *ctx);
 DT_API const char *dt_last_error(dt_ctx *ctx);
 DT_API int dt_set_stream(dt_ctx *ctx, void *hip_stream);
-/* ABI version of this header: major*100+minor (1.06: 1.05 + dt_gemm_split_bf16) */
+/* ABI version of this header: major*100+minor (1.07: 1.06 + dt_gemm_split) */
 DT_API int dt_abi_version(void);
 
 /* ---- detector: KerasYOLO ---------------------------------------------- */
@@ -283,6 +283,13 @@ DT_API int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int W, 
  * 2 = the 1x1 layers' form (P = 1): d_v is read as fp32 rows by the kernel itself, which splits its A fragments in registers. */
 DT_API int dt_gemm_split_bf16(dt_ctx *ctx, const float *d_v, const float *d_u, int P, int Mt, int K, int N, int half,
                               float *d_m);
+/* The same with the operand form chosen: nt = 3 -- three bf16 terms, six partial products per multiply (dt_gemm_split_bf16);
+ * nt = 2 -- the fp16 form the library runs by default since round 6: each operand scaled by a power of two from its measured
+ * max |x| (d_v as ONE tensor, like an activation; d_u per plane p, like the Winograd-domain weights) and carried as two fp16
+ * terms hi + lo, three partial products lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16, the fp32 accumulator scaled back
+ * in the epilogue (P <= 64). */
+DT_API int dt_gemm_split(dt_ctx *ctx, const float *d_v, const float *d_u, int P, int Mt, int K, int N, int half, int nt,
+                         float *d_m);
 
 /* ---- tuning / test knobs ------------------------------------------------- *
  * The DT_* environment variables of DESIGN.md's appendix are read ONCE, in dt_create (no launch path calls

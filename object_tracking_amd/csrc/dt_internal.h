@@ -114,6 +114,8 @@ struct WinoArgs {
     float *v;
     unsigned short *v_s3;   // non-null: V as three bf16 terms [P][3][C/16][Mp][16] for wino_gemm_s3.hip instead of v (ts == 6, C % 32 == 0)
     int Mp;                 // rows of that layout (Mt rounded up to the GEMM's row tile)
+    int nt;                 // 2: v_s3 takes TWO fp16 terms [P][2][C/16][Mp][16] of the scaled V (wino_gemm_s3.hip's fp16 form); 0 / 3: three bf16 terms
+    const unsigned *amax;   // nt = 2: the max-|x| slot (DT_AMAX_SUB words) of the input tensor
     // output transform: m [P][Mt][m_ld], N columns -> out (full resolution, may be null) / out2 (2x2 pooled, may be null)
     const float *m;
     int m_ld, N;
@@ -176,7 +178,58 @@ struct GemmS3Args {
     int half;                  // 0: the launcher chooses between 256-row tiles (one workgroup per CU) and 128-row tiles (two per CU); 1 / -1: force
     int waves;                 // 8 / 4 waves per workgroup (64 x BN/2 or 128 x BN/2 per wave); 0 = the default (Policy::s3_waves)
     unsigned long long *dbg;   // -DS3_TIMING builds of the micro-benchmark only: per-wave wait cycles; otherwise null
+    // the fp16 form (round 6): nt = 2 -- a / b hold TWO fp16 terms (hi, lo) of SCALED operands, [P][2][K/16][rows][16], three products per multiply
+    int nt;                    // 0 / 3: three bf16 terms; 2: two fp16 terms
+    const float *pscale;       // nt = 2: [P] epilogue factor of position p = 1 / (U's scale[p] * the static part of V's scale[p])
+    const unsigned *amax;      // nt = 2: the DT_AMAX_SUB-word max-|x| slot of the tensor V was made from (bits of a non-negative float): V carries
+                               //         dt_h2_base(amax) (x the static per-position factor), the epilogue multiplies by dt_h2_base_inv(amax)
+    const float *bias;         // nt = 2, 1x1 form: fp32 bias [N] or null, added in the epilogue (ones / bias_s3 stay null)
 };
+// ---- scaling of the fp16 form's operands (wino_gemm_s3.hip header) ----------------------------------------------------------------
+// max |x| of a tensor is kept as the integer bits of a non-negative float in a slot of DT_AMAX_SUB words (producers spread their atomicMax
+// over the sub-slots; a reader takes the maximum).  base = 2^(14 - floor(log2 amax)): amax * base is in [2^14, 2^15), a factor 2 below
+// fp16's largest finite value 65504.  The exponent field is clamped to [27, 240] (amax = 0 -> base 2^114 on zeros; nothing overflows).
+#define DT_AMAX_SUB 16
+__host__ __device__ inline unsigned dt_h2_expfield(unsigned amax_bits)
+{
+    const unsigned e = (amax_bits >> 23) & 0xffu;
+    return e < 27u ? 27u : (e > 240u ? 240u : e);
+}
+__host__ __device__ inline float dt_h2_from_field(unsigned f)
+{
+    const unsigned u = f << 23;
+    float x;
+    __builtin_memcpy(&x, &u, 4);
+    return x;
+}
+__host__ __device__ inline float dt_h2_base(unsigned amax_bits) { return dt_h2_from_field(268u - dt_h2_expfield(amax_bits)); }       // 2^(14 - e)
+__host__ __device__ inline float dt_h2_base_inv(unsigned amax_bits) { return dt_h2_from_field(dt_h2_expfield(amax_bits) - 14u); }   // 2^(e - 14)
+// static part of V's scale: the 1-D input transform's rows have absolute coefficient sums 12.5 / 7.5 / 15 (F(6,3)) and 10 / 6 (F(4,3));
+// row i of Bt d B is scaled by the power of two that brings its sum below 1, so |V[p] * f[xi] * f[nu]| < max |d|
+__host__ __device__ inline float dt_h2_rowfac(int ts, int i)
+{
+    if (ts == 6) return (i == 3 || i == 4) ? 0.125f : 0.0625f;
+    if (ts == 4) return (i == 3 || i == 4) ? 0.125f : 0.0625f;
+    return 1.0f;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned dt_amax_read(const unsigned *slot)      // wave-uniform
+{
+    unsigned v = slot[threadIdx.x & (DT_AMAX_SUB - 1)];
+#pragma unroll
+    for (int o = DT_AMAX_SUB / 2; o; o >>= 1) {
+        const unsigned w = (unsigned)__shfl_xor((int)v, o);
+        v = w > v ? w : v;
+    }
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+#endif
+// fp32 <-> fp16 bits on the host, round to nearest even, subnormals kept (what v_cvt_f16_f32 does under the default mode)
+unsigned short h2_f16_rne(float x);
+float h2_f16_f32(unsigned short h);
+void wino_h2_split_host(float x_scaled, unsigned short t[2]);
+// U [P][npad][K] fp32 (host) -> two fp16 terms [P][2][K/16][npad][16] of U[p] * uscale[p] (host)
+void wino_h2_pack_weights(const float *u, int P, int npad, int K, const float *uscale, unsigned short *dst);
 int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus);
 bool wino_gemm_s3_usable(int Mt, int K, int N);
 bool wino_gemm_s3_half_chosen(const GemmS3Args &a, int cus);
@@ -187,6 +240,10 @@ int launch_wino_input(hipStream_t st, const WinoArgs &a);
 // U [P][npad][K] fp32 (device) -> split-bf16 [P][3][K/16][npad][16] (device)
 int launch_wino_s3_pack(hipStream_t st, const float *u, int P, int npad, int K, unsigned short *dst);
 int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates);
+// max |x| of `planes` tensors of rows x cols floats (row stride ld, plane stride plane_stride) -> slots[planes][DT_AMAX_SUB] (zeroed here)
+int launch_absmax(hipStream_t st, const float *x, long long rows, int cols, long long ld, int planes, long long plane_stride, unsigned *slots);
+// U [P][npad][K] fp32 (device) -> two fp16 terms [P][2][K/16][npad][16] + epilogue factors pscale[P] (device); ts: Winograd tile (0: plain GEMM operand)
+int launch_wino_h2_pack(hipStream_t st, const float *u, int P, int npad, int K, int ts, unsigned *slots, unsigned short *dst, float *pscale);
 void wino_pack_weights(int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map, int cin_dst, const int *n_map,
                        int npad, const float *scale, float *dst);
 
@@ -264,6 +321,8 @@ struct ConvLayer {
     float *wt = nullptr;                 // device, packed
     unsigned short *wt_s3 = nullptr;     // device, 1x1 layers: wt as split-bf16 terms [3][cin/16][npad][16] (wino_gemm_s3.hip) or null
     unsigned short *bias_s3 = nullptr;   // device, with wt_s3: the bias as the B rows of one extra K stage, [3][npad][16]
+    unsigned short *wt_h2 = nullptr;     // device, 1x1 layers: wt as two fp16 terms of the scaled weights [2][cin/16][npad][16] (wino_gemm_s3.hip's fp16 form) or null
+    float *pscale_h2 = nullptr;          // device, with wt_h2: [1] the epilogue factor 1 / (the weights' power of two)
     float *wino = nullptr;               // device, [P][npad][cin] Winograd-domain weights (wide 3x3 layers) or null
     int wino_ts = 0;                     // their output tile size (2, 4 or 6)
     float *wino_alt = nullptr;           // device, F(4x4) weights kept next to F(6x6) ones for small-batch launches, or null
@@ -301,6 +360,10 @@ struct Policy {
                              //        0 never (fp32 MFMA) / 1 where it wins (K >= s3_mink, GEMM rows >= s3_minrows) / 2 wherever the shape allows
     int s3_mink = 128, s3_minrows = 2048;   // DT_S3_MINK / DT_S3_MINROWS (K >= 128 since round 4: with the line-sized epilogue stores the K = 128 GEMMs of
                                             // conv_6 / conv_8 take 3.4 instead of 4.3 ms on the fp32 kernel, their split input transform costs 0.7 back)
+    int s3_h2 = 1;           // DT_S3_H2: the split GEMMs in the fp16 form -- two terms of SCALED operands, three products on v_mfma_f32_32x32x16_f16 (half the
+                             //           matrix-pipe work and 4 instead of 6 bytes per operand element; wino_gemm_s3.hip) -- wherever the bf16 form would run; 0 = three
+                             //           bf16 terms / six products (round 3).  Read at weight load (the fp16 terms are built then) and per launch.  DT_PIN takes the
+                             //           bf16 form: the fp16 form's scale is the batch's max |x|, so its rounding of small elements depends on the batch
     int s3_half = 0;          // DT_S3_HALF: 128-row tiles / two workgroups per CU in the split GEMM: 0 where it needs fewer rounds (default) / 1 always (N % 256 == 0) / -1 never
     int s3_rec_minrows = 512; // DT_S3_REC_MINROWS: the ConvLSTM recurrent step's F(4x4) GEMM (gate update in its output transform) takes the split
                               //                    kernel from this many GEMM rows (48 clips at 13x13: 588); 0 = never
@@ -333,6 +396,12 @@ struct dt_ctx {
     ConvLayer layers[24];   // 1..23
     unsigned short *s3_ones = nullptr;   // device, [256][16] FLOATS: the A rows (1, 0, .., 0) that carry a 1x1 layer's bias through wino_gemm_s3.hip
     std::map<const void *, unsigned short *> wino_s3;   // F(6x6) Winograd weights (device pointer) -> their split-bf16 form (wino_gemm_s3.hip), when built
+    struct H2Weights { unsigned short *terms = nullptr; float *pscale = nullptr; };
+    std::map<const void *, H2Weights> wino_h2;          // ... -> their fp16 form: two terms of U[p] * 2^su[p], and the epilogue factors [P]
+    // max-|x| slots of the fp16 form (DT_AMAX_SUB words each; dt_internal.h: dt_h2_base).  Slot 0 holds 1.0 (|h_t| < 1: the ConvLSTM recurrent step);
+    // slot i in 1..23: the INPUT of conv_i; 24: the tracker's z / conv_feat; 25..27: test entry points; 64..127: scratch of the weight packs
+    unsigned *amax = nullptr;
+    std::map<const float *, int> amax_tag;   // tensor (device pointer) -> slot that holds its max |x| -- valid inside one API call only (amax_reset)
     float *conv1_w = nullptr, *conv1_b = nullptr, *lut255 = nullptr;
     unsigned *conv1_w3 = nullptr, *conv1_w3u8 = nullptr;   // device: split-bf16 weight tables of conv1_s3_kernel: w and w / 255 (conv1.hip:conv1_split_tables)
     std::vector<float> conv1_hwio32, conv1_scale, conv1_shift;   // host copy of conv_1 as a Cin = 32 layer (dt_detector_extract)
@@ -364,6 +433,7 @@ struct dt_ctx {
     hipEvent_t gev_in = nullptr, gev_out = nullptr;
     std::map<std::string, hipGraphExec_t> graphs;
     std::map<std::string, int> graph_seen;
+    std::map<std::string, std::map<const float *, int>> graph_tags;   // amax_tag as a graphed sequence left it (re-applied on replay)
     int64_t graph_replays = 0, graph_captures = 0;
     // profiling
     bool prof = false;

@@ -43,6 +43,7 @@ static void graphs_clear(dt_ctx *ctx)
     for (auto &kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
     ctx->graphs.clear();
     ctx->graph_seen.clear();
+    ctx->graph_tags.clear();
 }
 
 // Runs `body` (a sequence of launches on ctx->stream that touches library-owned buffers only), as a replayed
@@ -52,14 +53,18 @@ static int graphed(dt_ctx *ctx, const std::string &key, const std::function<int(
 {
     if (!ctx->graph_on || ctx->prof || ctx->capturing) return body();
     hipStream_t user = ctx->stream;
+    // a graphed sequence measures the max |x| of whatever it reads from outside ITSELF (a replay runs no host code: what the host knew at
+    // capture time may not hold then); what it leaves behind is re-applied on replay
+    ctx->amax_tag.clear();
     auto it = ctx->graphs.find(key);
     if (it == ctx->graphs.end()) {
         int &seen = ctx->graph_seen[key];
-        if (seen < 0 || seen++ == 0) return body();
+        if (seen < 0 || seen++ == 0) { const int rc0 = body(); ctx->graph_tags[key] = ctx->amax_tag; return rc0; }
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(ctx->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) { seen = -1; return body(); }
         ctx->capturing = true; ctx->stream = ctx->gstream;
         const int rc = body();
+        ctx->graph_tags[key] = ctx->amax_tag;
         ctx->stream = user; ctx->capturing = false;
         const hipError_t e = hipStreamEndCapture(ctx->gstream, &g);
         hipGraphExec_t ex = nullptr;
@@ -77,6 +82,7 @@ static int graphed(dt_ctx *ctx, const std::string &key, const std::function<int(
     // synchronisation -- no event pair per replay (round 3 replayed on the internal stream between two events and was 0.06 ms
     // SLOWER than plain launches at batch 8)
     HIP_TRY(ctx, hipGraphLaunch(it->second, user));
+    ctx->amax_tag = ctx->graph_tags[key];
     ++ctx->graph_replays;
     return DT_OK;
 }
@@ -152,7 +158,30 @@ static void s3_drop(dt_ctx *ctx, const void *wino)
 {
     auto it = ctx->wino_s3.find(wino);
     if (wino && it != ctx->wino_s3.end()) { (void)hipFree(it->second); ctx->wino_s3.erase(it); }
+    auto ih = ctx->wino_h2.find(wino);
+    if (wino && ih != ctx->wino_h2.end()) { (void)hipFree(ih->second.terms); (void)hipFree(ih->second.pscale); ctx->wino_h2.erase(ih); }
 }
+
+// ---- max-|x| slots of the fp16 form (dt_internal.h: dt_ctx::amax) ------------------------------------------------------------------
+#define DT_AMAX_SLOTS 128
+enum { AMAX_ONE = 0, AMAX_TRK = 24, AMAX_TEST = 25, AMAX_PACK = 64 };
+static unsigned *amax_slot(dt_ctx *ctx, int slot) { return ctx->amax ? ctx->amax + (size_t)slot * DT_AMAX_SUB : nullptr; }
+// every API entry that runs layers starts here: what a previous call knew about a tensor's maximum says nothing about the bytes behind the pointer now
+static void amax_reset(dt_ctx *ctx) { ctx->amax_tag.clear(); }
+// the slot that holds max |x| of the rows x cols tensor at x: the one its producer filled (tagged), else measured here into `slot`
+static const unsigned *ensure_amax(dt_ctx *ctx, const float *x, long long rows, int cols, long long ld, int slot)
+{
+    auto it = ctx->amax_tag.find(x);
+    if (it != ctx->amax_tag.end()) return amax_slot(ctx, it->second);
+    unsigned *s = amax_slot(ctx, slot);
+    if (!s) { dt_fail(ctx, DT_ERR_STATE, "max-|x| slots not allocated"); return nullptr; }
+    ProfScope ps(ctx, "absmax", 0.0, 4.0 * (double)rows * cols);
+    if (launch_absmax(ctx->stream, x, rows, cols, ld, 1, 0, s)) { dt_fail(ctx, DT_ERR_DEVICE, "absmax launch failed"); return nullptr; }
+    ctx->amax_tag[x] = slot;
+    return s;
+}
+// does this launch take the fp16 form of the split GEMM?  (DT_PIN keeps the bf16 form: see Policy::s3_h2)
+static bool h2_wanted(const dt_ctx *ctx) { return ctx->pol.s3 != 0 && ctx->pol.s3_h2 != 0 && !ctx->pol.pin; }
 
 static int upload(dt_ctx *ctx, float **dst, const std::vector<float> &h)
 {
@@ -163,7 +192,7 @@ static int upload(dt_ctx *ctx, float **dst, const std::vector<float> &h)
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int dt_abi_version(void) { return 106; }   // 1.06: + dt_gemm_split_bf16 (test entry point of wino_gemm_s3.hip)
+extern "C" int dt_abi_version(void) { return 107; }   // 1.07: + dt_gemm_split (test entry point of wino_gemm_s3.hip: bf16 x 3 or fp16 x 2 terms)
 
 extern "C" int dt_create(dt_ctx **out)
 {
@@ -191,6 +220,16 @@ extern "C" int dt_create(dt_ctx **out)
         delete c;
         return DT_ERR_DEVICE;
     }
+    {   // max-|x| slots; slot 0 = 1.0
+        std::vector<unsigned> am((size_t)DT_AMAX_SLOTS * DT_AMAX_SUB, 0u);
+        for (int q = 0; q < DT_AMAX_SUB; ++q) am[q] = 0x3f800000u;
+        if (hipMalloc(reinterpret_cast<void **>(&c->amax), am.size() * sizeof(unsigned)) != hipSuccess ||
+            hipMemcpy(c->amax, am.data(), am.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) {
+            snprintf(g_static_err, sizeof(g_static_err), "dt_create: max-|x| slot allocation failed");
+            delete c;
+            return DT_ERR_DEVICE;
+        }
+    }
     *out = c;
     return DT_OK;
 }
@@ -207,6 +246,8 @@ extern "C" void dt_destroy(dt_ctx *ctx)
         s3_drop(ctx, ctx->layers[i].wino);
         if (ctx->layers[i].wt_s3) (void)hipFree(ctx->layers[i].wt_s3);
         if (ctx->layers[i].bias_s3) (void)hipFree(ctx->layers[i].bias_s3);
+        if (ctx->layers[i].wt_h2) (void)hipFree(ctx->layers[i].wt_h2);
+        if (ctx->layers[i].pscale_h2) (void)hipFree(ctx->layers[i].pscale_h2);
         if (ctx->layers[i].wino) (void)hipFree(ctx->layers[i].wino);
         if (ctx->layers[i].wino_alt) (void)hipFree(ctx->layers[i].wino_alt);
         if (ctx->layers[i].fused4s) (void)hipFree(ctx->layers[i].fused4s);
@@ -221,6 +262,7 @@ extern "C" void dt_destroy(dt_ctx *ctx)
     s3_drop(ctx, ctx->trk_wx_wino);
     s3_drop(ctx, ctx->trk_wh_wino);
     if (ctx->s3_ones) (void)hipFree(ctx->s3_ones);
+    if (ctx->amax) (void)hipFree(ctx->amax);
     if (ctx->conv1_w3) (void)hipFree(ctx->conv1_w3);
     if (ctx->conv1_w3u8) (void)hipFree(ctx->conv1_w3u8);
     for (float *p : singles)
@@ -328,6 +370,16 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->s3_ones), ones.size() * sizeof(float)));
             HIP_TRY(ctx, hipMemcpy(ctx->s3_ones, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+    }
+    if (L.wt_h2) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wt_h2); L.wt_h2 = nullptr; }
+    if (L.pscale_h2) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.pscale_h2); L.pscale_h2 = nullptr; }
+    if (L.wt_s3 && ctx->pol.s3_h2 != 0) {
+        // ... and in the fp16 form: two terms of wt * 2^s (s from max |wt|), the epilogue factor 2^-s; the bias stays fp32 (L.bias)
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&L.wt_h2), packed.size() * 2 * sizeof(unsigned short)));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&L.pscale_h2), sizeof(float)));
+        if (launch_wino_h2_pack(ctx->stream, L.wt, 1, L.npad, cin, 0, amax_slot(ctx, AMAX_PACK), L.wt_h2, L.pscale_h2))
+            return dt_fail(ctx, DT_ERR_DEVICE, "fp16-form weight pack launch failed");
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (L.scale) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.scale); L.scale = nullptr; }
     L.scale_has_zero = false;
@@ -549,6 +601,7 @@ void policy_from_env(Policy &p)
     p.s3_1x1_minrows = geti("DT_S3_1X1_MINROWS", d.s3_1x1_minrows);
     p.s3_rec_minrows = geti("DT_S3_REC_MINROWS", d.s3_rec_minrows);
     p.s3_half = geti("DT_S3_HALF", d.s3_half);
+    p.s3_h2 = geti("DT_S3_H2", d.s3_h2);
     p.persist = geti("DT_PERSIST", d.persist);
     p.xcd_remap = geti("DT_XCD_REMAP", d.xcd_remap);
     p.tile_gn = geti("DT_TILE_GN", d.tile_gn);
@@ -610,6 +663,17 @@ static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int 
             return dt_fail(ctx, DT_ERR_DEVICE, "split-bf16 weight pack failed");
         }
         ctx->wino_s3[*dst] = s3;
+        if (ctx->pol.s3_h2 != 0 && (ts + 2) * (ts + 2) <= 64) {      // ... and the fp16 form next to it (DT_PIN runs take the bf16 one)
+            dt_ctx::H2Weights h;
+            const int P = (ts + 2) * (ts + 2);
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&h.terms), u.size() * 2 * sizeof(unsigned short)));
+            if (hipMalloc(reinterpret_cast<void **>(&h.pscale), P * sizeof(float)) != hipSuccess) { (void)hipFree(h.terms); return dt_fail(ctx, DT_ERR_DEVICE, "hipMalloc failed"); }
+            if (launch_wino_h2_pack(ctx->stream, *dst, P, npad, cin_dst, ts, amax_slot(ctx, AMAX_PACK), h.terms, h.pscale) || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                (void)hipFree(h.terms); (void)hipFree(h.pscale);
+                return dt_fail(ctx, DT_ERR_DEVICE, "fp16-form weight pack failed");
+            }
+            ctx->wino_h2[*dst] = h;
+        }
     }
     return DT_OK;
 }
@@ -702,7 +766,8 @@ static WinoGeom wino_geometry(const dt_ctx *ctx, int ts, int B, int H, int W, bo
 }
 
 static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias, int cin, int N, int npad, int B, int H,
-                    int W, const WinoIO &io, float slope, const char *tag, int cin_alg = 0 /* channels of the reference's layer when cin is padded */)
+                    int W, const WinoIO &io, float slope, const char *tag, int cin_alg = 0 /* channels of the reference's layer when cin is padded */,
+                    int in_slot = AMAX_TEST /* max-|x| slot of the input tensor (fp16 form); AMAX_ONE: bounded by 1, nothing to measure */)
 {
     const double cin_df = cin_alg > 0 ? cin_alg : cin;
     WinoArgs w;
@@ -728,18 +793,31 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
         auto it = ctx->wino_s3.find(wino_wt);
         if (it != ctx->wino_s3.end()) u_s3 = it->second;
     }
+    // ... in the fp16 form (two terms of scaled operands, three products) where its weights exist
+    const dt_ctx::H2Weights *h2 = nullptr;
+    if (u_s3 && h2_wanted(ctx)) {
+        auto ih = ctx->wino_h2.find(wino_wt);
+        if (ih != ctx->wino_h2.end()) { h2 = &ih->second; u_s3 = h2->terms; }
+    }
+    const int NT = h2 ? 2 : 3;
     const size_t mp = (mt + 255) / 256 * 256;
-    float *V = ws_get(ctx, "wino_v", u_s3 ? (size_t)P * 3 * mp * cin * sizeof(unsigned short) : P * mt * cin * sizeof(float));
+    float *V = ws_get(ctx, "wino_v", u_s3 ? (size_t)P * NT * mp * cin * sizeof(unsigned short) : P * mt * cin * sizeof(float));
     float *Mp = ws_get(ctx, "wino_m", P * mt * N * sizeof(float));
     if (!V || !Mp) return DT_ERR_DEVICE;
     if (u_s3) { w.v_s3 = reinterpret_cast<unsigned short *>(V); w.Mp = (int)mp; }
+    const unsigned *amax = nullptr;
+    if (h2) {      // V's power of two comes from the input's max |x|
+        amax = in_slot == AMAX_ONE ? amax_slot(ctx, AMAX_ONE) : ensure_amax(ctx, io.in, (long long)B * H * W, cin, io.in_ld, in_slot);
+        if (!amax) return DT_ERR_DEVICE;
+        w.nt = 2; w.amax = amax;
+    }
     w.in = io.in; w.in_bs = io.in_bs; w.in_ld = io.in_ld; w.C = cin; w.v = V;
     w.m = Mp; w.m_ld = N; w.N = N; w.bias = bias; w.bias16 = io.bias16; w.slope = slope;
     w.out = io.out; w.out_bs = io.out_bs; w.out_ld = io.out_ld; w.out2 = io.out2; w.out2_ld = io.out2_ld;
     w.xproj = io.xproj; w.xp_bs = io.xp_bs; w.xp_ld = io.xp_ld;
     w.cstate = io.cstate; w.c_bs = io.c_bs; w.c_ld = io.c_ld;
     {
-        ProfScope ps(ctx, "wino_input", 0.0, 4.0 * (double)B * H * W * cin + (u_s3 ? 6.0 : 4.0) * (double)P * mt * cin, tag);
+        ProfScope ps(ctx, "wino_input", 0.0, 4.0 * (double)B * H * W * cin + (u_s3 ? 2.0 * NT : 4.0) * (double)P * mt * cin, tag);
         const int rc = launch_wino_input(ctx->stream, w);
         if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: Winograd input transform launch failed", tag);
     }
@@ -748,8 +826,10 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
         memset(&g, 0, sizeof(g));
         g.a = w.v_s3; g.b = u_s3; g.c = Mp; g.c_ps = (long long)mt * N; g.P = P; g.Mt = w.Mt; g.Mp = (int)mp; g.N = N; g.Np = npad;
         g.K = cin; g.ldc = N; g.half = ctx->pol.s3_half;
-        // flops = EXECUTED bf16 MFMA work (six partial products per multiply); bytes = V + U (three bf16 terms each) + M'
-        ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), (double)P * (6.0 * mt * cin + 6.0 * (double)cin * N + 4.0 * (double)mt * N), tag);
+        if (h2) { g.nt = 2; g.pscale = h2->pscale; g.amax = amax; }
+        // flops = EXECUTED 16-bit MFMA work (six partial products per multiply, three in the fp16 form); bytes = V + U (NT 16-bit terms each) + M'
+        ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), (double)P * (2.0 * NT * mt * cin + 2.0 * NT * (double)cin * N + 4.0 * (double)mt * N), tag);
+        if (ctx->prof && !ctx->capturing) ctx->prof_tab[h2 ? "s3_form:f16x2" : "s3_form:bf16x3"].launches += 1;
         prof_direct_form(ctx, 2.0 * B * H * W * 9.0 * cin_df * N,
                          4.0 * ((double)B * H * W * cin_df + 9.0 * cin_df * N + (io.out ? (double)B * H * W * N : 0.0) +
                                 (io.out2 ? (double)B * H * W * N / 4.0 : 0.0) + (io.cstate ? 4.0 * B * H * W * N / 4.0 : 0.0)), DF_S3);
@@ -827,15 +907,22 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
     if (L.bias_s3 && ctx->s3_ones && epi == EPI_PLAIN && order == ORD_LINEAR && !out2 && in_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 3) == 0 && s3_1x1_eligible(ctx, L, (long long)B * H * W)) {
         const long long M = (long long)B * H * W;
+        const bool h2 = L.wt_h2 && L.pscale_h2 && L.npad <= 2048 && h2_wanted(ctx);
         GemmS3Args g;
         memset(&g, 0, sizeof(g));
         g.a_f32 = in; g.a_ld = in_ld; g.b = L.wt_s3; g.c = out; g.c_ps = 0; g.P = 1; g.Mt = (int)M; g.Mp = (int)((M + 255) / 256 * 256); g.N = L.cout; g.Np = L.npad;
         g.half = ctx->pol.s3_half;
         g.K = L.cin; g.ldc = out_ld; g.ones = ctx->s3_ones; g.bias_s3 = L.bias_s3; g.act = 1; g.slope = slope;
+        if (h2) {      // the fp16 form: scaled operands (the activation's power of two from its max |x|), the bias added in the epilogue
+            g.nt = 2; g.b = L.wt_h2; g.pscale = L.pscale_h2; g.bias = L.bias; g.ones = nullptr; g.bias_s3 = nullptr;
+            g.amax = ensure_amax(ctx, in, M, L.cin, in_ld, L.idx >= 1 && L.idx <= 23 ? L.idx : AMAX_TEST);
+            if (!g.amax) return DT_ERR_DEVICE;
+        }
         char tag[32];
         snprintf(tag, sizeof(tag), "conv_%d", L.idx);
-        // bytes = A (fp32) + U (three bf16 terms) + out
-        ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), 4.0 * M * L.cin + 6.0 * (double)L.cin * L.cout + 4.0 * (double)M * L.cout, tag);
+        if (ctx->prof && !ctx->capturing) ctx->prof_tab[h2 ? "s3_form:f16x2" : "s3_form:bf16x3"].launches += 1;
+        // bytes = A (fp32) + U (NT 16-bit terms) + out
+        ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), 4.0 * M * L.cin + (h2 ? 4.0 : 6.0) * (double)L.cin * L.cout + 4.0 * (double)M * L.cout, tag);
         prof_direct_form(ctx, 2.0 * M * (double)L.cin * L.cout, 4.0 * ((double)M * L.cin + (double)L.cin * L.cout + (double)M * L.cout), DF_S3);
         const int rc = launch_wino_gemm_s3(ctx->stream, g, 0);
         if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: split-bf16 1x1 GEMM launch failed (rc=%d)", tag, rc);
@@ -898,7 +985,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
             const long long t6 = 64ll * ((q6.Mt + 127) / 128) * ((L.cout + 127) / 128);
             if (t6 <= 4096 && small_gemm_cost(q4.Mt, L.cout, 36, nullptr) < small_gemm_cost(q6.Mt, L.cout, 64, nullptr)) { wt = L.wino_alt; ts = 4; }
         }
-        return run_wino(ctx, wt, ts, L.bias, L.cin, L.cout, L.npad, B, H, W, io, slope, tag);
+        return run_wino(ctx, wt, ts, L.bias, L.cin, L.cout, L.npad, B, H, W, io, slope, tag, 0, L.idx >= 1 && L.idx <= 23 ? L.idx : AMAX_TEST);
     }
     // Wave quantisation for small batches (few frames at 13x13 / 26x26): with 512 resident
     // workgroup slots (256 CUs x 2) a layer of a few hundred output tiles leaves the chip
@@ -1071,6 +1158,7 @@ extern "C" int dt_detect_forward(dt_ctx *ctx, const void *d_frames, int frames_d
                                  float *d_feat)
 {
     if (!ctx || !d_frames) return dt_fail(ctx, DT_ERR_ARG, "null argument");
+    amax_reset(ctx);
     const int G2 = (ctx->image_h / 32) * (ctx->image_w / 32);
     Dest feat{d_feat, 1024}, net{d_netout, ctx->cb};
     if (!d_feat) {
@@ -1142,6 +1230,7 @@ static bool parse_layer_name(const dt_ctx *ctx, const char *name, int *idx, int 
 extern "C" int dt_detector_extract(dt_ctx *ctx, const void *d_frames, int frames_dtype, int batch, const char *layer,
                                    float *d_out, size_t out_floats, int *shape4)
 {
+    if (ctx) amax_reset(ctx);
     if (!ctx || !layer) return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (!ctx->cb) return dt_fail(ctx, DT_ERR_STATE, "dt_detector_config must be called first");
     int idx = 0, kind = 0, oh = 0, ow = 0, oc = 0;
@@ -1400,14 +1489,14 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
         io.out = xproj; io.out_ld = N4; io.out_bs = (long long)GG * N4;
         io.bias16 = ctx->trk_bx16 + N4;         // corrections of the 16 border cases; row 0 of the table is the interior bias
         if (ctx->prof && !ctx->capturing) ctx->prof_tab["convlstm_xproj:merged_conv23"].launches += 1;
-        const int rc = run_wino(ctx, ctx->trk_wxm_wino, 6, ctx->trk_bx16, 1024, N4, N4, F, gh, gw, io, 1.0f, "convlstm_xproj", ctx->cb + 1024);
+        const int rc = run_wino(ctx, ctx->trk_wxm_wino, 6, ctx->trk_bx16, 1024, N4, N4, F, gh, gw, io, 1.0f, "convlstm_xproj", ctx->cb + 1024, AMAX_TRK);
         if (rc) return rc;
     } else if (wino_runs(ctx, wx_wino, ctx->trk_wino_ts, F, gh, gw, Cx, N4)) {
         WinoIO io;
         memset(&io, 0, sizeof(io));
         io.in = z; io.in_ld = Cx; io.in_bs = (long long)GG * Cx;
         io.out = xproj; io.out_ld = N4; io.out_bs = (long long)GG * N4;
-        const int rc = run_wino(ctx, wx_wino, ctx->trk_wino_ts, bx, Cx, N4, N4, F, gh, gw, io, 1.0f, "convlstm_xproj", ctx->cb + 1024);
+        const int rc = run_wino(ctx, wx_wino, ctx->trk_wino_ts, bx, Cx, N4, N4, F, gh, gw, io, 1.0f, "convlstm_xproj", ctx->cb + 1024, AMAX_TRK);
         if (rc) return rc;
     } else {
         ConvArgs a;
@@ -1441,7 +1530,8 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
             io.out = hseq + (long long)t * GG * U; io.out_ld = U; io.out_bs = h_bs;
             io.xproj = xproj + (long long)t * GG * N4; io.xp_ld = N4; io.xp_bs = xp_bs;
             io.cstate = cst; io.c_ld = U; io.c_bs = c_bs;
-            const int rc = run_wino(ctx, wh_wino, ctx->trk_wh_ts, nullptr, U, N4, N4, n_clips, gh, gw, io, 1.0f, "convlstm_step");
+            // (h_{t-1} = o * tanh(c) lies in (-1, 1): the fp16 form's scale is static, nothing is measured)
+            const int rc = run_wino(ctx, wh_wino, ctx->trk_wh_ts, nullptr, U, N4, N4, n_clips, gh, gw, io, 1.0f, "convlstm_step", 0, AMAX_ONE);
             if (rc) return rc;
             continue;
         }
@@ -1500,6 +1590,7 @@ static int track_recurrent_internal(dt_ctx *ctx, const float *z, int n_clips, in
 extern "C" int dt_track_forward(dt_ctx *ctx, const void *d_frames, int frames_dtype, int n_clips, int T,
                                 float *d_trk, float *d_det)
 {
+    if (ctx) amax_reset(ctx);
     if (!ctx || !d_frames) return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (!ctx->trk_loaded) return dt_fail(ctx, DT_ERR_STATE, "tracker weights not loaded");
     if (n_clips <= 0 || T <= 0) return dt_fail(ctx, DT_ERR_ARG, "n_clips and T must be positive");
@@ -1529,6 +1620,7 @@ extern "C" int dt_track_row_width(dt_ctx *ctx)
 
 extern "C" int dt_track_detect(dt_ctx *ctx, const void *d_frames, int frames_dtype, int n_frames, float *d_z)
 {
+    if (ctx) amax_reset(ctx);
     if (!ctx || !d_frames || !d_z) return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (!ctx->trk_loaded) return dt_fail(ctx, DT_ERR_STATE, "tracker weights not loaded");
     if (n_frames <= 0) return dt_fail(ctx, DT_ERR_ARG, "n_frames must be positive");
@@ -1541,6 +1633,7 @@ extern "C" int dt_track_detect(dt_ctx *ctx, const void *d_frames, int frames_dty
 
 extern "C" int dt_track_recurrent(dt_ctx *ctx, const float *d_z, int n_clips, int T, float *d_trk, float *d_det)
 {
+    if (ctx) amax_reset(ctx);
     if (!ctx || !d_z) return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (!ctx->trk_loaded) return dt_fail(ctx, DT_ERR_STATE, "tracker weights not loaded");
     if (n_clips <= 0 || T <= 0) return dt_fail(ctx, DT_ERR_ARG, "n_clips and T must be positive");
@@ -1564,6 +1657,7 @@ extern "C" int dt_track_xproj_width(dt_ctx *ctx)
 
 extern "C" int dt_track_detect_xproj(dt_ctx *ctx, const void *d_frames, int frames_dtype, int n_frames, float *d_xp, float *d_det)
 {
+    if (ctx) amax_reset(ctx);
     if (!ctx || !d_frames || !d_xp) return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (!ctx->trk_loaded) return dt_fail(ctx, DT_ERR_STATE, "tracker weights not loaded");
     if (n_frames <= 0) return dt_fail(ctx, DT_ERR_ARG, "n_frames must be positive");
@@ -1583,6 +1677,7 @@ extern "C" int dt_track_detect_xproj(dt_ctx *ctx, const void *d_frames, int fram
 
 extern "C" int dt_track_recurrent_xproj(dt_ctx *ctx, const float *d_xp, int n_clips, int T, float *d_trk)
 {
+    if (ctx) amax_reset(ctx);
     if (!ctx || !d_xp) return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (!ctx->trk_loaded) return dt_fail(ctx, DT_ERR_STATE, "tracker weights not loaded");
     if (n_clips <= 0 || T <= 0) return dt_fail(ctx, DT_ERR_ARG, "n_clips and T must be positive");
@@ -1802,6 +1897,7 @@ extern "C" int dt_top_box(dt_ctx *ctx, const float *d_boxes, const int *d_counts
 extern "C" int dt_conv2d(dt_ctx *ctx, const float *d_in, int B, int H, int W, int Cin, const float *h_kernel, int k,
                          int Cout, const float *h_bias, float leaky_slope, int pool, float *d_out, float *d_out2)
 {
+    if (ctx) amax_reset(ctx);
     if (!ctx || !d_in || !h_kernel || !d_out) return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (Cin % 32) return dt_fail(ctx, DT_ERR_ARG, "Cin must be a multiple of 32");
     if (k != 1 && k != 3) return dt_fail(ctx, DT_ERR_ARG, "kernel size must be 1 or 3");
@@ -1843,6 +1939,7 @@ extern "C" int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int
                                 const float *d_c, int U, const float *h_kernel, const float *h_recurrent,
                                 const float *h_bias, float *d_h_out, float *d_c_out)
 {
+    if (ctx) amax_reset(ctx);
     if (!ctx || !d_x || !d_h || !d_c || !h_kernel || !h_recurrent || !h_bias || !d_h_out || !d_c_out)
         return dt_fail(ctx, DT_ERR_ARG, "null argument");
     if (Cx % 32 || U % 32) return dt_fail(ctx, DT_ERR_ARG, "Cx and U must be multiples of 32");
@@ -1871,14 +1968,18 @@ extern "C" int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int
         memset(&io, 0, sizeof(io));
         io.in = d_x; io.in_ld = Cx; io.in_bs = (long long)GG * Cx;
         io.out = xproj; io.out_ld = N4; io.out_bs = (long long)GG * N4;
-        if ((rc = run_wino(ctx, *uwx, ts, *dbx, Cx, N4, N4, B, H, W, io, 1.0f, "convlstm_xproj"))) return rc;
+        struct Twins {      // the split twins of the two temporaries go with them
+            dt_ctx *c; float **a, **b;
+            ~Twins() { (void)hipStreamSynchronize(c->stream); s3_drop(c, *a); s3_drop(c, *b); }
+        } twins{ctx, uwx, uwh};
+        if ((rc = run_wino(ctx, *uwx, ts, *dbx, Cx, N4, N4, B, H, W, io, 1.0f, "convlstm_xproj", 0, AMAX_TEST))) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(d_c_out, d_c, (size_t)B * GG * U * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         memset(&io, 0, sizeof(io));
         io.in = d_h; io.in_ld = U; io.in_bs = (long long)GG * U;
         io.out = d_h_out; io.out_ld = U; io.out_bs = (long long)GG * U;
         io.xproj = xproj; io.xp_ld = N4; io.xp_bs = (long long)GG * N4;
         io.cstate = d_c_out; io.c_ld = U; io.c_bs = (long long)GG * U;
-        return run_wino(ctx, *uwh, ts, nullptr, U, N4, N4, B, H, W, io, 1.0f, "convlstm_step");
+        return run_wino(ctx, *uwh, ts, nullptr, U, N4, N4, B, H, W, io, 1.0f, "convlstm_step", 0, AMAX_TEST + 1);      // (a caller's h: measured)
     }
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -1901,43 +2002,56 @@ extern "C" int dt_convlstm_step(dt_ctx *ctx, const float *d_x, int B, int H, int
     return DT_OK;
 }
 
-// wino_gemm_s3.hip on caller data (parity tests at the benched shapes): both operands padded to the kernel's row tiles,
-// split into three bf16 terms by the production pack kernel, then the production launcher.
-extern "C" int dt_gemm_split_bf16(dt_ctx *ctx, const float *d_v, const float *d_u, int P, int Mt, int K, int N, int half, float *d_m)
+// wino_gemm_s3.hip on caller data (parity tests at the benched shapes): both operands padded to the kernel's row tiles, split by the
+// production pack kernels -- nt = 3: three bf16 terms; nt = 2: two fp16 terms of the scaled operands (V by ONE power of two from its
+// max |x| like an activation, U per plane like the weights) -- then the production launcher.
+extern "C" int dt_gemm_split(dt_ctx *ctx, const float *d_v, const float *d_u, int P, int Mt, int K, int N, int half, int nt, float *d_m)
 {
     if (!ctx || !d_v || !d_u || !d_m) return dt_fail(ctx, DT_ERR_ARG, "null argument");
-    if (P <= 0 || Mt <= 0 || K <= 0 || N <= 0 || K % 32 || N % 128 || !wino_gemm_s3_usable(Mt, K, N))
-        return dt_fail(ctx, DT_ERR_ARG, "dt_gemm_split_bf16: unsupported shape P=%d Mt=%d K=%d N=%d", P, Mt, K, N);
+    amax_reset(ctx);
+    if (P <= 0 || Mt <= 0 || K <= 0 || N <= 0 || K % 32 || N % 128 || !wino_gemm_s3_usable(Mt, K, N) || (nt != 2 && nt != 3) || (nt == 2 && P > 64))
+        return dt_fail(ctx, DT_ERR_ARG, "dt_gemm_split: unsupported shape P=%d Mt=%d K=%d N=%d nt=%d", P, Mt, K, N, nt);
     const bool rows_form = half == 2;      // the 1x1 layers' form: the kernel reads d_v as fp32 rows and splits its fragments itself
-    if (rows_form && P != 1) return dt_fail(ctx, DT_ERR_ARG, "dt_gemm_split_bf16: the fp32-rows form is one GEMM (P = 1)");
+    if (rows_form && P != 1) return dt_fail(ctx, DT_ERR_ARG, "dt_gemm_split: the fp32-rows form is one GEMM (P = 1)");
     if (rows_form) half = 0;
     const size_t Mp = ((size_t)Mt + 255) / 256 * 256, Np = ((size_t)N + 255) / 256 * 256;
     DevTemps tmp(ctx->stream);
-    tmp.p.reserve(4);
-    float **vpad = tmp.add(), **upad = tmp.add(), **vs = tmp.add(), **us = tmp.add();
+    tmp.p.reserve(5);
+    float **vpad = tmp.add(), **upad = tmp.add(), **vs = tmp.add(), **us = tmp.add(), **ps = tmp.add();
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(vpad), (size_t)P * Mp * K * sizeof(float)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(upad), (size_t)P * Np * K * sizeof(float)));
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(vs), (size_t)P * 3 * Mp * K * sizeof(unsigned short)));
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(us), (size_t)P * 3 * Np * K * sizeof(unsigned short)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(vs), (size_t)P * nt * Mp * K * sizeof(unsigned short)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(us), (size_t)P * nt * Np * K * sizeof(unsigned short)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(ps), 64 * sizeof(float)));
     HIP_TRY(ctx, hipMemsetAsync(*vpad, 0, (size_t)P * Mp * K * sizeof(float), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(*upad, 0, (size_t)P * Np * K * sizeof(float), ctx->stream));
     HIP_TRY(ctx, hipMemcpy2DAsync(*vpad, Mp * K * sizeof(float), d_v, (size_t)Mt * K * sizeof(float), (size_t)Mt * K * sizeof(float), P,
                                   hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpy2DAsync(*upad, Np * K * sizeof(float), d_u, (size_t)N * K * sizeof(float), (size_t)N * K * sizeof(float), P,
                                   hipMemcpyDeviceToDevice, ctx->stream));
-    if (launch_wino_s3_pack(ctx->stream, *vpad, P, (int)Mp, K, reinterpret_cast<unsigned short *>(*vs)) ||
-        launch_wino_s3_pack(ctx->stream, *upad, P, (int)Np, K, reinterpret_cast<unsigned short *>(*us)))
-        return dt_fail(ctx, DT_ERR_DEVICE, "split-bf16 pack launch failed");
     GemmS3Args g;
     memset(&g, 0, sizeof(g));
+    if (nt == 2) {
+        unsigned *vslot = amax_slot(ctx, AMAX_TEST);
+        if (launch_wino_h2_pack(ctx->stream, *vpad, P, (int)Mp, K, 0, vslot, reinterpret_cast<unsigned short *>(*vs), nullptr) ||
+            launch_wino_h2_pack(ctx->stream, *upad, P, (int)Np, K, 0, amax_slot(ctx, AMAX_PACK), reinterpret_cast<unsigned short *>(*us), *ps))
+            return dt_fail(ctx, DT_ERR_DEVICE, "fp16-form pack launch failed");
+        g.nt = 2; g.pscale = *ps; g.amax = vslot;      // (the fp32-rows form measures the same tensor: the padding rows are zeros)
+    } else if (launch_wino_s3_pack(ctx->stream, *vpad, P, (int)Mp, K, reinterpret_cast<unsigned short *>(*vs)) ||
+               launch_wino_s3_pack(ctx->stream, *upad, P, (int)Np, K, reinterpret_cast<unsigned short *>(*us)))
+        return dt_fail(ctx, DT_ERR_DEVICE, "split-bf16 pack launch failed");
     g.a = reinterpret_cast<unsigned short *>(*vs); g.b = reinterpret_cast<unsigned short *>(*us); g.c = d_m;
-    if (rows_form) { g.a = nullptr; g.a_f32 = d_v; g.a_ld = K; g.act = 1; g.slope = 1.0f; }      // (no bias stage, no activation)
+    if (rows_form) { g.a = nullptr; g.a_f32 = d_v; g.a_ld = K; g.act = 1; g.slope = 1.0f; }      // (no bias, no activation)
     g.c_ps = (long long)Mt * N; g.P = P; g.Mt = Mt; g.Mp = (int)Mp; g.N = N; g.Np = (int)Np; g.K = K; g.ldc = N; g.half = half;
-    ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), (double)P * (6.0 * Mt * K + 6.0 * (double)K * N + 4.0 * (double)Mt * N), "test_gemm");
+    ProfScope pscope(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), (double)P * (2.0 * nt * Mt * K + 2.0 * nt * (double)K * N + 4.0 * (double)Mt * N), "test_gemm");
     if (ctx->prof && !ctx->capturing) ctx->prof_tab[wino_gemm_s3_half_chosen(g, 0) ? "s3_tile:128x2" : "s3_tile:256"].launches += 1;
     const int rc = launch_wino_gemm_s3(ctx->stream, g, 0);
-    if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "dt_gemm_split_bf16: launch failed (rc=%d)", rc);
+    if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "dt_gemm_split: launch failed (rc=%d)", rc);
     return DT_OK;
+}
+extern "C" int dt_gemm_split_bf16(dt_ctx *ctx, const float *d_v, const float *d_u, int P, int Mt, int K, int N, int half, float *d_m)
+{
+    return dt_gemm_split(ctx, d_v, d_u, P, Mt, K, N, half, 3, d_m);
 }
 
 // Re-reads the tuning / test knobs from the environment into the context (they are otherwise read once, in

@@ -26,10 +26,23 @@
 // LDS image of one (operand, term, stage): [row][2 granules of 8 bf16], granule index XOR (row >> 3) & 1 -- with the
 // ds_read_b128 lane groups of gfx950 ({0-3,12-15,20-27}, ...) every group then covers all 64 banks once
 // (SQ_LDS_BANK_CONFLICT = 0 measured).
+//
+// Round 6: the same kernel with TWO fp16 terms (NT = 2, "h2"):   x * 2^s = hi + lo,  hi = f16(x 2^s), lo = f16(x 2^s - hi)
+// (round to nearest even; x 2^s - hi is exact in fp32 and has at most 12 significant bits, so lo drops at most its last one:
+// |x 2^s - hi - lo| <= 2^-23 |x 2^s|, zero for three elements in four) and THREE partial products per multiply
+//      u*v ~= lo_u hi_v + hi_u lo_v + hi_u hi_v                                  (dropped: lo_u lo_v <= 2^-22 |u v|)
+// on v_mfma_f32_32x32x16_f16 -- half the matrix-pipe work of the bf16 form, 4 bytes per operand element instead of 6.
+// fp16's 5-bit exponent needs the operands SCALED into its range: V by a power of two from the measured max |activation| of the
+// tensor the transform reads (dt_internal.h: dt_h2_base; the 16-sub-slot `amax` word its producer -- or absmax_kernel -- filled)
+// times a static per-position factor (the transform's gain), U per position at load (its own max); the epilogue multiplies the
+// fp32 accumulator by the inverse (GemmS3Args::pscale[p] * dt_h2_base_inv(amax)): powers of two, exact.  Elements more than
+// ~2^13 below the tensor's maximum have a subnormal lo term (absolute error 2^-25 in scaled units = 2^-40 of the maximum).
 #include "dt_internal.h"
 #include <cstring>
 
 typedef __bf16 s3_bf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 s3_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 s3_h2 __attribute__((ext_vector_type(2)));
 typedef float s3_f16 __attribute__((ext_vector_type(16)));
 typedef float s3_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void s3_lptr_t;
@@ -67,18 +80,36 @@ __device__ __forceinline__ void s3_split_pair(const s3_f2 x, unsigned &h, unsign
     l = s3_cvt2(r2);
 }
 
+// the two-term fp16 split of a pair (already scaled): one packed convert per term, the residual exact in fp32
+__device__ __forceinline__ void h2_split_pair(const s3_f2 x, unsigned &h, unsigned &l)
+{
+    const s3_h2 hh = __builtin_convertvector(x, s3_h2);
+    const s3_f2 r = x - __builtin_convertvector(hh, s3_f2);
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, s3_h2));
+}
+
 // vmcnt(N) alone (expcnt / lgkmcnt at their "don't wait" values); N < 64
 template <int N>
 __device__ __forceinline__ void s3_wait_vm() { __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14)); }
 
+template <int NT>
 __device__ __forceinline__ void s3_mfma(s3_f16 &c, const s3_bf8 &a, const s3_bf8 &b)      // a: U fragment (rows n), b: V fragment (rows m)
 {
+    if constexpr (NT == 2) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s3_h8, b), __builtin_bit_cast(s3_h8, a), c, 0, 0, 0);      // D[i = m][j = n]
+    } else {
 #if S3_EPI_ROWS
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0);      // D[i = m][j = n]
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0);      // D[i = m][j = n]
 #else
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);      // D[i = n][j = m]
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);      // D[i = n][j = m]
 #endif
+    }
 }
+// the partial products of one multiply, smallest first: term of U, term of V
+template <int NT> struct S3Prod;
+template <> struct S3Prod<3> { static constexpr int N = 6; static constexpr int UT[6] = {2, 1, 0, 1, 0, 0}; static constexpr int VT[6] = {0, 1, 2, 0, 1, 0}; };
+template <> struct S3Prod<2> { static constexpr int N = 3; static constexpr int UT[3] = {1, 0, 0}; static constexpr int VT[3] = {0, 1, 0}; };
 
 // NW waves per workgroup: 8 = 4 (m) x 2 (n) waves of 64 x BN/2 at two waves per SIMD (<= 256 registers each);
 //                         4 = 2 x 2 waves of 128 x BN/2, one wave per SIMD with the whole 512-entry register file (256 accumulators
@@ -92,9 +123,12 @@ __device__ __forceinline__ void s3_mfma(s3_f16 &c, const s3_bf8 &a, const s3_bf8
 //   BM rows of V per tile, NS LDS stages: 256 x 3 (one workgroup per CU, 144 KiB) or 128 x 2 with four waves (72 KiB: TWO workgroups
 //   per CU, each with one wave per SIMD -- the same two waves per SIMD in all, but one workgroup's epilogue and barriers overlap
 //   the other's main loop, and 128-row tiles fit short GEMMs better: the recurrent step's 588 rows are 5 x 128 instead of 3 x 256)
-template <int BN, int NW, bool ACT, int BM = 256, int NS = 3>
+//   NT: terms per operand -- 3 bf16 terms / six products (round 3), or 2 fp16 terms of SCALED operands / three products (round 6)
+template <int BN, int NW, bool ACT, int BM = 256, int NS = 3, int NT = 3>
 __device__ __forceinline__ void s3_body(const GemmS3Args &p)
 {
+    static_assert(NT == 3 || (NT == 2 && S3_EPI_ROWS), "the fp16 form has the row epilogue only");
+    constexpr int NPROD = S3Prod<NT>::N;
     constexpr int WM = NW / 2;                        // waves along m (two along n)
     constexpr int MB = BM / (WM * 32);             // 32-high m blocks per wave
     constexpr int NBW = BN / 64;                      // 32-wide n blocks per wave (BN/2 columns)
@@ -108,15 +142,29 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     // 1x1 layer write split rows).  Same terms, same products, same order: bit-identical to the pre-split form.
     constexpr bool VF = ACT;
     constexpr int PVF = (BM / 16) / NW;               // 16-row pieces of the fp32 A region per wave
-    constexpr int PT = VF ? 3 * PU + PVF : 3 * (PU + PV);   // DMA instructions per wave per stage
-    constexpr int OP_A = 3 * BN * 32;                 // bytes of U terms per stage
-    constexpr int STAGE = OP_A + (VF ? BM * 64 : 3 * BM * 32);      // + V (fp32 | terms)
+    constexpr int PT = VF ? NT * PU + PVF : NT * (PU + PV);   // DMA instructions per wave per stage
+    constexpr int OP_A = NT * BN * 32;                // bytes of U terms per stage
+    constexpr int STAGE = OP_A + (VF ? BM * 64 : NT * BM * 32);     // + V (fp32 | terms)
     extern __shared__ __attribute__((aligned(16))) unsigned char s3_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int KB = p.K >> 4;
-    const int MT = (p.Mt + BM - 1) / BM, NT = (p.N + BN - 1) / BN;      // (a ragged N only in the 1x1 form: its columns past N meet zero rows of U and are not stored)
-    const int ntiles = p.P * MT * NT;              // < 2^31 (launcher)
+    // fp16 form: the power of two this launch's V was scaled by (1x1 form: applied HERE, to the fp32 fragments) and its inverse for the
+    // epilogue; behind the stage ring: [64] per-position epilogue factors | [Np] bias of a 1x1 layer (read per lane in the epilogue --
+    // LDS reads wait on lgkmcnt, a global load there would wait for the next tile's DMA in flight)
+    [[maybe_unused]] float h2_fwd = 1.0f, h2_inv = 1.0f;
+    [[maybe_unused]] float *h2_tab = reinterpret_cast<float *>(s3_lds + NS * STAGE);
+    if constexpr (NT == 2) {
+        const unsigned am = dt_amax_read(p.amax);
+        h2_fwd = dt_h2_base(am);
+        h2_inv = dt_h2_base_inv(am);
+        for (int i = tid; i < 64; i += NW * 64) h2_tab[i] = i < p.P ? p.pscale[i] : 0.0f;
+        if (ACT)
+            for (int i = tid; i < p.Np; i += NW * 64) h2_tab[64 + i] = (p.bias && i < p.N) ? p.bias[i] : 0.0f;
+        __syncthreads();      // (nothing is in flight yet)
+    }
+    const int MT = (p.Mt + BM - 1) / BM, NTL = (p.N + BN - 1) / BN;      // (a ragged N only in the 1x1 form: its columns past N meet zero rows of U and are not stored)
+    const int ntiles = p.P * MT * NTL;             // < 2^31 (launcher)
     // XCD-aware order: workgroup w runs on XCD w % 8; each XCD walks a contiguous range of the n-fastest tile order, so
     // the 32 tiles resident on an XCD share their V / U panels through that XCD's L2
     const int G = gridDim.x;
@@ -129,13 +177,13 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     struct Tile { long long a0, b0; int m0, n0, pz; };
     auto tile_of = [&](int L) {
         Tile t;
-        const int nt = L % NT;
-        const int r = L / NT;
+        const int nt = L % NTL;
+        const int r = L / NTL;
         const int mt = r % MT;
         t.pz = r / MT;
         t.m0 = mt * BM; t.n0 = nt * BN;
-        t.a0 = (long long)t.pz * 3 * a_term + (long long)t.m0 * 16;
-        t.b0 = (long long)t.pz * 3 * b_term + (long long)t.n0 * 16;
+        t.a0 = (long long)t.pz * NT * a_term + (long long)t.m0 * 16;
+        t.b0 = (long long)t.pz * NT * b_term + (long long)t.n0 * 16;
         return t;
     };
     // running DMA sources of this lane (term 0; the other terms sit a_term / b_term elements further): advanced by one
@@ -147,7 +195,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     // tile), B rows = [bias[n], 0, ..., 0] as split terms (p.bias_s3) -- the three products b_t x 1.0 are among the six formed,
     // so the accumulator receives the bias to 2^-25 and the epilogue needs no loads (a vector load there has to wait on
     // vmcnt, i.e. on the stores before it and on the next tile's DMA in flight: measured 2.4x slower at K = 128)
-    const int KBX = KB + (p.bias_s3 ? 1 : 0);
+    const int KBX = KB + ((NT == 3 && p.bias_s3) ? 1 : 0);      // (the fp16 form adds the bias in its epilogue: h2_bias below)
     auto issue_src = [&](const Tile &t) {
         ta = a_term; tb = b_term;
         src_b = p.b + ((S3_ABLATE & 8) ? 0 : t.b0) + (long long)(32 * PU * wave + lrow) * 16 + dgran * 8;   // probe 8: every tile streams the same panels (L2 hits only)
@@ -167,7 +215,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
         unsigned char *dst = s3_lds + buf * STAGE;
         int k = 0;
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) {
+        for (int t3 = 0; t3 < NT; ++t3) {
 #pragma unroll
             for (int sp = 0; sp < PU; ++sp, ++k)
                 if (k >= lo && k < hi && (!U_HALF || wave < BN / 32))
@@ -265,10 +313,10 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
         if (keep <= 0) s3_wait_vm<0>();
         else if (keep == 1) {
             if (!U_HALF || wave < BN / 32) s3_wait_vm<PT>();
-            else s3_wait_vm<(VF ? PVF : 3 * PV)>();
+            else s3_wait_vm<(VF ? PVF : NT * PV)>();
         } else {
             if (!U_HALF || wave < BN / 32) s3_wait_vm<2 * PT>();
-            else s3_wait_vm<(VF ? 2 * PVF : 6 * PV)>();
+            else s3_wait_vm<(VF ? 2 * PVF : 2 * NT * PV)>();
         }
     };
 
@@ -277,30 +325,35 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     for (int q = 0; q < NS; ++q) issue_next();
     wait_dma(n_ahead - 1);
     if (!(S3_ABLATE & 4)) __builtin_amdgcn_s_barrier();
-    s3_bf8 v[MB][3], vn[MB][3], ua[3], ub[3];
+    s3_bf8 v[MB][NT], vn[MB][NT], ua[NT], ub[NT];
+    // VF: one pair of a fragment -> its NT terms (the fp16 form scales by the tensor's power of two first)
+    auto split_to = [&](const s3_f2 x, unsigned (*t)[4], int e) {
+        if constexpr (NT == 2) h2_split_pair(x * h2_fwd, t[0][e], t[1][e]);
+        else s3_split_pair(x, t[0][e], t[1][e], t[2][e]);
+    };
     {
         const unsigned char *sb = s3_lds;
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             if (VF) {
                 const s3_f4 lo = fragf(sb, offV[i]), hi = fragf(sb, offV[i] ^ 16);
-                unsigned t[3][4];
-                s3_split_pair(s3_f2{lo[0], lo[1]}, t[0][0], t[1][0], t[2][0]);
-                s3_split_pair(s3_f2{lo[2], lo[3]}, t[0][1], t[1][1], t[2][1]);
-                s3_split_pair(s3_f2{hi[0], hi[1]}, t[0][2], t[1][2], t[2][2]);
-                s3_split_pair(s3_f2{hi[2], hi[3]}, t[0][3], t[1][3], t[2][3]);
+                unsigned t[NT][4];
+                split_to(s3_f2{lo[0], lo[1]}, t, 0);
+                split_to(s3_f2{lo[2], lo[3]}, t, 1);
+                split_to(s3_f2{hi[0], hi[1]}, t, 2);
+                split_to(s3_f2{hi[2], hi[3]}, t, 3);
 #pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = __builtin_bit_cast(s3_bf8, s3_u4{t[t3][0], t[t3][1], t[t3][2], t[t3][3]});
+                for (int t3 = 0; t3 < NT; ++t3) v[i][t3] = __builtin_bit_cast(s3_bf8, s3_u4{t[t3][0], t[t3][1], t[t3][2], t[t3][3]});
             } else {
 #pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) v[i][t3] = frag(sb, offV[i] + t3 * BM * 32);
+                for (int t3 = 0; t3 < NT; ++t3) v[i][t3] = frag(sb, offV[i] + t3 * BM * 32);
             }
         }
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) ua[t3] = frag(sb, offU[0] + t3 * BN * 32);
+        for (int t3 = 0; t3 < NT; ++t3) ua[t3] = frag(sb, offU[0] + t3 * BN * 32);
     }
     [[maybe_unused]] s3_f4 vraw[MB][2];             // VF: the next stage's fp32 fragments ...
-    [[maybe_unused]] unsigned vnu[MB][3][4];        // ... and their terms, built pair by pair
+    [[maybe_unused]] unsigned vnu[MB][NT][4];       // ... and their terms, built pair by pair
     bool drain = false;       // global stores were issued since the last full wait
 #ifdef S3_TIMING
     unsigned long long tm_lgkm = 0, tm_vm = 0, tm_bar = 0, tm_n = 0;
@@ -351,7 +404,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                 }
                 // the group's first MFMA goes ahead of the loads for the NEXT group: the wait the compiler puts in front of
                 // it (for this group's fragments, read one group ago) then does not cover those fresh loads
-                s3_mfma(acc[j][0], u[2], v[0][0]);
+                s3_mfma<NT>(acc[j][0], u[S3Prod<NT>::UT[0]], v[0][S3Prod<NT>::VT[0]]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (j == NBW - 1) {
                     iss_go = iss.valid;                                  // refill the buffer this stage occupied, piecewise from here on
@@ -367,15 +420,15 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                 //   3 MB + 3 reads), then this group's share of the DMA pieces
                 constexpr int per = (PT + NBW - 1) / NBW, ng = (PT + per - 1) / per;   // pieces per group, groups that carry pieces
                 const int g = (j + 1) % NBW;                             // groups since the barrier: 0 = the barrier's own group
-                constexpr int VR = VF ? 2 * MB : 3 * MB;                  // V fragment reads of the next stage (last group)
-                const int n_reads = (j == NBW - 1) ? VR + 3 : 3;
+                constexpr int VR = VF ? 2 * MB : NT * MB;                 // V fragment reads of the next stage (last group)
+                const int n_reads = (j == NBW - 1) ? VR + NT : NT;
                 const int n_side = n_reads + ((g < ng) ? per : 0);
                 auto side = [&](int k) {
                     if (k < n_reads) {
                         if (j == NBW - 1) {
                             if (k < VR) {
                                 if (VF) vraw[k / 2][k % 2] = fragf(sn, offV[k / 2] ^ ((k % 2) * 16));
-                                else vn[k / 3][k % 3] = frag(sn, offV[k / 3] + (k % 3) * BM * 32);
+                                else vn[k / NT][k % NT] = frag(sn, offV[k / NT] + (k % NT) * BM * 32);
                             } else (j & 1 ? ua : ub)[k - VR] = frag(sn, offU[0] + (k - VR) * BN * 32);
                         } else
                             (j & 1 ? ua : ub)[k] = frag(sb, offU[j + 1] + k * BN * 32);
@@ -386,18 +439,19 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                     }
                 };
                 {
-                    constexpr int UT[6] = {2, 1, 0, 1, 0, 0}, VT[6] = {0, 1, 2, 0, 1, 0};
                     // VF, last group: the next stage's fp32 fragments were requested in slots 0 .. 2 MB - 1; their split -- 4 MB pairs of
                     // 9 VALU instructions, about one MFMA's shadow each -- goes pair by pair into the slots behind the reads, two pairs
                     // per slot towards the end, the rest behind the group's last MFMA
                     auto split_pair = [&](int q) {      // pair q % 4 of block q / 4
                         const int i = q >> 2, e = q & 3;
                         const s3_f4 &src = vraw[i][e >> 1];
-                        s3_split_pair(s3_f2{src[2 * (e & 1)], src[2 * (e & 1) + 1]}, vnu[i][0][e], vnu[i][1][e], vnu[i][2][e]);
+                        split_to(s3_f2{src[2 * (e & 1)], src[2 * (e & 1) + 1]}, vnu[i], e);
                     };
-                    constexpr int NPAIR = 4 * MB, SLOT0 = 2 * MB + 3, NSLOT = 6 * MB - 1 - SLOT0;
+                    // (the fp16 form's last group has fewer MFMA slots than reads: all its pairs follow the group's last MFMA, in the
+                    //  shadow of the SIMD's other wave)
+                    constexpr int NPAIR = 4 * MB, SLOT0 = 2 * MB + NT, NSLOT = NPROD * MB - 1 - SLOT0;
                     auto split_slot = [&](int sidx) {
-                        if (!(VF && j == NBW - 1) || sidx < SLOT0) return;
+                        if (!(VF && j == NBW - 1) || NSLOT < 2 || sidx < SLOT0) return;
                         const int r = sidx - SLOT0;
                         const int lo = r < NSLOT - 2 ? r : (NSLOT - 2) + 2 * (r - (NSLOT - 2));
                         const int hi = r < NSLOT - 2 ? lo + 1 : lo + 2;
@@ -406,20 +460,20 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                             if (q >= lo && q < hi) split_pair(q);
                     };
 #pragma unroll
-                    for (int m = 1; m < 6 * MB; ++m) {
+                    for (int m = 1; m < NPROD * MB; ++m) {
                         if (m - 1 < n_side) side(m - 1);                 // (indices are compile-time constants after unrolling)
                         split_slot(m - 1);
                         const int pr = m / MB, i = m % MB;
-                        s3_mfma(acc[j][i], u[UT[pr]], v[i][VT[pr]]);
+                        s3_mfma<NT>(acc[j][i], u[S3Prod<NT>::UT[pr]], v[i][S3Prod<NT>::VT[pr]]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
-                    for (int kk = 6 * MB - 1; kk < 3 * MB + 3 + per; ++kk)    // (more side work than MFMA slots: MB = 2, last group)
+                    for (int kk = NPROD * MB - 1; kk < NT * MB + NT + per; ++kk)    // (more side work than MFMA slots: MB = 2, last group)
                         if (kk < n_side) side(kk);
                     if (VF && j == NBW - 1) {
 #pragma unroll
                         for (int q = 0; q < NPAIR; ++q)
-                            if (q >= (NSLOT - 2) + 4) split_pair(q);
+                            if (NSLOT < 2 || q >= (NSLOT - 2) + 4) split_pair(q);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -427,10 +481,21 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3)
+                for (int t3 = 0; t3 < NT; ++t3)
                     v[i][t3] = VF ? __builtin_bit_cast(s3_bf8, s3_u4{vnu[i][t3][0], vnu[i][t3][1], vnu[i][t3][2], vnu[i][t3][3]}) : vn[i][t3];
         }
 
+        if constexpr (NT == 2) {      // back to the operands' own scale (powers of two: exact), a 1x1 layer's bias in the same fma
+            const float f = h2_tab[cur.pz] * h2_inv;
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) {
+                const float bl = ACT ? h2_tab[64 + cur.n0 + wn * (BN / 2) + rl + 32 * j] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[j][i][e] = ACT ? __builtin_fmaf(acc[j][i][e], f, bl) : acc[j][i][e] * f;
+            }
+        }
         if (ACT) {      // a 1x1 layer: LeakyReLU (its bias came in through the extra K stage).  ALL of it before the first store:
                         // a VALU write to a register an in-flight store still reads waits for that store (32 serialised stores, 2.2x)
 #pragma unroll
@@ -495,56 +560,68 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     }
 }
 
-template <int BN, int NW, bool ACT>
+#ifndef S3_H2_NS
+#define S3_H2_NS 4           // LDS stages of the fp16 form (32 KiB each at 256-row tiles: 128 KiB)
+#endif
+#ifndef S3_H2_HALF_NS
+#define S3_H2_HALF_NS 3      // ... of its 128-row form (24 KiB each, two workgroups per CU: 144 KiB)
+#endif
+template <int NT> constexpr int s3_ns() { return NT == 2 ? S3_H2_NS : 3; }
+template <int NT> constexpr int s3_ns_half() { return NT == 2 ? S3_H2_HALF_NS : 2; }
+template <int BN, int NW, bool ACT, int NT>
 __global__ __launch_bounds__(NW * 64) void wino_gemm_s3_kernel(GemmS3Args p)
 {
-    s3_body<BN, NW, ACT>(p);
+    s3_body<BN, NW, ACT, 256, s3_ns<NT>(), NT>(p);
 }
 // the two-workgroups-per-CU form: 128-row tiles, four waves, two LDS stages
-template <int BN, bool ACT>      // (two waves per SIMD: without the attribute the allocator spreads over all 512 registers and only one workgroup fits)
+template <int BN, bool ACT, int NT>      // (two waves per SIMD: without the attribute the allocator spreads over all 512 registers and only one workgroup fits)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_gemm_s3_half_kernel(GemmS3Args p)
 {
-    s3_body<BN, 4, ACT, 128, 2>(p);
+    s3_body<BN, 4, ACT, 128, s3_ns_half<NT>(), NT>(p);
 }
 #ifdef S3_WITH_4WAVES
 // the one-wave-per-SIMD form: told so, or the register allocator budgets for two waves and spills the accumulators
-template <int BN, bool ACT>
+template <int BN, bool ACT, int NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_gemm_s3_kernel_w4(GemmS3Args p)
 {
-    s3_body<BN, 4, ACT>(p);
+    s3_body<BN, 4, ACT, 256, s3_ns<NT>(), NT>(p);
 }
 #endif
 
-// executed bf16 MFMA FLOPs of one launch (six partial products per multiply, whole tiles)
-double wino_gemm_s3_flops(const GemmS3Args &a) { return 12.0 * a.P * (double)a.Mt * a.K * a.N; }
+// executed 16-bit MFMA FLOPs of one launch (six partial products per multiply in the bf16 form, three in the fp16 form)
+double wino_gemm_s3_flops(const GemmS3Args &a) { return (a.nt == 2 ? 6.0 : 12.0) * a.P * (double)a.Mt * a.K * a.N; }
 
 bool wino_gemm_s3_usable(int Mt, int K, int N)
 {
     return Mt > 0 && K >= 32 && K % 16 == 0 && N >= 128 && N % 128 == 0;
 }
 
-template <int BN, int NW, bool ACT>
+#define S3_H2_MAXNP 2048      // widest 1x1 layer whose bias the fp16 form keeps in LDS
+template <int BN, int NW, bool ACT, int NT>
 static int s3_launch(hipStream_t st, const GemmS3Args &a, long long grid)
 {
     static PerDeviceOnce attr;
-    const size_t lds = (size_t)3 * (3 * BN * 32 + (ACT ? 256 * 64 : 3 * 256 * 32));      // ACT: the fp32 A stage
+    // the largest request of this instance (ACT: the fp32 A stage; fp16 form: + the epilogue tables)
+    const size_t lds_max = (size_t)s3_ns<NT>() * (NT * BN * 32 + (ACT ? 256 * 64 : NT * 256 * 32)) + (NT == 2 ? 256 + (ACT ? S3_H2_MAXNP * 4 : 0) : 0);
+    const size_t lds = lds_max - ((NT == 2 && ACT) ? (size_t)(S3_H2_MAXNP - a.Np) * 4 : 0);
     if (attr.ensure(nullptr, [&](int) {
-            return hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_kernel<BN, NW, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess;
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_kernel<BN, NW, ACT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess;
         }))
         return 1;
-    hipLaunchKernelGGL((wino_gemm_s3_kernel<BN, NW, ACT>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((wino_gemm_s3_kernel<BN, NW, ACT, NT>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
-template <int BN, bool ACT>
+template <int BN, bool ACT, int NT>
 static int s3_launch_half(hipStream_t st, const GemmS3Args &a, long long grid)
 {
     static PerDeviceOnce attr;
-    const size_t lds = (size_t)2 * (3 * BN * 32 + (ACT ? 128 * 64 : 3 * 128 * 32));
+    const size_t lds_max = (size_t)s3_ns_half<NT>() * (NT * BN * 32 + (ACT ? 128 * 64 : NT * 128 * 32)) + (NT == 2 ? 256 + (ACT ? S3_H2_MAXNP * 4 : 0) : 0);
+    const size_t lds = lds_max - ((NT == 2 && ACT) ? (size_t)(S3_H2_MAXNP - a.Np) * 4 : 0);
     if (attr.ensure(nullptr, [&](int) {
-            return hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_half_kernel<BN, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess;
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(wino_gemm_s3_half_kernel<BN, ACT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess;
         }))
         return 1;
-    hipLaunchKernelGGL((wino_gemm_s3_half_kernel<BN, ACT>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((wino_gemm_s3_half_kernel<BN, ACT, NT>), dim3((unsigned)grid), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -581,6 +658,9 @@ int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
     if (a.a_f32 ? (a.Mt <= 0 || a.K < 32 || a.K % 16 || a.N < 64 || a.N > a.Np) : !wino_gemm_s3_usable(a.Mt, a.K, a.N)) return 2;
     if (a.Mp % 256 || a.Mp < a.Mt || (!S3_EPI_ROWS && a.ldc % 4) || a.P <= 0) return 2;      // (the row-form epilogue stores 4 bytes per lane: any ldc)
     if ((a.bias_s3 != nullptr) != (a.ones != nullptr)) return 2;
+    if (a.nt != 0 && a.nt != 2 && a.nt != 3) return 2;
+    const bool h2 = a.nt == 2;      // the fp16 form: scaled operands, its bias (1x1 form) as plain floats for the epilogue
+    if (h2 && (!a.pscale || !a.amax || a.bias_s3 || a.P > 64 || (a.a_f32 && a.Np > S3_H2_MAXNP))) return 2;
     // the 1x1 form: A = fp32 rows [Mt][a_ld] (a_f32), P = 1, LeakyReLU(slope) in the epilogue (slope 1 = none); the Winograd form: A = split terms (a)
     if (a.a_f32 ? (a.P != 1 || a.a_ld % 4 || a.a_ld < a.K || (reinterpret_cast<uintptr_t>(a.a_f32) & 15)) : (a.a == nullptr || a.act)) return 2;
     const bool act = a.a_f32 != nullptr;
@@ -601,26 +681,37 @@ int launch_wino_gemm_s3(hipStream_t st, const GemmS3Args &a, int cus)
     if (half && wide) {
         long long grid = 2ll * cus;
         if (grid > tiles_h) grid = tiles_h;
-        return act ? s3_launch_half<256, true>(st, a, grid) : s3_launch_half<256, false>(st, a, grid);
+        if (h2) return act ? s3_launch_half<256, true, 2>(st, a, grid) : s3_launch_half<256, false, 2>(st, a, grid);
+        return act ? s3_launch_half<256, true, 3>(st, a, grid) : s3_launch_half<256, false, 3>(st, a, grid);
     }
     long long grid = cus;      // one workgroup per CU (108 / 144 KiB of LDS), persistent over the tiles
     if (grid > tiles) grid = tiles;
     const int nw = a.waves == 8 ? 8 : (a.waves == 4 ? 4 : S3_DEFAULT_WAVES);
-    if (act) return wide ? s3_launch<256, 8, true>(st, a, grid) : s3_launch<128, 8, true>(st, a, grid);
 #ifdef S3_WITH_4WAVES      // the one-wave-per-SIMD form (micro-benchmark builds)
-    if (nw == 4) {
-        static PerDeviceOnce attr4[2];
-        const size_t lds = (size_t)3 * (3 * BN * 32 + 3 * 256 * 32);
-        const void *fn = wide ? reinterpret_cast<const void *>(wino_gemm_s3_kernel_w4<256, false>) : reinterpret_cast<const void *>(wino_gemm_s3_kernel_w4<128, false>);
-        if (attr4[wide].ensure(nullptr, [&](int) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess; }))
+    if (nw == 4 && !act) {
+        static PerDeviceOnce attr4[4];
+        const size_t lds = h2 ? (size_t)s3_ns<2>() * (2 * BN * 32 + 2 * 256 * 32) + 256 : (size_t)3 * (3 * BN * 32 + 3 * 256 * 32);
+        const void *fn = h2 ? (wide ? reinterpret_cast<const void *>(wino_gemm_s3_kernel_w4<256, false, 2>) : reinterpret_cast<const void *>(wino_gemm_s3_kernel_w4<128, false, 2>))
+                            : (wide ? reinterpret_cast<const void *>(wino_gemm_s3_kernel_w4<256, false, 3>) : reinterpret_cast<const void *>(wino_gemm_s3_kernel_w4<128, false, 3>));
+        if (attr4[wide + 2 * h2].ensure(nullptr, [&](int) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess; }))
             return 1;
-        if (wide) hipLaunchKernelGGL((wino_gemm_s3_kernel_w4<256, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((wino_gemm_s3_kernel_w4<128, false>), dim3((unsigned)grid), dim3(256), lds, st, a);
+        if (h2) {
+            if (wide) hipLaunchKernelGGL((wino_gemm_s3_kernel_w4<256, false, 2>), dim3((unsigned)grid), dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((wino_gemm_s3_kernel_w4<128, false, 2>), dim3((unsigned)grid), dim3(256), lds, st, a);
+        } else {
+            if (wide) hipLaunchKernelGGL((wino_gemm_s3_kernel_w4<256, false, 3>), dim3((unsigned)grid), dim3(256), lds, st, a);
+            else hipLaunchKernelGGL((wino_gemm_s3_kernel_w4<128, false, 3>), dim3((unsigned)grid), dim3(256), lds, st, a);
+        }
         return hipGetLastError() == hipSuccess ? 0 : 1;
     }
 #endif
+    if (h2) {
+        if (act) return wide ? s3_launch<256, 8, true, 2>(st, a, grid) : s3_launch<128, 8, true, 2>(st, a, grid);
+        return wide ? s3_launch<256, 8, false, 2>(st, a, grid) : s3_launch<128, 8, false, 2>(st, a, grid);
+    }
+    if (act) return wide ? s3_launch<256, 8, true, 3>(st, a, grid) : s3_launch<128, 8, true, 3>(st, a, grid);
     (void)nw;
-    return wide ? s3_launch<256, 8, false>(st, a, grid) : s3_launch<128, 8, false>(st, a, grid);
+    return wide ? s3_launch<256, 8, false, 3>(st, a, grid) : s3_launch<128, 8, false, 3>(st, a, grid);
 }
 
 // fp32 -> three bf16 terms, round-to-nearest-even at every step (the same arithmetic as the device split, winograd.hip:s3_split)
@@ -659,5 +750,60 @@ void wino_s3_pack_weights(const float *u, int P, int npad, int K, unsigned short
                 wino_s3_split_host(u[((size_t)p * npad + n) * K + k], t);
                 for (int t3 = 0; t3 < 3; ++t3)
                     dst[((((size_t)p * 3 + t3) * KB + (k >> 4)) * npad + n) * 16 + (k & 15)] = t[t3];
+            }
+}
+
+// ---- the fp16 form's host twins -------------------------------------------------------------------------------------------------------
+unsigned short h2_f16_rne(float x)
+{
+    unsigned int u;
+    memcpy(&u, &x, 4);
+    const unsigned sign = (u >> 16) & 0x8000u;
+    const unsigned a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return (unsigned short)(sign | 0x7c00u | (a > 0x7f800000u ? 0x200u : 0u));      // inf / nan
+    if (a >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);      // >= 65520: rounds to infinity
+    const int e = (int)(a >> 23) - 127;
+    if (e >= -14) {      // normal in fp16: drop 13 mantissa bits, nearest even (a carry out of the mantissa bumps the exponent: still the right bits)
+        const unsigned m = a & 0x7fffffu;
+        unsigned h = ((unsigned)(e + 15) << 10) | (m >> 13);
+        const unsigned rem = m & 0x1fffu;
+        if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+        return (unsigned short)(sign | h);
+    }
+    if (e < -25) return (unsigned short)sign;      // below half the smallest subnormal
+    // subnormal: value = m24 * 2^(e - 23), unit 2^-24
+    const unsigned m24 = (a & 0x7fffffu) | 0x800000u;
+    const int sh = -e - 1;      // 14 .. 24
+    unsigned h = m24 >> sh;
+    const unsigned rem = m24 & ((1u << sh) - 1u), halfway = 1u << (sh - 1);
+    if (rem > halfway || (rem == halfway && (h & 1u))) ++h;
+    return (unsigned short)(sign | h);
+}
+float h2_f16_f32(unsigned short h)
+{
+    const unsigned sign = ((unsigned)h & 0x8000u) << 16;
+    const unsigned e = (h >> 10) & 31u, m = h & 0x3ffu;
+    float x;
+    if (e == 31u) { const unsigned u = sign | 0x7f800000u | (m << 13); memcpy(&x, &u, 4); return x; }
+    if (e == 0u) { x = (float)m * 5.9604644775390625e-8f; return sign ? -x : x; }      // m * 2^-24
+    const unsigned u = sign | ((e + 112u) << 23) | (m << 13);
+    memcpy(&x, &u, 4);
+    return x;
+}
+void wino_h2_split_host(float x, unsigned short t[2])
+{
+    t[0] = h2_f16_rne(x);
+    t[1] = h2_f16_rne(x - h2_f16_f32(t[0]));
+}
+void wino_h2_pack_weights(const float *u, int P, int npad, int K, const float *uscale, unsigned short *dst)
+{
+    const int KB = K / 16;
+    for (int p = 0; p < P; ++p)
+        for (int n = 0; n < npad; ++n)
+            for (int k = 0; k < K; ++k) {
+                unsigned short t[2];
+                wino_h2_split_host(u[((size_t)p * npad + n) * K + k] * uscale[p], t);
+                for (int t2 = 0; t2 < 2; ++t2)
+                    dst[((((size_t)p * 2 + t2) * KB + (k >> 4)) * npad + n) * 16 + (k & 15)] = t[t2];
             }
 }

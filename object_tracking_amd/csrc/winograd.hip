@@ -205,6 +205,16 @@ __device__ __forceinline__ void s3_split2(const VecOf<2>::T x, unsigned t[3])
     t[0] = __builtin_bit_cast(unsigned, h); t[1] = __builtin_bit_cast(unsigned, m); t[2] = __builtin_bit_cast(unsigned, l);
 }
 
+// ---- the fp16 form (wino_gemm_s3.hip, NT = 2): x scaled by a power of two, then  hi = f16(x), lo = f16(x - hi)  (nearest even) ----
+typedef _Float16 wino_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void h2_split4(const VecOf<4>::T x, wino_u2 t[2])
+{
+    const wino_h4 h = __builtin_convertvector(x, wino_h4);
+    const VecOf<4>::T r = x - __builtin_convertvector(h, VecOf<4>::T);
+    t[0] = __builtin_bit_cast(wino_u2, h);
+    t[1] = __builtin_bit_cast(wino_u2, __builtin_convertvector(r, wino_h4));
+}
+
 // One work item = (tile, V channels).  Tile (grp, ty, tx) covers virtual rows TS*ty-1 .. TS*ty+TS, cols
 // TS*tx-1 .. TS*tx+TS ('same' padding, separators and the rows/columns past the image read as zero).
 // S3: V leaves as split-bf16 terms [P][3][C/16][Mp][16] (wino_gemm_s3.hip).  Items then run (16-channel block, tile, channel group)
@@ -600,10 +610,13 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_input_coop6_kernel(WinoArgs
 // other half of the same input lines).  wino_input_coop6_kernel<true> is the 4-channel form of the same thing (DT_S3_IN=0).
 #define WINO_S3IN_THREADS 128
 typedef unsigned int wino_u4 __attribute__((ext_vector_type(4)));
-template <int TS>      // TS = 6: the 8x8 window of F(6x6); TS = 4: the 6x6 window of F(4x4) (lanes 6, 7 of each group idle) -- the recurrent step
+// NT = 3: three bf16 terms; NT = 2: two fp16 terms of V[p] * dt_h2_base(amax of the input) * rowfac[xi] * rowfac[nu] (dt_internal.h)
+template <int TS, int NT = 3>      // TS = 6: the 8x8 window of F(6x6); TS = 4: the 6x6 window of F(4x4) (lanes 6, 7 of each group idle) -- the recurrent step
 __global__ __launch_bounds__(WINO_S3IN_THREADS) void wino_input_s3_kernel(WinoArgs p)
 {
     constexpr int NI = TS + 2;
+    [[maybe_unused]] float h2_row = 1.0f;      // fp16 form: this lane's row factor times the tensor's power of two
+    if constexpr (NT == 2) h2_row = dt_h2_base(dt_amax_read(p.amax)) * dt_h2_rowfac(TS, (int)(threadIdx.x & 7));
     typedef VecOf<4>::T T;
     constexpr int IPW = WINO_S3IN_THREADS / 8;      // items per workgroup
     // measured (profiles/r04_transform_ab.txt): the big F(6x6) launches are fastest with round 3's form -- two LDS images and a
@@ -664,20 +677,26 @@ if constexpr (ONE) {      // one LDS image, the two channel halves one after the
             unsigned short *dst = p.v_s3 + ((long long)(c >> 4) * p.Mp + tile) * 16 + (c & 15);
             // every split BEFORE the first store, each result in its own registers: a VALU write to a register that a store
             // in flight still reads waits for that store (the stores then run one after the other)
-            wino_u4 o[NI][3];
+            wino_u4 o[NI][NT];
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                wino_u2 ta[3], tb[3];
-                s3_split4(ca[j], ta);
-                s3_split4(cb[j], tb);
+                wino_u2 ta[NT], tb[NT];
+                if constexpr (NT == 2) {
+                    const float f = h2_row * dt_h2_rowfac(TS, j);
+                    h2_split4(ca[j] * f, ta);
+                    h2_split4(cb[j] * f, tb);
+                } else {
+                    s3_split4(ca[j], ta);
+                    s3_split4(cb[j], tb);
+                }
 #pragma unroll
-                for (int k = 0; k < 3; ++k) o[j][k] = wino_u4{ta[k][0], ta[k][1], tb[k][0], tb[k][1]};
+                for (int k = 0; k < NT; ++k) o[j][k] = wino_u4{ta[k][0], ta[k][1], tb[k][0], tb[k][1]};
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) s3_store<1>(dst + ((long long)(NI * sub + j) * 3 + k) * term, o[j][k]);
+                for (int k = 0; k < NT; ++k) s3_store<1>(dst + ((long long)(NI * sub + j) * NT + k) * term, o[j][k]);
         }
         if constexpr (ONE) wino_item_sync(); else __syncthreads();
     }
@@ -779,6 +798,95 @@ int launch_wino_s3_pack(hipStream_t st, const float *u, int P, int npad, int K, 
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// ---- fp16 form: max |x| of a tensor, weights / caller operands as two fp16 terms --------------------------------------------------------
+// max |x| over rows x cols floats (row stride ld) per plane z -> slot z (DT_AMAX_SUB words, zeroed by the caller): the integer order of
+// the bits of non-negative floats is their order as numbers, so the reduction is an unsigned max and its result does not depend on
+// the order of the atomics
+__global__ __launch_bounds__(256) void absmax_kernel(const float *x, long long rows, int cols, long long ld, long long plane, unsigned *slots)
+{
+    const float *xz = x + (long long)blockIdx.y * plane;
+    const int cq = cols >> 2;
+    const long long items = rows * cq;
+    unsigned m = 0;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long long)gridDim.x * blockDim.x) {
+        const long long r = it / cq;
+        const int c = (int)(it - r * cq) * 4;
+        const VecOf<4>::T v = __builtin_nontemporal_load(reinterpret_cast<const VecOf<4>::T *>(xz + r * ld + c));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned b = __float_as_uint(v[e]) & 0x7fffffffu;
+            m = b > m ? b : m;
+        }
+    }
+    if ((cols & 3) && blockIdx.x == 0)      // ragged tail columns (caller tensors)
+        for (long long r = threadIdx.x; r < rows; r += blockDim.x)
+            for (int c = cq * 4; c < cols; ++c) {
+                const unsigned b = __float_as_uint(xz[r * ld + c]) & 0x7fffffffu;
+                m = b > m ? b : m;
+            }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const unsigned w = (unsigned)__shfl_xor((int)m, o);
+        m = w > m ? w : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(slots + (long long)blockIdx.y * DT_AMAX_SUB + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (DT_AMAX_SUB - 1)), m);
+}
+int launch_absmax(hipStream_t st, const float *x, long long rows, int cols, long long ld, int planes, long long plane_stride, unsigned *slots)
+{
+    if (!x || !slots || rows <= 0 || cols <= 0 || planes <= 0 || planes > 65535) return 2;
+    if (cols >= 4 && ((ld & 3) || (plane_stride & 3) || (reinterpret_cast<uintptr_t>(x) & 15))) return 2;
+    if (hipMemsetAsync(slots, 0, (size_t)planes * DT_AMAX_SUB * sizeof(unsigned), st) != hipSuccess) return 1;
+    const long long items = rows * (cols >= 4 ? cols >> 2 : 1);
+    long long nb = (items + 255) / 256 / 8;      // ~8 items (128 bytes) per thread
+    nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)nb, (unsigned)planes), dim3(256), 0, st, x, rows, cols, ld, plane_stride, slots);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+// U [P][npad][K] fp32 -> two fp16 terms [P][2][K/16][npad][16] of U[p] * dt_h2_base(max |U[p]|); the plane maxima in `slots` (launch_absmax)
+__global__ __launch_bounds__(256) void wino_h2_pack_kernel(const float *u, int P, int npad, int K, const unsigned *slots, int slot_stride, unsigned short *dst)
+{
+    const int kq = K / 4;
+    const long long n_items = (long long)P * npad * kq;
+    const long long term = (long long)(K >> 4) * npad * 16;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < n_items; it += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(it % kq) * 4;
+        const long long r = it / kq;
+        const int n = (int)(r % npad), pz = (int)(r / npad);
+        unsigned am = 0;
+#pragma unroll
+        for (int q = 0; q < DT_AMAX_SUB; ++q) { const unsigned w = slots[pz * slot_stride + q]; am = w > am ? w : am; }
+        wino_u2 tr[2];
+        h2_split4(vload<4>(u + r * K + k) * dt_h2_base(am), tr);
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+            *reinterpret_cast<wino_u2 *>(dst + ((long long)pz * 2 + t2) * term + ((long long)(k >> 4) * npad + n) * 16 + (k & 15)) = tr[t2];
+    }
+}
+// epilogue factor of position p: 1 / (U's power of two  x  the static row factors of V's scale); ts = 0: a plain GEMM (no row factors)
+__global__ void wino_h2_pscale_kernel(const unsigned *slots, int P, int ts, float *pscale)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    unsigned am = 0;
+    for (int q = 0; q < DT_AMAX_SUB; ++q) { const unsigned w = slots[p * DT_AMAX_SUB + q]; am = w > am ? w : am; }
+    const int ni = ts + 2;
+    const float rf = ts ? dt_h2_rowfac(ts, p / ni) * dt_h2_rowfac(ts, p % ni) : 1.0f;
+    pscale[p] = dt_h2_base_inv(am) / rf;
+}
+// weights (or a caller's operand, ts = 0) in the fp16 form: plane maxima -> terms + per-position epilogue factors.  `slots`: P x DT_AMAX_SUB words of scratch
+// pscale == null: ONE scale for all planes (an activation-like operand: `slots` is one slot, the maximum over the whole tensor)
+int launch_wino_h2_pack(hipStream_t st, const float *u, int P, int npad, int K, int ts, unsigned *slots, unsigned short *dst, float *pscale)
+{
+    if (!u || !dst || !slots || P <= 0 || npad <= 0 || K % 16) return 2;
+    if (int rc = pscale ? launch_absmax(st, u, npad, K, K, P, (long long)npad * K, slots) : launch_absmax(st, u, (long long)P * npad, K, K, 1, 0, slots)) return rc;
+    const long long n_items = (long long)P * npad * (K / 4);
+    long long nb = (n_items + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(wino_h2_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, u, P, npad, K, slots, pscale ? DT_AMAX_SUB : 0, dst);
+    if (pscale) hipLaunchKernelGGL(wino_h2_pscale_kernel, dim3((P + 63) / 64), dim3(64), 0, st, slots, P, ts, pscale);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 // a launch this small is latency-bound on the one-thread-per-item kernels: take the cooperative form
 static inline bool wino_coop_wanted(const WinoArgs &a, long long items_pairs)
 {
@@ -788,7 +896,13 @@ static inline bool wino_coop_wanted(const WinoArgs &a, long long items_pairs)
 int launch_wino_input(hipStream_t st, const WinoArgs &a)
 {
     if (a.C % 4 || a.in_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4 && a.ts != 6) || a.g < 1) return 2;
-    if (a.v_s3 && a.ts == 4) {
+    if (a.v_s3 && a.nt == 2) {      // the fp16 form: the cooperative 8-channel producer only
+        if ((a.ts != 6 && a.ts != 4) || a.C % 32 || a.Mp < a.Mt || !a.amax) return 2;
+        const long long wgs = ((long long)((a.Mt + 3) & ~3) * (a.C / 8) + WINO_S3IN_THREADS / 8 - 1) / (WINO_S3IN_THREADS / 8);
+        const unsigned grid = (unsigned)(wgs < 262144 ? wgs : 262144);
+        if (a.ts == 6) hipLaunchKernelGGL((wino_input_s3_kernel<6, 2>), dim3(grid), dim3(WINO_S3IN_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((wino_input_s3_kernel<4, 2>), dim3(grid), dim3(WINO_S3IN_THREADS), 0, st, a);
+    } else if (a.v_s3 && a.ts == 4) {
         if (a.C % 16 || a.Mp < a.Mt) return 2;
         if (a.C % 32 == 0 && a.coop != 0) {      // the cooperative 8-channel form (20 instead of 44 us per recurrent step at 48 clips)
             const long long wgs = ((long long)((a.Mt + 3) & ~3) * (a.C / 8) + WINO_S3IN_THREADS / 8 - 1) / (WINO_S3IN_THREADS / 8);

@@ -29,7 +29,7 @@ SYMBOLS = [
     "dt_track_row_width", "dt_track_detect", "dt_track_recurrent",
     "dt_packed_row_ints", "dt_pack_detections", "dt_unpack_detections",
     "dt_track_xproj_width", "dt_track_detect_xproj", "dt_track_recurrent_xproj",
-    "dt_gemm_split_bf16",
+    "dt_gemm_split_bf16", "dt_gemm_split",
 ]
 
 _lib = None
@@ -90,6 +90,7 @@ def load_library():
     L.dt_conv2d.argtypes = [vp, vp, ci, ci, ci, ci, vp, ci, ci, vp, cf, ci, vp, vp]
     L.dt_convlstm_step.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp]
     L.dt_gemm_split_bf16.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    L.dt_gemm_split.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     L.dt_profile_enable.argtypes = [vp, ci]
     L.dt_graph_enable.argtypes = [vp, ci]
     L.dt_profile_reset.argtypes = [vp]
@@ -520,9 +521,10 @@ class Context(object):
                                               ks[0][1], ks[1][1], ks[2][1], _dptr(ho), _dptr(co)), "dt_convlstm_step")
         return ho, co
 
-    def gemm_split_bf16(self, v, u, half=0):
-        """v [P,Mt,K], u [P,N,K] float32 -> [P,Mt,N] through wino_gemm_s3.hip (three-term bf16 split of both operands on
-        the device, six MFMA partial products per multiply): the Winograd-domain contraction at a caller-chosen shape."""
+    def gemm_split_bf16(self, v, u, half=0, nt=3):
+        """v [P,Mt,K], u [P,N,K] float32 -> [P,Mt,N] through wino_gemm_s3.hip: the Winograd-domain contraction at a caller-chosen
+        shape.  nt=3: three-term bf16 split of both operands on the device, six MFMA partial products per multiply; nt=2: the
+        fp16 form (two terms of the scaled operands, three products)."""
         t = self.torch
         assert v.is_cuda and u.is_cuda and v.is_contiguous() and u.is_contiguous() and v.dtype == t.float32 and u.dtype == t.float32
         P, Mt, K = v.shape
@@ -530,8 +532,11 @@ class Context(object):
         N = u.shape[1]
         out = self._f32(P, Mt, N)
         self._sync_stream()
-        self._check(self.lib.dt_gemm_split_bf16(self.h, _dptr(v), _dptr(u), P, Mt, K, N, int(half), _dptr(out)), "dt_gemm_split_bf16")
+        self._check(self.lib.dt_gemm_split(self.h, _dptr(v), _dptr(u), P, Mt, K, N, int(half), int(nt), _dptr(out)), "dt_gemm_split")
         return out
+
+    def gemm_split(self, v, u, half=0, nt=2):
+        return self.gemm_split_bf16(v, u, half=half, nt=nt)
 
     # ---- profiling ------------------------------------------------------
     def profile_enable(self, on=True):

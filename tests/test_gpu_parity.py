@@ -1444,6 +1444,7 @@ def test_split_bf16_gemm_error_against_float64(ctx, monkeypatch):
     assert err["2"] < 5e-5, err
 
 
+@pytest.mark.parametrize("nt", [2, 3], ids=["f16x2", "bf16x3"])
 @pytest.mark.parametrize("P,Mt,K,N,half,what", [
     (64, 7840, 1024, 1024, -1, "conv_19 / conv_20 at 48 clips (160 3x3 mosaics x 49 tiles), 256-row tiles"),
     (64, 7840, 1280, 1024, -1, "conv_22"),
@@ -1456,9 +1457,10 @@ def test_split_bf16_gemm_error_against_float64(ctx, monkeypatch):
     (1, 973440, 512, 256, 2, "conv_10 / conv_12 over 1440 x 676 pixels, the same form"),
     (1, 500000, 256, 128, 2, "conv_7's shape (K = 256, 128-column tile), the same form"),
 ])
-def test_split_bf16_gemm_benched_shapes_against_float64(ctx, P, Mt, K, N, half, what):
+def test_split_bf16_gemm_benched_shapes_against_float64(ctx, P, Mt, K, N, half, what, nt):
     """wino_gemm_s3.hip AT THE SHAPES THE BENCH STEP LAUNCHES (48 clips x 30 frames x 416x416), through the production
-    pack kernel and launcher (dt_gemm_split_bf16), against float64 products of the same fp32 operands.  Operands spread
+    pack kernels and launcher (dt_gemm_split), in BOTH operand forms -- nt = 2: two fp16 terms of the scaled operands, three
+    products (the default since round 6); nt = 3: three bf16 terms, six products (DT_S3_H2=0, DT_PIN) -- against float64 products of the same fp32 operands.  Operands spread
     over 13 binades (heavy-tailed sums: a few terms dominate, so the accumulator rounds at the sum's own scale).  Error relative
     to sum_k |v||u| (the scale fp32 rounding is relative to): the split form must not be above the error of the fp32 library
     GEMM (torch.bmm: fp32 MFMA) on the same data -- rms and max -- and stay at the level of fp32 rounding in absolute terms
@@ -1469,7 +1471,7 @@ def test_split_bf16_gemm_benched_shapes_against_float64(ctx, P, Mt, K, N, half, 
     v = t.randn((P, Mt, K), generator=g, device=ctx.device) * t.exp2(t.randint(-6, 7, (P, Mt, K), generator=g, device=ctx.device).float())
     u = t.randn((P, N, K), generator=g, device=ctx.device) * t.exp2(t.randint(-3, 4, (P, N, K), generator=g, device=ctx.device).float()) / float(np.sqrt(K))
     ctx.profile_reset(); ctx.profile_enable(True)
-    got = ctx.gemm_split_bf16(v, u, half=half)
+    got = ctx.gemm_split(v, u, half=half, nt=nt)
     ctx.profile_enable(False)
     assert ctx.profile_read("s3_tile:128x2" if half == 1 else "s3_tile:256")["launches"] == 1
     se = sf = 0.0
@@ -1487,18 +1489,21 @@ def test_split_bf16_gemm_benched_shapes_against_float64(ctx, P, Mt, K, N, half, 
             se += float((e * e).sum()); sf += float((f * f).sum()); n += e.numel()
             me = max(me, float(e.max())); mf = max(mf, float(f.max()))
     rms_e, rms_f = float(np.sqrt(se / n)), float(np.sqrt(sf / n))
-    print("gemm_s3 P=%d Mt=%d K=%d N=%d half=%d: rms %.3g max %.3g | fp32 library GEMM rms %.3g max %.3g  (%s)" % (P, Mt, K, N, half, rms_e, me, rms_f, mf, what))
+    form = "f16x2" if nt == 2 else "bf16x3"
+    print("gemm_s3 %s P=%d Mt=%d K=%d N=%d half=%d: rms %.3g max %.3g | fp32 library GEMM rms %.3g max %.3g  (%s)" % (form, P, Mt, K, N, half, rms_e, me, rms_f, mf, what))
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    with open(os.path.join(d, "parity_r04_gemm_s3_f64.txt"), "a") as fh:
-        fh.write("P=%d Mt=%d K=%d N=%d half=%d  split-bf16: rms %.4g max %.4g   fp32 library GEMM: rms %.4g max %.4g   # %s\n" % (P, Mt, K, N, half, rms_e, me, rms_f, mf, what))
+    with open(os.path.join(d, "parity_r06_gemm_split_f64.txt"), "a") as fh:
+        fh.write("%-6s P=%d Mt=%d K=%d N=%d half=%d  split: rms %.4g max %.4g   fp32 library GEMM: rms %.4g max %.4g   # %s\n" % (form, P, Mt, K, N, half, rms_e, me, rms_f, mf, what))
     # measured (profiles/parity_r04_gemm_s3_f64.txt): split 6.5-6.8e-8 rms / 0.94-1.1e-6 max, fp32 library GEMM 8.2-8.8e-8 / 1.3-1.7e-6
     assert rms_e <= 1.02 * rms_f and me <= 1.05 * mf, (rms_e, rms_f, me, mf)      # not above an fp32 GEMM's error on the same data
     assert rms_e < 1.5 * 2.0 ** -24 and me < 32 * 2.0 ** -24, (rms_e, me)        # and at the level of fp32 rounding in absolute terms
 
 
-def test_split_bf16_gemm_one_hot_taps(ctx, monkeypatch):
+@pytest.mark.parametrize("h2", ["1", "0"], ids=["f16x2", "bf16x3"])
+def test_split_bf16_gemm_one_hot_taps(ctx, monkeypatch, h2):
     """one-hot taps on small integers: every K block / term plane / row tile / column tile of the split layout must line up."""
+    monkeypatch.setenv("DT_S3_H2", h2)
     monkeypatch.setenv("DT_WINO", "2")
     monkeypatch.setenv("DT_WINO_TILE", "6")
     monkeypatch.setenv("DT_S3", "2")
@@ -1511,49 +1516,45 @@ def test_split_bf16_gemm_one_hot_taps(ctx, monkeypatch):
     got = ctx.conv2d(dev(x, ctx), w, None, leaky_slope=1.0, pool=0).cpu().numpy()
     ctx.profile_enable(False)
     assert ctx.profile_read("conv_gemm_s3")["launches"] == 1
+    assert ctx.profile_read("s3_form:f16x2" if h2 == "1" else "s3_form:bf16x3")["launches"] == 1
     assert np.abs(got - orc.conv2d(x, w)).max() < 0.05
 
 
-def test_split_bf16_default_policy_engages_on_deep_layers(ctx, monkeypatch):
-    """Default policy (DT_S3=1): K >= 256 and >= 2048 GEMM rows take the split form, short K / few rows stay on fp32 MFMA."""
-    monkeypatch.delenv("DT_S3", raising=False)
-    rs = np.random.RandomState(11)
-    for (B, H, W, Cin, Cout), want in (((384, 13, 13, 256, 256), 1), ((8, 13, 13, 256, 256), 0), ((96, 26, 26, 128, 256), 0)):
-        x, w, b = _conv_case(rs, B, H, W, Cin, Cout)
-        ctx.profile_reset(); ctx.profile_enable(True)
-        got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=0)
-        ctx.profile_enable(False)
-        assert ctx.profile_read("conv_gemm_s3")["launches"] == want, (B, H, W, Cin, Cout)
-        ref = orc.conv2d(x[:2], w, b)
-        ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
-        assert relerr(got[:2].cpu().numpy(), ref) < 2e-4
-
-
-def test_split_bf16_handover_to_1x1_layers(ctx, monkeypatch):
-    """conv_7, 10, 12, 15, 17 (and conv_23: ragged N = 85, unaligned output rows) as split GEMMs straight on the producing layer's fp32 activation (DT_S3_1X1=1, the default: the kernel
-    splits its A fragments itself, bias as an extra K stage, LeakyReLU in its epilogue) against the same network with those layers
-    on the fp32 MFMA kernel, and against the oracle on the frames the oracle is run on."""
-    B, H, W, C = 16, 416, 416, 12
-    frames = np.random.RandomState(3).randint(0, 256, (B, H, W, 3)).astype(np.uint8)
-    outs = {}
-    layers = None
-    for mode in ("1", "0"):
-        monkeypatch.setenv("DT_S3_1X1", mode)          # read when the context is created (dt_create)
-        monkeypatch.setenv("DT_S3_1X1_MINK", "256")    # (the default)
-        monkeypatch.setenv("DT_S3_1X1_MINROWS", "0")   # (the default policy takes these layers from 16384 pixels per launch)
-        det, layers, _ = _detector(ctx, H, W, C, seed=77)
-        c = det.model.ctx
-        c.profile_reset(); c.profile_enable(True)
-        outs[mode] = c.detect_forward(dev(frames, c)).cpu().numpy()
-        c.profile_enable(False)
-        hand = sorted(int(n.split("_")[-1]) for n in c.profile_names() if n.startswith("conv_gemm_s3:conv_") and c.profile_read(n)["launches"]
-                      and int(n.split("_")[-1]) in (4, 7, 10, 12, 15, 17, 21, 23))
-        # (conv_23 joins since round 5: the row-form epilogue stores 4 bytes per lane, so the netout's 85-float rows need no alignment)
-        assert hand == ([7, 10, 12, 15, 17, 23] if mode == "1" else []), hand
-        assert c.profile_read("wino_output:conv_14")["launches"] == 1
-    assert chan_err(flat_c(outs["1"]), flat_c(outs["0"])) < 1e-4          # two roundings of the same network (measured 5e-5)
-    ref_net, _, _ = orc.yolov2_forward(orc.normalize_u8(frames[:2]), layers, taps=())
-    assert chan_err(flat_c(outs["1"][:2]), flat_c(ref_net)) < NET_TOL
+@pytest.mark.parametrize("k", [3, 1], ids=["winograd", "1x1"])
+def test_h2_scale_follows_the_data(ctx, monkeypatch, k):
+    """The fp16 form scales its operands by a power of two from the MEASURED max |x| of the input tensor: the same layer on
+    x * 2^e (e = -70 ... +70: far outside fp16's exponent range) must give exactly 2^e times the same bits (bias-free layer,
+    LeakyReLU is positively homogeneous), an all-zero input exactly the bias, and one huge element must not disturb the rest."""
+    monkeypatch.setenv("DT_S3_H2", "1")
+    monkeypatch.setenv("DT_WINO", "2")
+    monkeypatch.setenv("DT_WINO_TILE", "6")
+    monkeypatch.setenv("DT_S3", "2")
+    rs = np.random.RandomState(5)
+    B, H, W, Cin, Cout = (20, 13, 13, 128, 256) if k == 3 else (64, 13, 13, 256, 128)
+    x = rs.randn(B, H, W, Cin).astype(np.float32)
+    w = (rs.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    base = ctx.conv2d(dev(x, ctx), w, None, leaky_slope=0.1, pool=0).cpu().numpy()
+    ctx.profile_enable(False)
+    assert ctx.profile_read("s3_form:f16x2")["launches"] == 1 and ctx.profile_read("absmax")["launches"] == 1
+    ref = orc.conv2d(x[:2], w)
+    ref = np.where(ref > 0, ref, ref * np.float32(0.1))
+    assert relerr(base[:2], ref) < 1e-4
+    for e in (-70, -20, 9, 70):
+        got = ctx.conv2d(dev(np.ldexp(x, e), ctx), w, None, leaky_slope=0.1, pool=0).cpu().numpy()
+        assert np.array_equal(got, np.ldexp(base, e)), e
+    zero = ctx.conv2d(dev(np.zeros_like(x), ctx), w, b, leaky_slope=1.0, pool=0).cpu().numpy()
+    assert np.array_equal(zero, np.broadcast_to(b, zero.shape))
+    # One outlier: the tensor's power of two follows it, elements more than ~2^11 below it get a subnormal lo term (absolute precision
+    # 2^-31 of the maximum instead of relative 2^-24): full precision with an outlier of 2^10, one bit lost per binade beyond --
+    # at 2^20 the frame WITHOUT the spike is still good to 1e-3 (measured 2e-4), and the parity bars are 3e-4 / 1e-3.
+    for e, bar in ((10, 3e-5), (20, 1e-3)):
+        xs = x.copy(); xs[0, 6, 6, 3] = 2.0 ** e
+        got = ctx.conv2d(dev(xs, ctx), w, None, leaky_slope=1.0, pool=0).cpu().numpy()
+        ref = orc.conv2d(xs[:2], w)
+        assert np.abs(got[1] - ref[1]).max() < bar * np.abs(ref[1]).max(), (e, np.abs(got[1] - ref[1]).max() / np.abs(ref[1]).max())
+        assert np.abs(got[0] - ref[0]).max() < 1e-3 * np.abs(ref[0]).max()      # (F(6x6) itself cancels spike-sized numbers in that tile)
 
 
 @pytest.mark.parametrize("tile", ["", "4"], ids=["projection_F6x6", "recurrent_F4x4"])

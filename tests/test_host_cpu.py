@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(mi355_dt.LIB_PATH)
     for s in declared:
         assert hasattr(lib, s), "missing export " + s
-    assert lib.dt_abi_version() == 106
+    assert lib.dt_abi_version() == 107
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -10,6 +10,8 @@
 #include <vector>
 #include <cmath>
 #include <random>
+#include <cstring>
+#include <algorithm>
 
 int dt_fail(dt_ctx *, int rc, const char *, ...) { return rc; }
 
@@ -22,20 +24,48 @@ static void run(int P, int Mt, int K, int N, int check_rows, int iters)
     std::vector<float> V((size_t)Pc * Mt * K), U((size_t)Pc * N * K);
     for (auto &x : V) x = nd(rng) * std::exp(nd(rng));
     for (auto &x : U) x = nd(rng) * 0.05f;
-    std::vector<unsigned short> Vs((size_t)P * 3 * KB * Mp * 16, 0), Us((size_t)P * 3 * KB * Np * 16, 0);
+    // S3_NT=2: the fp16 form (two terms, scaled operands).  S3_SMALLROWS=k: every 5th row of V is 2^-k of the others (its lo terms are
+    // fp16 subnormals from k ~ 18: the probe of whether the MFMA keeps them)
+    const int NT = getenv("S3_NT") ? atoi(getenv("S3_NT")) : 3;
+    const int smallk = getenv("S3_SMALLROWS") ? atoi(getenv("S3_SMALLROWS")) : 0;
+    if (smallk)
+        for (int p = 0; p < Pc; ++p)
+            for (int m = 0; m < Mt; m += 5)
+                for (int k = 0; k < K; ++k) V[((size_t)p * Mt + m) * K + k] = std::ldexp(V[((size_t)p * Mt + m) * K + k], -smallk);
+    auto bits = [](float x) { unsigned u; memcpy(&u, &x, 4); return u & 0x7fffffffu; };
+    float vmax = 0;
+    for (auto &x : V) vmax = std::max(vmax, std::fabs(x));
+    const float vbase = dt_h2_base(bits(vmax));
+    std::vector<float> uscale(P), pscale(P);
+    for (int p = 0; p < P; ++p) {
+        float um = 0;
+        for (size_t i = 0; i < (size_t)N * K; ++i) um = std::max(um, std::fabs(U[(size_t)(p % Pc) * N * K + i]));
+        uscale[p] = dt_h2_base(bits(um));
+        pscale[p] = 1.0f / uscale[p];
+    }
+    std::vector<unsigned short> Vs((size_t)P * NT * KB * Mp * 16, 0), Us((size_t)P * NT * KB * Np * 16, 0);
     for (int p = 0; p < P; ++p)
         for (int m = 0; m < Mt; ++m)
             for (int k = 0; k < K; ++k) {
                 unsigned short t[3];
-                wino_s3_split_host(V[((size_t)(p % Pc) * Mt + m) * K + k], t);
-                for (int t3 = 0; t3 < 3; ++t3) Vs[((((size_t)p * 3 + t3) * KB + (k >> 4)) * Mp + m) * 16 + (k & 15)] = t[t3];
+                const float x = V[((size_t)(p % Pc) * Mt + m) * K + k];
+                if (NT == 2) wino_h2_split_host(x * vbase, t); else wino_s3_split_host(x, t);
+                for (int t3 = 0; t3 < NT; ++t3) Vs[((((size_t)p * NT + t3) * KB + (k >> 4)) * Mp + m) * 16 + (k & 15)] = t[t3];
             }
     {
         std::vector<float> Upad((size_t)P * Np * K, 0.0f);
         for (int p = 0; p < P; ++p)
             for (int n = 0; n < N; ++n)
                 for (int k = 0; k < K; ++k) Upad[((size_t)p * Np + n) * K + k] = U[((size_t)(p % Pc) * N + n) * K + k];
-        wino_s3_pack_weights(Upad.data(), P, Np, K, Us.data());
+        if (NT == 2) wino_h2_pack_weights(Upad.data(), P, Np, K, uscale.data(), Us.data());
+        else wino_s3_pack_weights(Upad.data(), P, Np, K, Us.data());
+    }
+    float *dPs = nullptr; unsigned *dAm = nullptr;
+    {
+        unsigned am[DT_AMAX_SUB] = {};
+        am[3] = bits(vmax);      // (any sub-slot)
+        hipMalloc(&dPs, P * 4); hipMalloc(&dAm, sizeof(am));
+        hipMemcpy(dPs, pscale.data(), P * 4, hipMemcpyHostToDevice); hipMemcpy(dAm, am, sizeof(am), hipMemcpyHostToDevice);
     }
     unsigned short *dV, *dU;
     float *dC;
@@ -46,6 +76,7 @@ static void run(int P, int Mt, int K, int N, int check_rows, int iters)
     GemmS3Args a = {};
     a.a = dV; a.b = dU; a.c = dC; a.c_ps = (long long)Mt * N; a.P = P; a.Mt = Mt; a.Mp = Mp; a.N = N; a.Np = Np; a.K = K; a.ldc = N;
     a.dbg = nullptr;
+    if (NT == 2) { a.nt = 2; a.pscale = dPs; a.amax = dAm; }
     a.waves = getenv("S3_WAVES") ? atoi(getenv("S3_WAVES")) : 0;
     a.half = getenv("S3_HALF") ? atoi(getenv("S3_HALF")) : 0;
     a.act = getenv("S3_ACT") ? 1 : 0; a.slope = 0.1f;      // timing only (the check below expects the plain product)
@@ -61,6 +92,7 @@ static void run(int P, int Mt, int K, int N, int check_rows, int iters)
     hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost);
     // check: planes 0, 1 and the last; rows spread over the tile rows
     double e_s3 = 0, e_f32 = 0, ref_rms = 0; long long cnt = 0; double worst = 0;
+    double e_small = 0; long long cnt_small = 0;
     const int planes[3] = {0, 1 % P, P - 1};
     for (int pi = 0; pi < 3; ++pi) {
         const int p = planes[pi];
@@ -72,6 +104,7 @@ static void run(int P, int Mt, int K, int N, int check_rows, int iters)
                 for (int k = 0; k < K; ++k) { ref += (double)v[k] * (double)u[k]; f = fmaf(v[k], u[k], f); mag += fabs((double)v[k] * u[k]); }
                 const double got = C[((size_t)p * Mt + m) * N + n];
                 const double d = fabs(got - ref) / mag, d32 = fabs((double)f - ref) / mag;
+                if (smallk && m % 5 == 0) { e_small += d * d; ++cnt_small; continue; }
                 e_s3 += d * d; e_f32 += d32 * d32; ref_rms += 1; ++cnt;
                 if (d > worst) worst = d;
             }
@@ -93,8 +126,10 @@ static void run(int P, int Mt, int K, int N, int check_rows, int iters)
     hipEventElapsedTime(&ms, e0, e1);
     ms /= iters;
     const double eq = 2.0 * P * (double)Mt * K * N / (ms * 1e-3) / 1e12;
-    printf("P=%d Mt=%d K=%d N=%d: %.3f ms  %.1f TF/s fp32-equivalent (%.0f executed bf16)  rel.err/|u||v|: s3 rms %.3g max %.3g, fp32 fmaf rms %.3g (%lld samples)\n",
-           P, Mt, K, N, ms, eq, eq * 6, sqrt(e_s3 / cnt), worst, sqrt(e_f32 / cnt), cnt);
+    printf("NT=%d P=%d Mt=%d K=%d N=%d: %.3f ms  %.1f TF/s fp32-equivalent (%.0f executed 16-bit)  rel.err/|u||v|: split rms %.3g max %.3g, fp32 fmaf rms %.3g (%lld samples)",
+           NT, P, Mt, K, N, ms, eq, eq * (NT == 2 ? 3 : 6), sqrt(e_s3 / cnt), worst, sqrt(e_f32 / cnt), cnt);
+    if (cnt_small) printf("  rows 2^-%d: rms %.3g (%lld)", smallk, sqrt(e_small / cnt_small), cnt_small);
+    printf("\n");
 #ifdef S3_TIMING
     {
         std::vector<unsigned long long> h(256 * 8 * 5);
@@ -106,7 +141,7 @@ static void run(int P, int Mt, int K, int N, int check_rows, int iters)
         hipFree(a.dbg);
     }
 #endif
-    hipFree(dV); hipFree(dU); hipFree(dC);
+    hipFree(dV); hipFree(dU); hipFree(dC); hipFree(dPs); hipFree(dAm);
 }
 
 int main(int argc, char **argv)
