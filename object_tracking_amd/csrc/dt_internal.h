@@ -401,7 +401,8 @@ struct dt_ctx {
     // max-|x| slots of the fp16 form (DT_AMAX_SUB words each; dt_internal.h: dt_h2_base).  Slot 0 holds 1.0 (|h_t| < 1: the ConvLSTM recurrent step);
     // slot i in 1..23: the INPUT of conv_i; 24: the tracker's z / conv_feat; 25..27: test entry points; 64..127: scratch of the weight packs
     unsigned *amax = nullptr;
-    std::map<const float *, int> amax_tag;   // tensor (device pointer) -> slot that holds its max |x| -- valid inside one API call only (amax_reset)
+    struct AmaxTag { const float *lo, *hi; int slot; };   // the tensor that occupies [lo, hi) -> the slot that holds its max |x|
+    std::vector<AmaxTag> amax_tag;           // valid inside one API call only (amax_reset), and until a layer writes into [lo, hi) (amax_forget)
     float *conv1_w = nullptr, *conv1_b = nullptr, *lut255 = nullptr;
     unsigned *conv1_w3 = nullptr, *conv1_w3u8 = nullptr;   // device: split-bf16 weight tables of conv1_s3_kernel: w and w / 255 (conv1.hip:conv1_split_tables)
     std::vector<float> conv1_hwio32, conv1_scale, conv1_shift;   // host copy of conv_1 as a Cin = 32 layer (dt_detector_extract)
@@ -433,7 +434,7 @@ struct dt_ctx {
     hipEvent_t gev_in = nullptr, gev_out = nullptr;
     std::map<std::string, hipGraphExec_t> graphs;
     std::map<std::string, int> graph_seen;
-    std::map<std::string, std::map<const float *, int>> graph_tags;   // amax_tag as a graphed sequence left it (re-applied on replay)
+    std::map<std::string, std::vector<AmaxTag>> graph_tags;   // amax_tag as a graphed sequence left it (re-applied on replay)
     int64_t graph_replays = 0, graph_captures = 0;
     // profiling
     bool prof = false;

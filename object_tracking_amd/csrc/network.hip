@@ -169,15 +169,31 @@ static unsigned *amax_slot(dt_ctx *ctx, int slot) { return ctx->amax ? ctx->amax
 // every API entry that runs layers starts here: what a previous call knew about a tensor's maximum says nothing about the bytes behind the pointer now
 static void amax_reset(dt_ctx *ctx) { ctx->amax_tag.clear(); }
 // the slot that holds max |x| of the rows x cols tensor at x: the one its producer filled (tagged), else measured here into `slot`
+// a layer is about to write `floats` floats from `lo` on: what was known about tensors in that range is void
+static void amax_forget(dt_ctx *ctx, const float *lo, long long floats)
+{
+    if (!lo || ctx->amax_tag.empty()) return;
+    const float *hi = lo + floats;
+    auto &v = ctx->amax_tag;
+    for (size_t i = v.size(); i-- > 0;)
+        if (v[i].lo < hi && lo < v[i].hi) v.erase(v.begin() + (long)i);
+}
+static void amax_note(dt_ctx *ctx, const float *lo, long long floats, int slot)
+{
+    amax_forget(ctx, lo, floats);
+    ctx->amax_tag.push_back(dt_ctx::AmaxTag{lo, lo + floats, slot});
+}
 static const unsigned *ensure_amax(dt_ctx *ctx, const float *x, long long rows, int cols, long long ld, int slot)
 {
-    auto it = ctx->amax_tag.find(x);
-    if (it != ctx->amax_tag.end()) return amax_slot(ctx, it->second);
+    for (const auto &t : ctx->amax_tag)
+        if (t.lo == x && t.hi == x + rows * ld) return amax_slot(ctx, t.slot);
     unsigned *s = amax_slot(ctx, slot);
     if (!s) { dt_fail(ctx, DT_ERR_STATE, "max-|x| slots not allocated"); return nullptr; }
     ProfScope ps(ctx, "absmax", 0.0, 4.0 * (double)rows * cols);
     if (launch_absmax(ctx->stream, x, rows, cols, ld, 1, 0, s)) { dt_fail(ctx, DT_ERR_DEVICE, "absmax launch failed"); return nullptr; }
-    ctx->amax_tag[x] = slot;
+    for (const auto &t : ctx->amax_tag)      // (a slot names ONE tensor)
+        if (t.slot == slot) { amax_forget(ctx, t.lo, t.hi - t.lo); break; }
+    amax_note(ctx, x, rows * ld, slot);
     return s;
 }
 // does this launch take the fp16 form of the split GEMM?  (DT_PIN keeps the bf16 form: see Policy::s3_h2)
@@ -770,6 +786,8 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
                     int in_slot = AMAX_TEST /* max-|x| slot of the input tensor (fp16 form); AMAX_ONE: bounded by 1, nothing to measure */)
 {
     const double cin_df = cin_alg > 0 ? cin_alg : cin;
+    if (io.out) amax_forget(ctx, io.out, (long long)B * H * W * io.out_ld);
+    if (io.out2) amax_forget(ctx, io.out2, (long long)B * H * W / 4 * io.out2_ld);
     WinoArgs w;
     memset(&w, 0, sizeof(w));
     w.B = B; w.H = H; w.W = W; w.ts = ts;
@@ -903,6 +921,11 @@ static bool s3_1x1_eligible(const dt_ctx *ctx, const ConvLayer &L, long long M)
 static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld, int B, int H, int W, float *out,
                     int out_ld, int order, int epi, float slope, float *out2 = nullptr, int out2_ld = 0)
 {
+    {   // what this layer overwrites (the pooled epilogues write a quarter of the pixels; the s2d epilogue a quarter with 4x the row)
+        const long long pix = (long long)B * H * W;
+        amax_forget(ctx, out, (epi == EPI_POOL || epi == EPI_S2D ? pix / 4 : pix) * out_ld);
+        if (out2) amax_forget(ctx, out2, pix / 4 * out2_ld);
+    }
     // (the split 1x1 form reads its A rows with 16-byte DMA pieces: a caller tensor at a 4 / 8 / 12-byte offset takes the fp32 kernel instead of failing)
     if (L.bias_s3 && ctx->s3_ones && epi == EPI_PLAIN && order == ORD_LINEAR && !out2 && in_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 3) == 0 && s3_1x1_eligible(ctx, L, (long long)B * H * W)) {
@@ -1136,6 +1159,7 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
         const double c1_exec = c1s3 ? (dtype == DT_FRAMES_U8 ? 3.0 : 6.0) * 2.0 * B * H * W * 32.0 * 32.0 : 2.0 * B * H * W * 28.0 * 32.0;
         ProfScope ps(ctx, "conv1_direct", c1_exec, c1_bytes, c1s3 ? "bf16" : "f32");
         prof_direct_form(ctx, 2.0 * B * H * W * 27.0 * 32.0, c1_bytes, DF_CONV1);
+        amax_forget(ctx, bufA, (long long)per_frame * B);
         if (launch_conv1_direct(ctx->stream, frames, dtype, B, H, W, ctx->conv1_w, ctx->conv1_b, ctx->lut255, LEAKY,
                                 bufA, c1s3 ? ctx->conv1_w3 : nullptr, c1s3 ? ctx->conv1_w3u8 : nullptr))
             return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");
