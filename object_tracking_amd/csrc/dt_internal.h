@@ -116,6 +116,8 @@ struct WinoArgs {
     int Mp;                 // rows of that layout (Mt rounded up to the GEMM's row tile)
     int nt;                 // 2: v_s3 takes TWO fp16 terms [P][2][C/16][Mp][16] of the scaled V (wino_gemm_s3.hip's fp16 form); 0 / 3: three bf16 terms
     const unsigned *amax;   // nt = 2: the max-|x| slot (DT_AMAX_SUB words) of the input tensor
+    unsigned *amax_out;     // output transform (plain epilogue, thread-per-item kernels): non-null = take max |x| over the values STORED to out2 if it is set,
+                            // else to out, into this slot (dt_amax_publish); the caller zeroes the slot
     // output transform: m [P][Mt][m_ld], N columns -> out (full resolution, may be null) / out2 (2x2 pooled, may be null)
     const float *m;
     int m_ld, N;
@@ -153,6 +155,7 @@ struct Wino4FusedArgs {
     int out2_ld;
     int nby, nbx;        // set by the launcher
     const float *zeros;  // >= 16 B of device zeros: DMA source of out-of-image patch pixels (wino4s_fused.hip)
+    unsigned *amax_out;  // wino4s_fused.hip: non-null = max |x| over the stored outputs into this slot (dt_amax_publish)
 };
 // U staged through LDS by DMA, in-register output transform, persistent over (block pair, 64-channel slice) items
 int launch_wino4s_fused(hipStream_t st, const Wino4FusedArgs &a, const float *zeros);
@@ -184,6 +187,7 @@ struct GemmS3Args {
     const unsigned *amax;      // nt = 2: the DT_AMAX_SUB-word max-|x| slot of the tensor V was made from (bits of a non-negative float): V carries
                                //         dt_h2_base(amax) (x the static per-position factor), the epilogue multiplies by dt_h2_base_inv(amax)
     const float *bias;         // nt = 2, 1x1 form: fp32 bias [N] or null, added in the epilogue (ones / bias_s3 stay null)
+    unsigned *amax_out;        // 1x1 form: non-null = max |x| over the stored outputs into this slot (dt_amax_publish)
 };
 // ---- scaling of the fp16 form's operands (wino_gemm_s3.hip header) ----------------------------------------------------------------
 // max |x| of a tensor is kept as the integer bits of a non-negative float in a slot of DT_AMAX_SUB words (producers spread their atomicMax
@@ -223,6 +227,19 @@ __device__ __forceinline__ unsigned dt_amax_read(const unsigned *slot)      // w
     }
     return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
+// A producer's contribution to the slot of the tensor it writes: every lane brings the largest |value| it STORED (fmaxf: NaNs are skipped, like
+// in absmax_kernel -- the same set of numbers gives the same word whichever kernel took the maximum); the wave's maximum goes to one of the
+// slot's sub-words, and only if it is larger than what is there already (a relaxed read first: most waves find nothing to add)
+__device__ __forceinline__ void dt_amax_publish(unsigned *slot, float am)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned b = __float_as_uint(am);
+        unsigned *s = slot + ((blockIdx.x + (threadIdx.x >> 6)) & (DT_AMAX_SUB - 1));
+        if (b > __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(s, b);
+    }
+}
 #endif
 // fp32 <-> fp16 bits on the host, round to nearest even, subnormals kept (what v_cvt_f16_f32 does under the default mode)
 unsigned short h2_f16_rne(float x);
@@ -240,8 +257,9 @@ int launch_wino_input(hipStream_t st, const WinoArgs &a);
 // U [P][npad][K] fp32 (device) -> split-bf16 [P][3][K/16][npad][16] (device)
 int launch_wino_s3_pack(hipStream_t st, const float *u, int P, int npad, int K, unsigned short *dst);
 int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates);
+bool wino_output_fills_amax(const WinoArgs &a, int gates);
 // max |x| of `planes` tensors of rows x cols floats (row stride ld, plane stride plane_stride) -> slots[planes][DT_AMAX_SUB] (zeroed here)
-int launch_absmax(hipStream_t st, const float *x, long long rows, int cols, long long ld, int planes, long long plane_stride, unsigned *slots);
+int launch_absmax(hipStream_t st, const float *x, long long rows, int cols, long long ld, int planes, long long plane_stride, unsigned *slots, bool zero = true);
 // U [P][npad][K] fp32 (device) -> two fp16 terms [P][2][K/16][npad][16] + epilogue factors pscale[P] (device); ts: Winograd tile (0: plain GEMM operand)
 int launch_wino_h2_pack(hipStream_t st, const float *u, int P, int npad, int K, int ts, unsigned *slots, unsigned short *dst, float *pscale);
 void wino_pack_weights(int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map, int cin_dst, const int *n_map,
@@ -399,9 +417,11 @@ struct dt_ctx {
     struct H2Weights { unsigned short *terms = nullptr; float *pscale = nullptr; };
     std::map<const void *, H2Weights> wino_h2;          // ... -> their fp16 form: two terms of U[p] * 2^su[p], and the epilogue factors [P]
     // max-|x| slots of the fp16 form (DT_AMAX_SUB words each; dt_internal.h: dt_h2_base).  Slot 0 holds 1.0 (|h_t| < 1: the ConvLSTM recurrent step);
-    // slot i in 1..23: the INPUT of conv_i; 24: the tracker's z / conv_feat; 25..27: test entry points; 64..127: scratch of the weight packs
+    // slot i in 1..23: the OUTPUT of conv_i, filled by the epilogue of the kernel that writes it (network.hip: amax_begin zeroes them per forward);
+    // 32 + i: the INPUT of conv_i where no producer measured it (absmax_kernel); 56: the tracker's z / conv_feat; 57, 58: test entry points;
+    // 64..127: scratch of the weight packs
     unsigned *amax = nullptr;
-    struct AmaxTag { const float *lo, *hi; int slot; };   // the tensor that occupies [lo, hi) -> the slot that holds its max |x|
+    struct AmaxTag { const float *lo, *hi; int cols, slot; };   // the tensor that occupies [lo, hi), `cols` channels per pixel -> the slot that holds its max |x|
     std::vector<AmaxTag> amax_tag;           // valid inside one API call only (amax_reset), and until a layer writes into [lo, hi) (amax_forget)
     float *conv1_w = nullptr, *conv1_b = nullptr, *lut255 = nullptr;
     unsigned *conv1_w3 = nullptr, *conv1_w3u8 = nullptr;   // device: split-bf16 weight tables of conv1_s3_kernel: w and w / 255 (conv1.hip:conv1_split_tables)

@@ -164,7 +164,7 @@ static void s3_drop(dt_ctx *ctx, const void *wino)
 
 // ---- max-|x| slots of the fp16 form (dt_internal.h: dt_ctx::amax) ------------------------------------------------------------------
 #define DT_AMAX_SLOTS 128
-enum { AMAX_ONE = 0, AMAX_TRK = 24, AMAX_TEST = 25, AMAX_PACK = 64 };
+enum { AMAX_ONE = 0, AMAX_IN = 32, AMAX_TRK = 56, AMAX_TEST = 57, AMAX_PACK = 64 };
 static unsigned *amax_slot(dt_ctx *ctx, int slot) { return ctx->amax ? ctx->amax + (size_t)slot * DT_AMAX_SUB : nullptr; }
 // every API entry that runs layers starts here: what a previous call knew about a tensor's maximum says nothing about the bytes behind the pointer now
 static void amax_reset(dt_ctx *ctx) { ctx->amax_tag.clear(); }
@@ -178,22 +178,31 @@ static void amax_forget(dt_ctx *ctx, const float *lo, long long floats)
     for (size_t i = v.size(); i-- > 0;)
         if (v[i].lo < hi && lo < v[i].hi) v.erase(v.begin() + (long)i);
 }
-static void amax_note(dt_ctx *ctx, const float *lo, long long floats, int slot)
+static void amax_note(dt_ctx *ctx, const float *lo, long long floats, int cols, int slot)
 {
     amax_forget(ctx, lo, floats);
-    ctx->amax_tag.push_back(dt_ctx::AmaxTag{lo, lo + floats, slot});
+    ctx->amax_tag.push_back(dt_ctx::AmaxTag{lo, lo + floats, cols, slot});
 }
+// the producers' slots of one detector forward start from zero (the epilogues only ever raise them)
+static int amax_begin(dt_ctx *ctx)
+{
+    if (!ctx->amax) return DT_OK;
+    HIP_TRY(ctx, hipMemsetAsync(amax_slot(ctx, 1), 0, (size_t)(AMAX_IN - 1) * DT_AMAX_SUB * sizeof(unsigned), ctx->stream));
+    return DT_OK;
+}
+// slot a layer's epilogue fills with the max |x| of what it writes: conv_1 .. conv_23 only (the test entry points run "layer 0")
+static int amax_out_slot(const ConvLayer &L) { return L.idx >= 1 && L.idx <= 23 ? L.idx : 0; }
 static const unsigned *ensure_amax(dt_ctx *ctx, const float *x, long long rows, int cols, long long ld, int slot)
 {
     for (const auto &t : ctx->amax_tag)
-        if (t.lo == x && t.hi == x + rows * ld) return amax_slot(ctx, t.slot);
+        if (t.lo == x && t.hi == x + rows * ld && t.cols == cols) return amax_slot(ctx, t.slot);
     unsigned *s = amax_slot(ctx, slot);
     if (!s) { dt_fail(ctx, DT_ERR_STATE, "max-|x| slots not allocated"); return nullptr; }
     ProfScope ps(ctx, "absmax", 0.0, 4.0 * (double)rows * cols);
     if (launch_absmax(ctx->stream, x, rows, cols, ld, 1, 0, s)) { dt_fail(ctx, DT_ERR_DEVICE, "absmax launch failed"); return nullptr; }
     for (const auto &t : ctx->amax_tag)      // (a slot names ONE tensor)
         if (t.slot == slot) { amax_forget(ctx, t.lo, t.hi - t.lo); break; }
-    amax_note(ctx, x, rows * ld, slot);
+    amax_note(ctx, x, rows * ld, cols, slot);
     return s;
 }
 // does this launch take the fp16 form of the split GEMM?  (DT_PIN keeps the bf16 form: see Policy::s3_h2)
@@ -757,6 +766,7 @@ struct WinoIO {
     const float *xproj; long long xp_bs; int xp_ld;   // gates variant (cstate != null)
     float *cstate; long long c_bs; int c_ld;
     const float *bias16;                              // border-aware bias [16][N] instead of `bias` (WinoArgs::bias16) or null
+    int amax_out_slot;                                // > 0: the output transform takes max |x| of what it stores into this slot (and the tensor is tagged with it)
 };
 
 // Tile geometry of a Winograd launch.  Mosaic factor g: g x g frames with zero separators share one virtual image
@@ -880,8 +890,14 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
         const double outb = (io.out ? (double)B * H * W * N : 0.0) + (io.out2 ? (double)B * H * W * N / 4.0 : 0.0) +
                             (io.cstate ? 3.0 * B * H * W * N / 4.0 + (double)B * H * W * N : 0.0);
         ProfScope ps(ctx, "wino_output", 0.0, 4.0 * ((double)P * mt * N + outb), tag);
+        w.amax_out = io.amax_out_slot > 0 && h2_wanted(ctx) ? amax_slot(ctx, io.amax_out_slot) : nullptr;
+        if (!wino_output_fills_amax(w, io.cstate != nullptr)) w.amax_out = nullptr;
         const int rc = launch_wino_output(ctx->stream, w, io.cstate != nullptr);
         if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: Winograd output transform launch failed", tag);
+        if (w.amax_out) {      // (the pooled tensor when there is one: its consumer is the next layer; the unpooled twin of conv_13 feeds conv_21's fp32 kernel)
+            if (io.out2) amax_note(ctx, io.out2, (long long)B * H * W / 4 * io.out2_ld, N, io.amax_out_slot);
+            else amax_note(ctx, io.out, (long long)B * H * W * io.out_ld, N, io.amax_out_slot);
+        }
     }
     return DT_OK;
 }
@@ -938,17 +954,19 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
         g.K = L.cin; g.ldc = out_ld; g.ones = ctx->s3_ones; g.bias_s3 = L.bias_s3; g.act = 1; g.slope = slope;
         if (h2) {      // the fp16 form: scaled operands (the activation's power of two from its max |x|), the bias added in the epilogue
             g.nt = 2; g.b = L.wt_h2; g.pscale = L.pscale_h2; g.bias = L.bias; g.ones = nullptr; g.bias_s3 = nullptr;
-            g.amax = ensure_amax(ctx, in, M, L.cin, in_ld, L.idx >= 1 && L.idx <= 23 ? L.idx : AMAX_TEST);
+            g.amax = ensure_amax(ctx, in, M, L.cin, in_ld, L.idx >= 1 && L.idx <= 23 ? AMAX_IN + L.idx : AMAX_TEST);
             if (!g.amax) return DT_ERR_DEVICE;
         }
         char tag[32];
         snprintf(tag, sizeof(tag), "conv_%d", L.idx);
+        if (h2_wanted(ctx) && amax_out_slot(L)) g.amax_out = amax_slot(ctx, amax_out_slot(L));
         if (ctx->prof && !ctx->capturing) ctx->prof_tab[h2 ? "s3_form:f16x2" : "s3_form:bf16x3"].launches += 1;
         // bytes = A (fp32) + U (NT 16-bit terms) + out
         ProfScope ps(ctx, "conv_gemm_s3", wino_gemm_s3_flops(g), 4.0 * M * L.cin + (h2 ? 4.0 : 6.0) * (double)L.cin * L.cout + 4.0 * (double)M * L.cout, tag);
         prof_direct_form(ctx, 2.0 * M * (double)L.cin * L.cout, 4.0 * ((double)M * L.cin + (double)L.cin * L.cout + (double)M * L.cout), DF_S3);
         const int rc = launch_wino_gemm_s3(ctx->stream, g, 0);
         if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: split-bf16 1x1 GEMM launch failed (rc=%d)", tag, rc);
+        if (g.amax_out) amax_note(ctx, out, M * out_ld, L.cout, amax_out_slot(L));
         return DT_OK;
     }
     ConvArgs a;
@@ -986,9 +1004,11 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
             if (!zeros) return DT_ERR_DEVICE;
             const bool f4b = L.fused4b && ctx->pol.f4b != 0;
             if (f4b) f.u = reinterpret_cast<const float *>(L.fused4b);
+            if (!f4b && h2_wanted(ctx) && amax_out_slot(L)) f.amax_out = amax_slot(ctx, amax_out_slot(L));
             if (ctx->prof) ctx->prof_tab[f4b ? "conv_fused_kernel:bf16_split" : "conv_fused_kernel:fp32"].launches += 1;
             const int rc = f4b ? launch_wino4b_fused(ctx->stream, f, zeros) : launch_wino4s_fused(ctx->stream, f, zeros);
             if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused F(4x4) launch failed", tag);
+            if (f.amax_out) amax_note(ctx, out, (long long)a.M / (epi == EPI_POOL ? 4 : 1) * out_ld, L.cout, amax_out_slot(L));
             return DT_OK;
         }
     }
@@ -998,6 +1018,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
         io.in = in; io.in_ld = in_ld; io.in_bs = a.in_bs;
         if (epi == EPI_POOL) { io.out2 = out; io.out2_ld = out_ld; }
         else { io.out = out; io.out_ld = out_ld; io.out_bs = a.out_bs; io.out2 = out2; io.out2_ld = out2_ld; }
+        io.amax_out_slot = amax_out_slot(L);
         // F(6x6) or F(4x4) for this launch: with many tiles F(6x6)'s fewer multiplies win; with a few frames the choice
         // is about how the positions x row tiles x column tiles spread over the CUs (small_gemm_cost)
         const float *wt = L.wino;
@@ -1008,7 +1029,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
             const long long t6 = 64ll * ((q6.Mt + 127) / 128) * ((L.cout + 127) / 128);
             if (t6 <= 4096 && small_gemm_cost(q4.Mt, L.cout, 36, nullptr) < small_gemm_cost(q6.Mt, L.cout, 64, nullptr)) { wt = L.wino_alt; ts = 4; }
         }
-        return run_wino(ctx, wt, ts, L.bias, L.cin, L.cout, L.npad, B, H, W, io, slope, tag, 0, L.idx >= 1 && L.idx <= 23 ? L.idx : AMAX_TEST);
+        return run_wino(ctx, wt, ts, L.bias, L.cin, L.cout, L.npad, B, H, W, io, slope, tag, 0, L.idx >= 1 && L.idx <= 23 ? AMAX_IN + L.idx : AMAX_TEST);
     }
     // Wave quantisation for small batches (few frames at 13x13 / 26x26): with 512 resident
     // workgroup slots (256 CUs x 2) a layer of a few hundred output tiles leaves the chip
@@ -1089,6 +1110,7 @@ static int run_trunk(dt_ctx *ctx, int B, float *bufA, float *bufB, float *skip, 
     float *cur = bufA, *nxt = bufB;
     int h = H / 2, w = W / 2;
     int rc;
+    bool cat20 = false;
     for (int li = 1; li < 20; ++li) {   // conv_2 .. conv_20
         const int idx = TRUNK[li][0], pool = TRUNK[li][4];
         const ConvLayer &L = ctx->layers[idx];
@@ -1097,6 +1119,7 @@ static int run_trunk(dt_ctx *ctx, int B, float *bufA, float *bufB, float *skip, 
             rc = run_conv(ctx, L, cur, L.cin, B, h, w, skip, 512, ORD_QUAD, EPI_POOL_BOTH, LEAKY, nxt, 512);
         } else if (idx == 20) {   // writes channels [256,1280) of the concat buffer (KerasYOLO.py:391)
             rc = run_conv(ctx, L, cur, L.cin, B, h, w, cat + 256, 1280, ORD_LINEAR, EPI_PLAIN, LEAKY);
+            for (const auto &t : ctx->amax_tag) cat20 |= t.lo == cat + 256 && t.slot == 20;      // conv_20's epilogue measured its 1024 channels into slot 20
         } else if (pool) {
             rc = run_conv(ctx, L, cur, L.cin, B, h, w, nxt, L.cout, ORD_QUAD, EPI_POOL, LEAKY);
         } else {
@@ -1121,6 +1144,12 @@ static int run_trunk(dt_ctx *ctx, int B, float *bufA, float *bufB, float *skip, 
     // conv_21 on the skip tensor + tf.space_to_depth(2) -> channels [0,256) (KerasYOLO.py:386-391)
     rc = run_conv(ctx, ctx->layers[21], skip, 512, B, H / 16, W / 16, cat, 1280, ORD_QUAD, EPI_S2D, LEAKY);
     if (rc) return rc;
+    if (cat20 && h2_wanted(ctx)) {      // ... and the 256 channels conv_21's fp32 kernel wrote are added to the same slot: the concat tensor's max |x| (conv_22 reads it)
+        const long long rows = (long long)B * (H / 32) * (W / 32);
+        ProfScope ps(ctx, "absmax", 0.0, 4.0 * (double)rows * 256, "cat_skip");
+        if (launch_absmax(ctx->stream, cat, rows, 256, 1280, 1, 0, amax_slot(ctx, 20), /*zero=*/false)) return dt_fail(ctx, DT_ERR_DEVICE, "absmax launch failed");
+        amax_note(ctx, cat, rows * 1280, 1280, 20);
+    }
     if (ex && ex->kind == EX_CAT) {
         HIP_TRY(ctx, hipMemcpyAsync(ex->out, cat, (size_t)B * (H / 32) * (W / 32) * 1280 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         ex->done = true;
@@ -1160,6 +1189,7 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
         ProfScope ps(ctx, "conv1_direct", c1_exec, c1_bytes, c1s3 ? "bf16" : "f32");
         prof_direct_form(ctx, 2.0 * B * H * W * 27.0 * 32.0, c1_bytes, DF_CONV1);
         amax_forget(ctx, bufA, (long long)per_frame * B);
+        if (int rcz = amax_begin(ctx)) return rcz;
         if (launch_conv1_direct(ctx->stream, frames, dtype, B, H, W, ctx->conv1_w, ctx->conv1_b, ctx->lut255, LEAKY,
                                 bufA, c1s3 ? ctx->conv1_w3 : nullptr, c1s3 ? ctx->conv1_w3u8 : nullptr))
             return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");
@@ -1288,6 +1318,7 @@ extern "C" int dt_detector_extract(dt_ctx *ctx, const void *d_frames, int frames
         ctx->last_batch = 0;            // the tap workspaces no longer hold a complete forward
         ctx->tap_feat = ctx->tap_netout = false;
         const bool c1s3 = ctx->pol.s3 != 0 && ctx->pol.s3_conv1 != 0;
+        if (int rcz = amax_begin(ctx)) return rcz;
         if (launch_conv1_direct(ctx->stream, d_frames, frames_dtype, B, H, W, ctx->conv1_w, ctx->conv1_b, ctx->lut255, LEAKY, bufA,
                                 c1s3 ? ctx->conv1_w3 : nullptr, c1s3 ? ctx->conv1_w3u8 : nullptr))
             return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");

@@ -336,6 +336,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
     // ---- first item: prologue.  Patch stage 0 (set b fetches block image b), U stage 0, the block-0 half of patch stage 1
     // (its block-1 half is fetched by the data-movement set of stage 0); then V(0) by set 0. ----
     int item = blockIdx.x;
+    float out_am = 0.0f;      // the largest |value| this lane stored (Wino4FusedArgs::amax_out)
     Item cur = item_of(item, true);
 #ifdef DT_S4_TIMING
     int tt_i = 0;
@@ -459,13 +460,19 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
 #pragma unroll
                             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) S4_STORE(&ob[a * rs + c * p.out_ld], m[6 * a + c][h]);
+                                for (int c = 0; c < 4; ++c) {
+                                    if (p.amax_out) out_am = fmaxf(out_am, fabsf(m[6 * a + c][h]));
+                                    S4_STORE(&ob[a * rs + c * p.out_ld], m[6 * a + c][h]);
+                                }
                         } else {
 #pragma unroll
                             for (int a = 0; a < 4; ++a)
 #pragma unroll
                                 for (int c = 0; c < 4; ++c)
-                                    if (y0 + a < p.H && x0 + 4 * e + c < p.W) S4_STORE(&ob[a * rs + c * p.out_ld], m[6 * a + c][h]);
+                                    if (y0 + a < p.H && x0 + 4 * e + c < p.W) {
+                                        if (p.amax_out) out_am = fmaxf(out_am, fabsf(m[6 * a + c][h]));
+                                        S4_STORE(&ob[a * rs + c * p.out_ld], m[6 * a + c][h]);
+                                    }
                         }
                     } else {
                         const int H2 = p.H >> 1, W2 = p.W >> 1;
@@ -482,13 +489,19 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
 #pragma unroll
                             for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-                                for (int c2 = 0; c2 < 2; ++c2) S4_STORE(&ob[a2 * rs + c2 * p.out2_ld], mx[a2][c2]);
+                                for (int c2 = 0; c2 < 2; ++c2) {
+                                    if (p.amax_out) out_am = fmaxf(out_am, fabsf(mx[a2][c2]));
+                                    S4_STORE(&ob[a2 * rs + c2 * p.out2_ld], mx[a2][c2]);
+                                }
                         } else {
 #pragma unroll
                             for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
                                 for (int c2 = 0; c2 < 2; ++c2)
-                                    if ((y0 >> 1) + a2 < H2 && (x0 >> 1) + 2 * e + c2 < W2) S4_STORE(&ob[a2 * rs + c2 * p.out2_ld], mx[a2][c2]);
+                                    if ((y0 >> 1) + a2 < H2 && (x0 >> 1) + 2 * e + c2 < W2) {
+                                        if (p.amax_out) out_am = fmaxf(out_am, fabsf(mx[a2][c2]));
+                                        S4_STORE(&ob[a2 * rs + c2 * p.out2_ld], mx[a2][c2]);
+                                    }
                         }
                     }
                 }
@@ -503,6 +516,7 @@ __global__ __launch_bounds__(S4_THREADS) void wino4s_fused_kernel(Wino4FusedArgs
         item = nxt;
         cur = nx;
     }
+    if (p.amax_out) dt_amax_publish(p.amax_out, out_am);      // (max |x| of the stored outputs: the fp16 form of the next layer's GEMM scales by it)
 }
 
 int launch_wino4s_fused(hipStream_t st, const Wino4FusedArgs &a_in, const float *zeros)

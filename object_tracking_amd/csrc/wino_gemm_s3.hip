@@ -152,6 +152,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
     // fp16 form: the power of two this launch's V was scaled by (1x1 form: applied HERE, to the fp32 fragments) and its inverse for the
     // epilogue; behind the stage ring: [64] per-position epilogue factors | [Np] bias of a 1x1 layer (read per lane in the epilogue --
     // LDS reads wait on lgkmcnt, a global load there would wait for the next tile's DMA in flight)
+    [[maybe_unused]] float out_am = 0.0f;      // 1x1 form: the largest |value| this lane stored (GemmS3Args::amax_out)
     [[maybe_unused]] float h2_fwd = 1.0f, h2_inv = 1.0f;
     [[maybe_unused]] float *h2_tab = reinterpret_cast<float *>(s3_lds + NS * STAGE);
     if constexpr (NT == 2) {
@@ -520,7 +521,10 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
                     float *row = cz + (long long)m * p.ldc;
 #pragma unroll
                     for (int j = 0; j < NBW; ++j)
-                        if (!ACT || 32 * j < ncol) __builtin_nontemporal_store(acc[j][i][r], row + 32 * j);
+                        if (!ACT || 32 * j < ncol) {
+                            if (ACT && p.amax_out) out_am = fmaxf(out_am, fabsf(acc[j][i][r]));
+                            __builtin_nontemporal_store(acc[j][i][r], row + 32 * j);
+                        }
                 }
             }
         }
@@ -558,6 +562,7 @@ __device__ __forceinline__ void s3_body(const GemmS3Args &p)
         drain = true;
         cur = tile_of(Lcur);
     }
+    if (ACT && p.amax_out) dt_amax_publish(p.amax_out, out_am);
 }
 
 #ifndef S3_H2_NS

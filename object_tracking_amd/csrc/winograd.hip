@@ -351,6 +351,8 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
     const int nq = p.N / V;
     const long long items = (long long)p.Mt * nq;
     const long long plane = (long long)p.Mt * p.m_ld;
+    float am = 0.0f;      // largest |value| this thread stored (WinoArgs::amax_out)
+    const bool am_full = p.amax_out && !p.out2, am_pool = p.amax_out && p.out2;
     for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items;
          it += (long long)gridDim.x * blockDim.x) {
         const int tile = (int)(it / nq);
@@ -380,6 +382,10 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
                             const int k = wino_border_case(p, h, w);
                             if (k) v = v + vload<V>(p.bias16 + (long long)k * p.N + c);
                         }
+                        if (am_full) {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) am = fmaxf(am, fabsf(lane_of<V>(v, e)));
+                        }
                         vstore_nt<V>(p.out + (long long)b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c, v);
                     }
                 }
@@ -397,11 +403,16 @@ template <int TS, int V> __global__ __launch_bounds__(WINO_THREADS) void wino_ou
                         for (int e = 0; e < V; ++e)
                             set_lane<V>(mx, e, fmaxf(fmaxf(lane_of<V>(m[2 * i][2 * j], e), lane_of<V>(m[2 * i][2 * j + 1], e)),
                                                      fmaxf(lane_of<V>(m[2 * i + 1][2 * j], e), lane_of<V>(m[2 * i + 1][2 * j + 1], e))));
+                        if (am_pool) {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) am = fmaxf(am, fabsf(lane_of<V>(mx, e)));
+                        }
                         vstore<V>(p.out2 + ((long long)(t.grp * H2 + h2) * W2 + w2) * p.out2_ld + c, mx);
                     }
                 }
         }
     }
+    if (p.amax_out) dt_amax_publish(p.amax_out, am);
 }
 
 // ---- output transform, ConvLSTM2D gate update ------------------------------------------------------
@@ -807,35 +818,24 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *x, long long r
     const float *xz = x + (long long)blockIdx.y * plane;
     const int cq = cols >> 2;
     const long long items = rows * cq;
-    unsigned m = 0;
+    float m = 0.0f;      // (fmaxf skips NaNs: the producers' epilogues take their maxima the same way, dt_amax_publish)
     for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long long)gridDim.x * blockDim.x) {
         const long long r = it / cq;
         const int c = (int)(it - r * cq) * 4;
         const VecOf<4>::T v = __builtin_nontemporal_load(reinterpret_cast<const VecOf<4>::T *>(xz + r * ld + c));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned b = __float_as_uint(v[e]) & 0x7fffffffu;
-            m = b > m ? b : m;
-        }
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[e]));
     }
     if ((cols & 3) && blockIdx.x == 0)      // ragged tail columns (caller tensors)
         for (long long r = threadIdx.x; r < rows; r += blockDim.x)
-            for (int c = cq * 4; c < cols; ++c) {
-                const unsigned b = __float_as_uint(xz[r * ld + c]) & 0x7fffffffu;
-                m = b > m ? b : m;
-            }
-#pragma unroll
-    for (int o = 32; o; o >>= 1) {
-        const unsigned w = (unsigned)__shfl_xor((int)m, o);
-        m = w > m ? w : m;
-    }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(slots + (long long)blockIdx.y * DT_AMAX_SUB + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (DT_AMAX_SUB - 1)), m);
+            for (int c = cq * 4; c < cols; ++c) m = fmaxf(m, fabsf(xz[r * ld + c]));
+    dt_amax_publish(slots + (long long)blockIdx.y * DT_AMAX_SUB, m);
 }
-int launch_absmax(hipStream_t st, const float *x, long long rows, int cols, long long ld, int planes, long long plane_stride, unsigned *slots)
+int launch_absmax(hipStream_t st, const float *x, long long rows, int cols, long long ld, int planes, long long plane_stride, unsigned *slots, bool zero)
 {
     if (!x || !slots || rows <= 0 || cols <= 0 || planes <= 0 || planes > 65535) return 2;
     if (cols >= 4 && ((ld & 3) || (plane_stride & 3) || (reinterpret_cast<uintptr_t>(x) & 15))) return 2;
-    if (hipMemsetAsync(slots, 0, (size_t)planes * DT_AMAX_SUB * sizeof(unsigned), st) != hipSuccess) return 1;
+    if (zero && hipMemsetAsync(slots, 0, (size_t)planes * DT_AMAX_SUB * sizeof(unsigned), st) != hipSuccess) return 1;
     const long long items = rows * (cols >= 4 ? cols >> 2 : 1);
     long long nb = (items + 255) / 256 / 8;      // ~8 items (128 bytes) per thread
     nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
@@ -938,6 +938,12 @@ int launch_wino_input(hipStream_t st, const WinoArgs &a)
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// does launch_wino_output's kernel for these arguments fill WinoArgs::amax_out?  (the thread-per-item plain epilogues do)
+bool wino_output_fills_amax(const WinoArgs &a, int gates)
+{
+    if (gates || !a.amax_out) return false;
+    return !(a.ts == 6 && wino_coop_wanted(a, (long long)a.Mt * (a.N / 2)));
+}
 int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates)
 {
     if (a.m_ld % 4 || a.Mt <= 0 || (a.ts != 2 && a.ts != 4 && a.ts != 6) || a.g < 1 || (a.out2 && a.g != 1)) return 2;
