@@ -111,10 +111,17 @@ def cpu_baseline_track(blob, tw, H, W, n_frames):
     frames = orc.normalize_u8(synth.synth_clip(n_frames, H, W, 32, seed=999))
     ncpu = os.cpu_count() or 1
     try:
-        naff = len(os.sched_getaffinity(0))              # the cores this process may run on (cgroup / taskset), not the host's count
+        aff0 = set(os.sched_getaffinity(0))              # the cores this process may run on (cgroup / taskset), not the host's count
     except (AttributeError, OSError):
-        naff = ncpu
-    cand = sorted({n for n in (naff, naff // 2, 128, 64, 32, 16, 8) if 1 <= n <= naff} or {1}, reverse=True)
+        aff0 = set(range(ncpu))
+    # ONE NUMA node: frame-at-a-time convolutions spread over two sockets got SLOWER beyond 16-32 threads in round 5 (remote memory, no
+    # binding).  Every thread of this process is bound to the cores of the node with the most usable cores for the CPU leg and released after.
+    node_cpus, bound = _numa_node_cpus(aff0), None
+    if node_cpus and len(node_cpus) < len(aff0):
+        bound = _bind_all_threads(node_cpus)
+    naff = len(node_cpus) if bound is not None else len(aff0)
+    nphys = _physical_cores(node_cpus if bound is not None else aff0)
+    cand = sorted({n for n in (naff, nphys, nphys // 2, naff // 2, 64, 32, 16, 8) if 1 <= n <= naff} or {1}, reverse=True)
     sample = frames[:min(8, n_frames)]
     sweeps = {}
 
@@ -136,9 +143,18 @@ def cpu_baseline_track(blob, tw, H, W, n_frames):
 
     out = {}
     default_torch = torch.get_num_threads()
+    def torch_variant(cl):
+        def with_layout(f):
+            def g(*a):
+                torch_cpu.CHANNELS_LAST = cl
+                return f(*a)
+            return g
+        return with_layout(torch_cpu.tracker_forward), with_layout(torch_cpu.yolov2_forward)
+
     for name, fwd, det_fwd, set_threads in (
             ("oracle_c_openmp", orc.tracker_forward, orc.yolov2_forward, orc.set_threads),
-            ("torch_cpu_onednn", torch_cpu.tracker_forward, torch_cpu.yolov2_forward, torch.set_num_threads)):
+            ("torch_cpu_onednn_nhwc",) + torch_variant(True) + (torch.set_num_threads,),
+            ("torch_cpu_onednn_nchw",) + torch_variant(False) + (torch.set_num_threads,)):
         nt = sweep(name, set_threads, det_fwd)
         t0 = time.perf_counter()
         trk, _ = fwd(frames, layers, tw)
@@ -153,9 +169,58 @@ def cpu_baseline_track(blob, tw, H, W, n_frames):
         dt = time.perf_counter() - t0
         out[name] = (n_frames / dt, dt, nt)
     torch.set_num_threads(default_torch)
-    orc.set_threads(naff)
-    out["_host"] = {"host_logical_cores": ncpu, "affinity_cores": naff, "detector_frames_per_s_by_threads": sweeps}
+    orc.set_threads(len(aff0))
+    if bound is not None:
+        _bind_all_threads(aff0)
+    out["_host"] = {"host_logical_cores": ncpu, "affinity_cores": len(aff0), "numa_node_cores_bound": naff if bound is not None else None,
+                    "physical_cores_in_binding": nphys, "detector_frames_per_s_by_threads": sweeps}
     return out
+
+
+def _parse_cpulist(txt):
+    cpus = set()
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _numa_node_cpus(allowed):
+    """usable cpus of the NUMA node that has the most of them (None if the host does not say)"""
+    import glob
+    best = None
+    for d in glob.glob("/sys/devices/system/node/node[0-9]*"):
+        try:
+            cpus = _parse_cpulist(open(os.path.join(d, "cpulist")).read()) & set(allowed)
+        except (OSError, ValueError):
+            continue
+        if cpus and (best is None or len(cpus) > len(best)):
+            best = cpus
+    return best
+
+
+def _physical_cores(cpus):
+    seen = set()
+    for c in cpus:
+        try:
+            seen.add(min(_parse_cpulist(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read())))
+        except (OSError, ValueError):
+            seen.add(c)
+    return max(1, len(seen))
+
+
+def _bind_all_threads(cpus):
+    """affinity of every thread this process has (OpenMP / ATen pools keep the mask they were created with otherwise)"""
+    n = 0
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            os.sched_setaffinity(int(tid), cpus)
+            n += 1
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def detect_batch8_extra(device, H, W, seed0):
@@ -195,7 +260,7 @@ def _time_steps(step, warmup, steps):
     return (time.perf_counter() - t0) / steps
 
 
-def track_extra(device, size, clips, T, boxes, steps=3, env=None, what=None, graphs=False):
+def track_extra(device, size, clips, T, boxes, steps=3, env=None, what=None, graphs=False, want_det=False):
     """BASELINE.json configs[4]'s single-GPU shard under the same clock: MultiObjDetTracker at size x size with
     ~`boxes` candidate boxes per frame, `clips` clips x T frames per step, its own context.  `env`: policy knobs the
     context is created under (read once in dt_create), e.g. {"DT_S3": "0"} = every GEMM on the fp32 MFMA instruction."""
@@ -216,35 +281,16 @@ def track_extra(device, size, clips, T, boxes, steps=3, env=None, what=None, gra
         trk.model.ctx.graph_enable(True)      # captured on the second warm-up call, replayed afterwards
 
     def step():
-        res["r"] = trk.track_clips(frames, cap=cap)
+        if want_det:
+            grids = trk.model.forward(frames, want_det=True)
+            res["r"] = trk.decode_and_associate(grids[0] if isinstance(grids, (tuple, list)) else grids, cap=cap)
+        else:
+            res["r"] = trk.track_clips(frames, cap=cap)
     sec = _time_steps(step, 3 if graphs else 2, steps)
     return {"workload": what or "BASELINE.json configs[4] on one GPU: MultiObjDetTracker %dx%d, %d clips x %d frames per step, "
                                 "head calibrated to %d candidate boxes per frame" % (size, size, clips, T, boxes),
             "ms_per_step": 1e3 * sec, "frames_per_s": clips * T / sec,
             "boxes_per_frame": float(res["r"]["counts"].float().mean().item())}
-
-
-def two_partitions_extra(device, size, clips, T, boxes, steps=5):
-    """The headline step twice over, concurrently: two trackers (two contexts), `clips` clips each, on two streams masked to
-    complementary halves of the CUs (parallel.cu_partition_streams / track_clips_partitions).  One partition's launch gaps and kernel
-    tails are the other's working time; measured +3-4 % frames per second against one stream (profiles/r04_dual_partition.txt).
-    Reported beside the headline number, not as it: with two concurrent partitions the per-kernel event times sum to twice the step
-    and every launch runs at half the chip's rate, which is not what the roofline block describes."""
-    from object_tracking_amd import parallel
-    try:
-        streams = parallel.cu_partition_streams(device, 2)
-        frames = [make_frames(clips, T, size, size, device, seed0=7100 + 50 * i) for i in range(2)]
-        trks = [build_tracker(size, size, T, boxes, f)[0] for f in frames]
-        cap = max(128, 2 * boxes)
-        torch.cuda.synchronize()
-        sec = _time_steps(lambda: parallel.track_clips_partitions(trks, frames, streams, cap=cap, join=False), 2, steps)      # _time_steps synchronises the device around the timed steps
-        sec_join = _time_steps(lambda: parallel.track_clips_partitions(trks, frames, streams, cap=cap), 1, steps)
-        return {"workload": "2 x (%d clips x %d frames) per step: the headline workload in two half-chip partitions (CU-masked streams, one context each), "
-                            "batch after batch without a barrier between the partitions" % (clips, T),
-                "ms_per_step": 1e3 * sec, "frames_per_s": 2 * clips * T / sec,
-                "with_a_barrier_per_step": {"ms_per_step": 1e3 * sec_join, "frames_per_s": 2 * clips * T / sec_join}}
-    except Exception as e:      # an experiment: never in the way of the line
-        return {"error": repr(e)}
 
 
 def tiny_extra(device, H, W, seqs, steps=3):
@@ -512,9 +558,16 @@ def _run():
             d["traffic_bytes_per_launch"] = fam_traffic[tkey] / (prof["launches"] / steps)
         return d
 
+    # which operand form the split GEMMs ran in (the library counts its launches per form): fp16 x 2 terms / three products (default since
+    # round 6) or bf16 x 3 terms / six products (DT_S3_H2=0, DT_PIN)
+    n_h2, n_b3 = ctx.profile_read("s3_form:f16x2")["launches"], ctx.profile_read("s3_form:bf16x3")["launches"]
+    s3_h2 = n_h2 > 0 and n_b3 == 0
+    s3_products = 3.0 if s3_h2 else 6.0
     families = {
         "wino_gemm_s3": family("conv_gemm_s3", s3, "wino_gemm_s3_kernel / wino_gemm_s3_half_kernel (F(6x6) / F(4x4) batched GEMMs, 1x1 layers behind them)",
-                               "v_mfma_f32_32x32x16_bf16 on 3-term split fp32 operands, six per fp32 multiply-add, fp32 accumulate",
+                               ("v_mfma_f32_32x32x16_f16 on 2-term split fp32 operands scaled into fp16's range (hi + lo, 22+ bits), three per fp32 "
+                                "multiply-add, fp32 accumulate" if s3_h2 else
+                                "v_mfma_f32_32x32x16_bf16 on 3-term split fp32 operands, six per fp32 multiply-add, fp32 accumulate"),
                                PEAK_BF16_MFMA_TFLOPS, "wino_gemm_s3"),
         "conv_igemm_f32": family("conv_igemm", ig, "conv_igemm_f32 (implicit GEMM: the 1x1 layers with fewer than 128 output channels -- conv_4, conv_21, conv_23, tconv_2)",
                                  "v_mfma_f32_32x32x2_f32", PEAK_F32_MFMA_TFLOPS, "conv_igemm_f32"),
@@ -526,8 +579,10 @@ def _run():
                              else "v_mfma_f32_32x32x2_f32", PEAK_BF16_MFMA_TFLOPS if conv1_bf16 else PEAK_F32_MFMA_TFLOPS, "conv1_mfma"),
     }
     if families["wino_gemm_s3"]:
-        families["wino_gemm_s3"]["fp32_equivalent_tflops"] = families["wino_gemm_s3"]["achieved"] / 6.0
-        families["wino_gemm_s3"]["fp32_equivalent_over_fp32_mfma_peak"] = families["wino_gemm_s3"]["achieved"] / 6.0 / PEAK_F32_MFMA_TFLOPS
+        families["wino_gemm_s3"]["operand_form"] = "f16x2" if s3_h2 else ("bf16x3" if n_h2 == 0 else "mixed")
+        families["wino_gemm_s3"]["mfma_products_per_multiply"] = s3_products
+        families["wino_gemm_s3"]["fp32_equivalent_tflops"] = families["wino_gemm_s3"]["achieved"] / s3_products
+        families["wino_gemm_s3"]["fp32_equivalent_over_fp32_mfma_peak"] = families["wino_gemm_s3"]["achieved"] / s3_products / PEAK_F32_MFMA_TFLOPS
     transforms = None if wino_ms <= 0 else {
         "kernel": "wino_input_* / wino_output_* (Winograd transforms around the batched GEMMs)", "bound": "hbm", "peak_GBps": PEAK_HBM_GBS,
         "launches_per_step": (wino_in["launches"] + wino_out["launches"]) / steps, "ms_per_step": wino_ms / steps,
@@ -616,13 +671,24 @@ def _run():
                        "note": "kernels / roofline come from the separate instrumented pass (a HIP event pair around each of ~280 launches per step)"},
             "scaling": "strong" if (args.workload == "tiny" or (args.workload == "track" and args.shard == "frame" and world > 1)) else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_detail": ("fp32 storage, fp32 accumulation everywhere; the F(6x6,3x3) layers' GEMMs form each fp32 product from six bf16 MFMA "
-                             "partial products of 3-term split operands (x = x1 + x2 + x3, exact to 2^-25 |x|): error against float64 no "
-                             "larger than the fp32 MFMA path's (DT_S3=0), which the parity tests assert") if s3["ms"] > 0 else
+            "dtype_detail": (("fp32 storage, fp32 accumulation everywhere; the Winograd-form and 1x1 layers' GEMMs form each fp32 product from THREE fp16 MFMA "
+                              "partial products (lo*hi + hi*lo + hi*hi) of 2-term split operands: x * 2^s = hi + lo with hi = fp16(x 2^s), lo = fp16(x 2^s - hi), "
+                              "|x 2^s - hi - lo| <= 2^-23 |x 2^s| and zero for three elements in four; s per tensor from its MEASURED max |x| (taken by the "
+                              "producing kernel's epilogue), per Winograd position for the weights; accumulators scaled back by the exact inverse power of two.  "
+                              "Error against float64 at every benched GEMM shape: rms 5.5e-8 / max 1.0e-6 of sum |u||v| -- below the six-product bf16 form "
+                              "(6.8e-8 / 1.1e-6) and the fp32 library GEMM (8.7e-8 / 1.6e-6) on the same data, asserted in pytest -m gpu "
+                              "(test_split_bf16_gemm_benched_shapes_against_float64; profiles/parity_r06_gemm_split_f64.txt).  extra.track_bf16x3 / "
+                              "extra.track_fp32_mfma_only: the same step in the round-5 form and on the fp32 MFMA instruction only") if s3_h2 else
+                             ("fp32 storage, fp32 accumulation everywhere; the F(6x6,3x3) layers' GEMMs form each fp32 product from six bf16 MFMA "
+                              "partial products of 3-term split operands (x = x1 + x2 + x3, exact to 2^-25 |x|): error against float64 no "
+                              "larger than the fp32 MFMA path's (DT_S3=0), which the parity tests assert")) if s3["ms"] > 0 else
                             "fp32 storage, fp32 MFMA arithmetic, fp32 accumulation",
             "config": {"workload": ("BASELINE.json configs[2]: MultiObjDetTracker (YOLOv2 C=12 + ConvLSTM2D(512) + 1x1 "
                                     "+ decode/NMS + track ids), %d clips x %d frames per GPU per step, %dx%d uint8; the synthetic head is calibrated "
-                                    "to %d CANDIDATE boxes per frame, of which about 20 survive NMS (config.boxes_per_frame: measured)"
+                                    "to %d CANDIDATE boxes per frame, of which about 20 survive NMS (config.boxes_per_frame: measured).  The step computes the model's "
+                                    "TRACKING output, the one MultiObjDetTracker.predict reads (MultiObjDetTracker.py:307: output[0]); conv_23 is folded into the "
+                                    "ConvLSTM input projection's weights and the detection grid (output[1]) is not materialised -- "
+                                    "extra.track_with_detection_output times the step that writes both"
                                     % (args.clips, args.T, H, W, args.boxes)) if args.workload == "track" else
                        ("BASELINE.json configs[1]: YOLOv2 C=80 forward + decode/NMS, batch %d, %dx%d uint8"
                         % (args.batch, H, W)) if args.workload == "detect" else
@@ -652,7 +718,7 @@ def _run():
                 "frac_whole_conv_path": conv_path_pipe_frac,
                 "whole_conv_path": {"executed_fp32_mfma_tflop_per_step": conv_path_flops / steps / 1e12,
                                     "executed_bf16_mfma_tflop_per_step": conv_path_bf16 / steps / 1e12,
-                                    "fp32_equivalent_tflops": ((conv_path_flops + s3["flops"] / 6.0 + (conv1["flops"] / 3.0 if conv1_bf16 else 0.0)) / (conv_path_ms * 1e-3) / 1e12)
+                                    "fp32_equivalent_tflops": ((conv_path_flops + s3["flops"] / s3_products + (conv1["flops"] / 3.0 if conv1_bf16 else 0.0)) / (conv_path_ms * 1e-3) / 1e12)
                                     if conv_path_ms > 0 else None,
                                     "ms_per_step": conv_path_ms / steps,
                                     "direct_form_tflop_per_step": direct_form_all / steps / 1e12,
@@ -664,13 +730,13 @@ def _run():
                         "(families.*): executed = FLOPs on the matrix pipe; algorithmic = SURVEY.md 8d direct-form FLOPs (2MKN of the "
                         "reference's layer) of the layers THAT family's launches computed -- the 3x3 layers run in Winograd form "
                         "(F(6x6,3x3): 1.78 multiplies per output instead of 9; fused F(4x4,3x3): 2.25), so achieved_algorithmic exceeds "
-                        "achieved; wino_gemm_s3 carries every fp32 operand as three bf16 terms and forms each product from six bf16 "
+                        "achieved; wino_gemm_s3 carries every fp32 operand as two fp16 terms of the scaled operand (three bf16 terms under DT_S3_H2=0) and forms each product from three (six) 16-bit "
                         "MFMA partial products with fp32 accumulation (fp32 accuracy, tests/test_gpu_parity.py::"
-                        "test_split_bf16_gemm_benched_shapes_against_float64): fp32_equivalent_tflops = executed / 6. "
+                        "test_split_bf16_gemm_benched_shapes_against_float64): fp32_equivalent_tflops = executed / mfma_products_per_multiply. "
                         "implementation_* = bytes the kernels move by their own count (V + U + M' for the GEMMs); traffic_* = PMC "
                         "measurement (profiles/). transforms = the HBM-bound Winograd transform kernels around the GEMMs. "
                         "frac_whole_conv_path = time the matrix pipe needs at its peaks for everything the conv path executes "
-                        "(bf16 FLOPs / 2500 + fp32 FLOPs / 157.3) / the conv path's time incl. transforms."},
+                        "(16-bit FLOPs / 2500 + fp32 FLOPs / 157.3) / the conv path's time incl. transforms."},
             "kernels": kern,
         }
         if world == 1 and not args.no_extra and args.workload == "track":
@@ -686,13 +752,22 @@ def _run():
                                                  what="the headline workload (BASELINE.json configs[2], %d clips x %d frames) %s" % (
                                                      args.clips, args.T, "with plain launches instead of hipGraph replay" if args.graphs else
                                                      "with dt_graph_enable: the detector trunk and the ConvLSTM recurrence replayed as hipGraphs"))),
-                            ("track_two_partitions", lambda: two_partitions_extra(device, H, args.clips, args.T, args.boxes, steps=args.steps)),
                             # the headline workload with the split-bf16 GEMMs switched off (DT_S3=0: v_mfma_f32_32x32x2_f32
                             # everywhere), same run, same clock: what the bf16-pipe arithmetic buys
                             ("track_fp32_mfma_only", lambda: track_extra(
                                 device, args.size, args.clips, args.T, args.boxes, env={"DT_S3": "0"},
                                 what="the headline workload (BASELINE.json configs[2], %d clips x %d frames) with DT_S3=0: every GEMM on "
-                                     "the fp32 MFMA instruction" % (args.clips, args.T)))):
+                                     "the fp32 MFMA instruction" % (args.clips, args.T))),
+                            # ... in round 5's operand form: three bf16 terms, six MFMA products per multiply
+                            ("track_bf16x3", lambda: track_extra(
+                                device, args.size, args.clips, args.T, args.boxes, env={"DT_S3_H2": "0"}, steps=args.steps, graphs=args.graphs,
+                                what="the headline workload (BASELINE.json configs[2], %d clips x %d frames) with DT_S3_H2=0: the split GEMMs in the "
+                                     "three-term bf16 form (six products per multiply), same run" % (args.clips, args.T))),
+                            # ... writing BOTH outputs of the reference's model (tracking and detection grids: conv_23 launched, two-output forward)
+                            ("track_with_detection_output", lambda: track_extra(
+                                device, args.size, args.clips, args.T, args.boxes, steps=args.steps, graphs=args.graphs, want_det=True,
+                                what="the headline workload (BASELINE.json configs[2], %d clips x %d frames) computing the model's detection output "
+                                     "too (model.forward(want_det=True): conv_23 is launched and its grid written next to the tracking grid)" % (args.clips, args.T)))):
                 out["extra"][key] = fn()
                 gc.collect()                      # each extra owns a context with its own workspaces: release them
                 torch.cuda.empty_cache()
@@ -703,13 +778,19 @@ def _run():
             host = variants.pop("_host")
             best = max(variants, key=lambda k: variants[k][0])
             out["cpu_baseline"] = {"value": variants[best][0], "unit": "frames/s", "cores": variants[best][2], "kind": "port",
+                                   "gflops": variants[best][0] * gflop_per_frame, "gflops_per_thread": variants[best][0] * gflop_per_frame / max(1, variants[best][2]),
+                                   "numa_node_cores_bound": host["numa_node_cores_bound"], "physical_cores_in_binding": host["physical_cores_in_binding"],
+                                   "limit": ("threads: the sweep's fastest count is the largest tried" if variants[best][2] >= max(host["detector_frames_per_s_by_threads"][best])
+                                             else "not threads: %d threads beat every larger count of the sweep -- memory / synchronisation of the frame-sized "
+                                                  "convolutions (the 13x13 layers have 169 pixels per frame to share)" % variants[best][2]),
                                    "variant": best, "host_logical_cores": host["host_logical_cores"], "affinity_cores": host["affinity_cores"],
                                    "thread_sweep_detector_frames_per_s": host["detector_frames_per_s_by_threads"],
                                    "variants": {k: {"frames_per_s": v[0], "seconds": v[1], "threads": v[2]} for k, v in variants.items()},
-                                   "sample": "CPU restatement of the graph (NOT Keras/TF, which cannot run here), the faster of "
-                                             "oracle/oracle.c (C + OpenMP) and oracle/torch_cpu.py (ATen/oneDNN): 1 clip x %d "
+                                   "sample": "CPU restatement of the graph (NOT Keras/TF, which cannot run here), the fastest of "
+                                             "oracle/oracle.c (C + OpenMP) and oracle/torch_cpu.py (ATen/oneDNN, NHWC and NCHW tensors; the clip's "
+                                             "frames go through every layer as ONE batch): 1 clip x %d "
                                              "frames %dx%d through detector+ConvLSTM+1x1+decode+association after a warm-up and "
-                                             "a thread-count sweep without early exit over the cores this process may use "
+                                             "a thread-count sweep without early exit, every thread bound to the cores of one NUMA node "
                                              "(cores = threads of the reported variant), %.1f s"
                                              % (args.cpu_frames, H, W, variants[best][1])}
     else:

@@ -48,7 +48,7 @@ DT_API int dt_create(dt_ctx **out);
 DT_API void dt_destroy(dt_ctx *ctx);
 DT_API const char *dt_last_error(dt_ctx *ctx);
 DT_API int dt_set_stream(dt_ctx *ctx, void *hip_stream);
-/* ABI version of this header: major*100+minor (1.07: 1.06 + dt_gemm_split) */
+/* ABI version of this header: major*100+minor (1.07: 1.06 + dt_gemm_split, dt_policy_set) */
 DT_API int dt_abi_version(void);
 
 /* ---- detector: KerasYOLO ---------------------------------------------- */
@@ -295,6 +295,9 @@ DT_API int dt_gemm_split(dt_ctx *ctx, const float *d_v, const float *d_u, int P,
  * The DT_* environment variables of DESIGN.md's appendix are read ONCE, in dt_create (no launch path calls
  * getenv); this re-reads them into a live context.  dt_conv2d / dt_convlstm_step do the same on entry. */
 DT_API int dt_policy_reload(dt_ctx *ctx);
+/* One knob of ONE context without touching the process environment: name "pin", value 1 / 0 = DT_PIN for this context only
+ * (kernel selection independent of the batch a call carries; object_tracking_amd/parallel.py: deterministic=True). */
+DT_API int dt_policy_set(dt_ctx *ctx, const char *name, int value);
 
 /* ---- profiling --------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by HIP events on the ctx

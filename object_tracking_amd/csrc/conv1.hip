@@ -425,7 +425,7 @@ int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, in
     while (tpw > 1 && rows * ((ntx + tpw - 1) / tpw) < 2048) tpw = (tpw + 1) / 2;
     a.tpw = tpw;
     const dim3 grid((unsigned)((ntx + tpw - 1) / tpw), (unsigned)((H2 + 7) / 8), (unsigned)B);
-    if (w3 && w3u8 && (dtype != DT_FRAMES_U8 || (W % 4 == 0 && (reinterpret_cast<uintptr_t>(frames) & 3) == 0))) {      // uint8: aligned dword loads -- a view at an odd byte offset takes the fp32 MFMA kernel      // split-bf16 form (Policy::s3_conv1); uint8: the kernel reads aligned dwords of the rows
+    if (w3 && w3u8 && (dtype != DT_FRAMES_U8 || (W % 4 == 0 && (reinterpret_cast<uintptr_t>(frames) & 3) == 0))) {      // split-bf16 form (Policy::s3_conv1); uint8: the kernel reads aligned dwords of the rows -- a view at an odd byte offset takes the fp32 MFMA kernel
         const bool full = H % 16 == 0 && W % 16 == 0;
         if (dtype == DT_FRAMES_U8 && full) hipLaunchKernelGGL((conv1_s3_kernel<true, true>), grid, dim3(256), 0, st, a);
         else if (dtype == DT_FRAMES_U8) hipLaunchKernelGGL((conv1_s3_kernel<true, false>), grid, dim3(256), 0, st, a);

@@ -397,7 +397,7 @@ struct Policy {
     int xcd_remap = 1;       // DT_XCD_REMAP: 0 = plain tile numbering (L2 traffic experiments)
     int tile_gn = -1;        // DT_TILE_GN: column tiles per group of the tile order; -1 = per-layer default
 };
-void policy_from_env(Policy &p);
+void policy_from_env(Policy &p, int pin_override = -1 /* >= 0: this value instead of DT_PIN */);
 
 struct dt_ctx {
     std::string err;

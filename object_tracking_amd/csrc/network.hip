@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "dt_internal.h"
 
@@ -217,7 +218,7 @@ static int upload(dt_ctx *ctx, float **dst, const std::vector<float> &h)
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int dt_abi_version(void) { return 107; }   // 1.07: + dt_gemm_split (test entry point of wino_gemm_s3.hip: bf16 x 3 or fp16 x 2 terms)
+extern "C" int dt_abi_version(void) { return 107; }   // 1.07: + dt_gemm_split (test entry point of wino_gemm_s3.hip: bf16 x 3 or fp16 x 2 terms), dt_policy_set
 
 extern "C" int dt_create(dt_ctx **out)
 {
@@ -314,7 +315,10 @@ extern "C" int dt_set_stream(dt_ctx *ctx, void *hip_stream)
         graphs_clear(ctx);                              // (synchronises the OLD stream if any graph exists)
         hipEvent_t ev = nullptr;
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
-            if (hipEventRecord(ev, ctx->stream) == hipSuccess) (void)hipStreamWaitEvent(next, ev, 0);
+            if (hipEventRecord(ev, ctx->stream) != hipSuccess || hipStreamWaitEvent(next, ev, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(ctx->stream);      // (e.g. the caller already destroyed the old stream: nothing of it can be in flight then)
+            }
             (void)hipEventDestroy(ev);
         } else {
             (void)hipStreamSynchronize(ctx->stream);
@@ -425,7 +429,7 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
         wino4s_fused_pack(u36.data(), L.npad, cin, cout, uf.data());
         if ((rc = upload(ctx, &L.fused4s, uf))) return rc;
         if (ctx->pol.f4b != 0) {
-            // ... and as bf16 terms in the stage images of wino4b_fused.hip (the kernel that runs them by default)
+            // ... and as bf16 terms in the stage images of wino4b_fused.hip (DT_F4B=1 only: the fp32 kernel is the default)
             std::vector<unsigned short> ub((size_t)36 * cin * cout * 3);
             wino4b_fused_pack(u36.data(), L.npad, cin, cout, ub.data());
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&L.fused4b), ub.size() * sizeof(unsigned short)));
@@ -462,19 +466,28 @@ static int build_merged_xproj(dt_ctx *ctx)
     if (!wino_wanted(ctx, 3, 1024, N4) || wino_tile(ctx, false) != 6 || ctx->trk_wino_ts != 6) return DT_OK;
     const float *wk = ctx->trk_hkernel.data(), *w23 = ctx->conv23_hwio.data();
     std::vector<float> merged((size_t)9 * 1024 * N4);
-    std::vector<double> row(N4);
-    for (int tap = 0; tap < 9; ++tap)
-        for (int c = 0; c < 1024; ++c) {
-            const float *src = wk + ((size_t)tap * Csrc + Cb + c) * N4;           // Keras input order: x_bbox first, then conv_feat
-            for (int n = 0; n < N4; ++n) row[n] = src[n];
-            for (int j = 0; j < Cb; ++j) {
-                const double a = w23[(size_t)c * Cb + j];
-                const float *wb = wk + ((size_t)tap * Csrc + j) * N4;
-                for (int n = 0; n < N4; ++n) row[n] += a * wb[n];
+    {   // 9 x 1024 independent rows of Cb x 4U float64 multiply-adds (1.6 G at C = 12): over the host's threads
+        auto work = [&](int r0, int r1) {
+            std::vector<double> row(N4);
+            for (int r = r0; r < r1; ++r) {
+                const int tap = r / 1024, c = r % 1024;
+                const float *src = wk + ((size_t)tap * Csrc + Cb + c) * N4;           // Keras input order: x_bbox first, then conv_feat
+                for (int n = 0; n < N4; ++n) row[n] = src[n];
+                for (int j = 0; j < Cb; ++j) {
+                    const double a = w23[(size_t)c * Cb + j];
+                    const float *wb = wk + ((size_t)tap * Csrc + j) * N4;
+                    for (int n = 0; n < N4; ++n) row[n] += a * wb[n];
+                }
+                float *dst = merged.data() + ((size_t)tap * 1024 + c) * N4;
+                for (int n = 0; n < N4; ++n) dst[n] = (float)row[n];
             }
-            float *dst = merged.data() + ((size_t)tap * 1024 + c) * N4;
-            for (int n = 0; n < N4; ++n) dst[n] = (float)row[n];
-        }
+        };
+        unsigned nth = std::thread::hardware_concurrency();
+        nth = nth < 1 ? 1 : (nth > 16 ? 16 : nth);
+        std::vector<std::thread> pool;
+        for (unsigned i = 0; i < nth; ++i) pool.emplace_back(work, (int)(9216ull * i / nth), (int)(9216ull * (i + 1) / nth));
+        for (auto &th : pool) th.join();
+    }
     std::vector<int> n_map;
     gate_interleave_map(U, n_map);
     // bias of border case k: b + sum over the taps (dy, dx) whose pixel exists: dy = 0 needs h > 0, dy = 2 needs h < H - 1, likewise dx
@@ -599,7 +612,7 @@ static void prof_direct_form(dt_ctx *ctx, double flops, double bytes, int family
 //          launch has enough tiles (wino_runs);
 //          0 = never (direct MFMA form everywhere); 2 = every 3x3 layer the transforms support,
 //          at any size (parity tests of the path at small shapes).  Applied when weights are loaded.
-void policy_from_env(Policy &p)
+void policy_from_env(Policy &p, int pin_override)
 {
     auto geti = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
     Policy d;
@@ -631,10 +644,13 @@ void policy_from_env(Policy &p)
     p.xcd_remap = geti("DT_XCD_REMAP", d.xcd_remap);
     p.tile_gn = geti("DT_TILE_GN", d.tile_gn);
     p.trk_merge = geti("DT_TRK_MERGE", d.trk_merge);
-    p.pin = geti("DT_PIN", d.pin);
+    p.pin = pin_override >= 0 ? pin_override : geti("DT_PIN", d.pin);
     if (p.pin) {      // every choice below otherwise looks at the number of frames / rows / tiles of the launch
         p.wino = 2; p.mosaic = 1; p.fused4 = 2; p.s3_half = -1; p.ksplit = 1;
         if (p.s3) p.s3 = 2;
+        p.trk_merge = 0;      // ONE form of the input projection, whichever entry point carries the frame (the merged weights are a different rounding of the
+                              // same network, and dt_track_recurrent on a caller's z rows cannot take them)
+        // (the fp16 form of the split GEMM is off under DT_PIN as well: h2_wanted)
     }
 }
 
@@ -2116,6 +2132,19 @@ extern "C" int dt_policy_reload(dt_ctx *ctx)
     if (!ctx) return DT_ERR_ARG;
     graphs_clear(ctx);        // a captured graph holds the launches of the OLD kernel selection
     policy_from_env(ctx->pol);
+    return DT_OK;
+}
+
+// One knob of ONE context, without going through the process environment (which other contexts and threads share):
+//   "pin" 1 / 0 : kernel selection independent of the batch (DT_PIN; parallel.py: deterministic=True) -- the other knobs are re-read
+//                 from the environment as dt_policy_reload does, then pinned or not.  Captured graphs are dropped only when the value changes.
+extern "C" int dt_policy_set(dt_ctx *ctx, const char *name, int value)
+{
+    if (!ctx || !name) return DT_ERR_ARG;
+    if (strcmp(name, "pin") != 0) return dt_fail(ctx, DT_ERR_ARG, "dt_policy_set: unknown knob '%s'", name);
+    const int v = value ? 1 : 0;
+    if (v != (ctx->pol.pin ? 1 : 0)) graphs_clear(ctx);
+    policy_from_env(ctx->pol, v);
     return DT_OK;
 }
 

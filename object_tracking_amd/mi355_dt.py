@@ -29,7 +29,7 @@ SYMBOLS = [
     "dt_track_row_width", "dt_track_detect", "dt_track_recurrent",
     "dt_packed_row_ints", "dt_pack_detections", "dt_unpack_detections",
     "dt_track_xproj_width", "dt_track_detect_xproj", "dt_track_recurrent_xproj",
-    "dt_gemm_split_bf16", "dt_gemm_split",
+    "dt_gemm_split_bf16", "dt_gemm_split", "dt_policy_set",
 ]
 
 _lib = None
@@ -95,6 +95,7 @@ def load_library():
     L.dt_graph_enable.argtypes = [vp, ci]
     L.dt_profile_reset.argtypes = [vp]
     L.dt_policy_reload.argtypes = [vp]
+    L.dt_policy_set.argtypes = [vp, ctypes.c_char_p, ci]
     L.dt_profile_names.argtypes = [vp, ctypes.c_char_p, csz]
     L.dt_profile_read.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64),
                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
@@ -554,6 +555,10 @@ class Context(object):
     def reload_policy(self):
         """re-read the DT_* tuning / test knobs from the environment (they are read once, in dt_create)"""
         self._check(self.lib.dt_policy_reload(self.h), "dt_policy_reload")
+
+    def policy_set(self, name, value):
+        """one knob of THIS context ("pin"), without the process environment (dt_policy_set)"""
+        self._check(self.lib.dt_policy_set(self.h, name.encode(), int(value)), "dt_policy_set")
 
     def graph_enable(self, on=True):
         """hipGraph replay of the detector trunk and the ConvLSTM recurrence (low-latency serving)."""

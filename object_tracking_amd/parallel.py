@@ -89,10 +89,12 @@ def gather_detections(res, n_clips_max=None, group=None, ctx=None, clip_ids=None
     """Cross-stream exchange.  `res` is MultiObjDetTracker.track_clips output for
     this rank's clips (device tensors).  Returns the dict for ALL clips of all ranks in global clip
     order with an extra `gids` tensor of globally unique track ids.  Shards may be uneven: rows are padded to
-    `n_clips_max` clips per rank.  n_clips_max=None (the default) means EQUAL shards -- every rank holds as many clips as this one, the
-    clip-shard's normal case -- and no rank issues anything but the ONE all-gather of one packed buffer per step; uneven shards pass
-    their maximum (ceil(total / world)), or n_clips_max="max" to let one extra scalar all-reduce find it.  Without an initialised
-    process group (single process) only the id globalisation is applied.
+    `n_clips_max` clips per rank.  n_clips_max=None / "max" (the default): one extra scalar all-reduce finds the largest shard -- safe for
+    any partition.  A caller that KNOWS its partition passes the number (ceil(total / world)), or n_clips_max="equal" (every rank holds as
+    many clips as this one: the clip-shard's normal case) -- then no rank issues anything but the ONE all-gather of one packed buffer per
+    step.  ("equal" on shards that are not equal would hand the collective buffers of different sizes: it is an assertion by the caller,
+    and the valid-row count of the result is checked against world x n_local.)  Without an initialised process group (single process)
+    only the id globalisation is applied.
       ctx       a mi355_dt.Context: pack / unpack / id globalisation run as the library's kernels
                 (dt_pack_detections / dt_unpack_detections) instead of torch indexing -- the path a C-ABI caller has;
       clip_ids  global clip index of every gathered row in rank-major order (block partition: omit; round-robin
@@ -104,9 +106,10 @@ def gather_detections(res, n_clips_max=None, group=None, ctx=None, clip_ids=None
     native = ctx is not None and boxes.is_cuda
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
-        if n_clips_max is None:
-            n_clips_max = n_local          # equal shards (documented precondition): no scalar collective on the default path
-        elif n_clips_max == "max":
+        equal = isinstance(n_clips_max, str) and n_clips_max == "equal"
+        if equal:
+            n_clips_max = n_local          # the caller's assertion: no scalar collective
+        elif n_clips_max is None or (isinstance(n_clips_max, str) and n_clips_max == "max"):
             m = torch.tensor([n_local], dtype=torch.int64, device=boxes.device if dist.get_backend(group) == "nccl" else "cpu")
             dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
             n_clips_max = int(m.item())
@@ -118,8 +121,12 @@ def gather_detections(res, n_clips_max=None, group=None, ctx=None, clip_ids=None
             stats["bytes_received"] = stats.get("bytes_received", 0) + (world - 1) * mine.numel() * 4
         if native and clip_ids is None:
             boxes, counts, ids, nids, gids = ctx.unpack_detections(allrows.contiguous(), T, cap)
+            if equal and boxes.shape[0] != world * n_local:
+                raise RuntimeError("gather_detections(n_clips_max='equal'): %d clips arrived from %d ranks, this rank holds %d -- the shards are not equal" % (boxes.shape[0], world, n_local))
             return dict(boxes=boxes, counts=counts, ids=ids, nids=nids, gids=gids)
         boxes, counts, ids, nids = _unpack_rows(allrows, T, cap)
+        if equal and boxes.shape[0] != world * n_local:
+            raise RuntimeError("gather_detections(n_clips_max='equal'): %d clips arrived from %d ranks, this rank holds %d -- the shards are not equal" % (boxes.shape[0], world, n_local))
         if clip_ids is not None:
             order = torch.argsort(torch.as_tensor(list(clip_ids), dtype=torch.int64)).to(boxes.device)
             assert order.numel() == boxes.shape[0], "clip_ids names %d rows, the exchange delivered %d" % (order.numel(), boxes.shape[0])
@@ -163,27 +170,22 @@ def _all_to_all_rows(send, group, async_op):
 
 
 class pinned_policy(object):
-    """DT_PIN=1 on a live context (csrc/network.hip:policy_from_env): the library's kernel selection no longer looks at the batch a
-    call carries, so a frame is the same rounding of the network whatever batch it travels in -- for any world size / `chunks`.
-    The previous policy is restored on exit."""
+    """DT_PIN=1 on ONE live context (dt_policy_set: no process-wide environment variable is touched, other contexts and threads keep
+    their policy): the library's kernel selection no longer looks at the batch a call carries, so a frame is the same rounding of the
+    network whatever batch it travels in -- for any world size / `chunks`.  The context is un-pinned on exit (captured hipGraphs are
+    dropped when the value changes: a deployment that replays graphs pins its context once, not per call)."""
 
     def __init__(self, ctx, on=True):
         self.ctx, self.on = ctx, on
 
     def __enter__(self):
         if self.on:
-            self.saved = os.environ.get("DT_PIN")
-            os.environ["DT_PIN"] = "1"
-            self.ctx.reload_policy()
+            self.ctx.policy_set("pin", 1)
         return self
 
     def __exit__(self, *exc):
         if self.on:
-            if self.saved is None:
-                os.environ.pop("DT_PIN", None)
-            else:
-                os.environ["DT_PIN"] = self.saved
-            self.ctx.reload_policy()
+            self.ctx.policy_set("pin", 0)
 
 
 def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=2, stats=None, rows=None, deterministic=False):
@@ -209,7 +211,7 @@ def track_clips_frame_sharded(trk, frames, cap=None, group=None, T=None, chunks=
     same frame is a different rounding of the same network for another world size or `chunks`.  Everything discrete --
     counts, cells, labels, track ids -- is identical unless a score / IoU lies within that rounding (~1e-4) of its
     threshold.  A deployment that needs ids that do not vary with the number of ranks pins the selection with the
-    threshold.  deterministic=True runs the call under DT_PIN=1 (`pinned_policy`): the selection then ignores the batch, every frame is
+    selection.  deterministic=True runs the call under DT_PIN=1 (`pinned_policy`): the selection then ignores the batch, every frame is
     computed by the same kernels in the same order for any world size, and boxes and ids are BIT-IDENTICAL between 1, 2, 4, 8 ranks
     (tests/test_gpu_multi.py::test_frame_shard_world_sizes_agree) -- at the price of the small-batch optimisations.
     `stats` (dict) receives bytes_received (rows + detection records from other ranks) for this call."""
@@ -341,59 +343,3 @@ def init_from_env(backend=None):
         torch.cuda.set_device(local)
     return rank, world, local
 
-
-# ---------------------------------------------------------------------------
-# Partitions of ONE GPU (throughput mode; no reference counterpart)
-# ---------------------------------------------------------------------------
-def cu_partition_streams(device=None, n=2):
-    """n HIP streams whose kernels are confined to complementary n-ths of the device's CUs (hipExtStreamCreateWithCUMask).
-    Independent clip batches run on them concurrently -- one context (one tracker object) per stream -- and one partition's launch
-    gaps and kernel tails are the other's working time: two partitions of 48 clips each deliver 3-4 % more frames per second than
-    one stream of the same 96 clips (profiles/r04_dual_partition.txt); half-size batches on two partitions deliver less."""
-    import ctypes
-    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    hip = ctypes.CDLL("libamdhip64.so")
-    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-    words = (n_cu + 31) // 32
-    out = []
-    with torch.cuda.device(device):
-        for i in range(n):
-            mask = (ctypes.c_uint32 * words)()
-            for cu in range(i * n_cu // n, (i + 1) * n_cu // n):
-                mask[cu // 32] |= 1 << (cu % 32)
-            st = ctypes.c_void_p()
-            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), words, mask)
-            if rc != 0:
-                raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
-            out.append(torch.cuda.ExternalStream(st.value, device=device))
-    return out
-
-
-def track_clips_partitions(trackers, frames_list, streams, cap=None, join=True):
-    """trackers[i].track_clips(frames_list[i]) on streams[i], all enqueued before any is waited for.  Every partition stream first waits for
-    ONE event recorded on the caller's current stream (whatever produced frames_list[i] there -- an H2D copy, a preprocessing kernel -- is
-    complete before a partition reads it), and every result tensor is recorded on the caller's stream (`record_stream`: the caching
-    allocator will not hand its block to another stream while the caller may still use it).  join=True: the caller's stream also waits
-    for every partition before the results are returned (a barrier per call).  join=False: that trailing wait is skipped -- a pipeline
-    that feeds batch after batch keeps both partitions busy across batch boundaries (that is where most of the gain is: +3-4 % against
-    +1.4 % with the barrier) and synchronises streams[i] (or waits on an event of it) before it READS result i.  Each tracker must own
-    its context."""
-    assert len(trackers) == len(frames_list) == len(streams)
-    cur = torch.cuda.current_stream()
-    # ONE event on the caller's stream, recorded before anything is launched: the CU-masked streams are blocking streams, and an
-    # operation on the legacy default stream between two partitions' launches (an event record is one) orders the second partition
-    # behind the whole of the first
-    ready = cur.record_event()
-    res = []
-    for trk, fr, st in zip(trackers, frames_list, streams):
-        st.wait_event(ready)
-        with torch.cuda.stream(st):
-            r = trk.track_clips(fr, cap=cap)
-        for v in (r.values() if isinstance(r, dict) else ()):
-            if torch.is_tensor(v) and v.is_cuda:
-                v.record_stream(cur)
-        res.append(r)
-    if join:
-        for st in streams:
-            cur.wait_stream(st)
-    return res

@@ -349,40 +349,6 @@ def test_graph_replay_with_caller_owned_rows():
         ctx.graph_enable(False)
 
 
-def test_two_cu_partitions_equal_one_stream():
-    """parallel.cu_partition_streams / track_clips_partitions: two trackers (two contexts, the same weights) on two streams masked to
-    complementary halves of the CUs, run concurrently several times over -- every partition's boxes, counts and ids are bit-identical
-    to the same tracker's result on the default stream (no kernel depends on how many CUs it runs on, no workspace is shared)."""
-    import numpy as np
-    import torch
-    from models_tracking.MultiObjDetTracker import MultiObjDetTracker
-    from object_tracking_amd import parallel
-    from utility import synth
-    H = W = 128; T = 6; N = 5; C = 12
-
-    class Trk(MultiObjDetTracker):
-        IMAGE_H, IMAGE_W = H, W
-        GRID_H, GRID_W = 4, 4
-        SEQUENCE_LENGTH = T
-        LOAD_MODEL = False
-        OBJ_THRESHOLD = 1e-4
-    blob, tw = synth.synth_darknet_blob(C), synth.synth_tracker_weights(C)
-    trks = [Trk(detector_weights=blob, tracker_weights=tw) for _ in range(2)]
-    assert trks[0].model.ctx is not trks[1].model.ctx
-    dev = trks[0].model.ctx.device
-    frames = [torch.from_numpy(np.stack([synth.synth_clip(T, H, W, 3, seed=500 + 20 * k + i) for i in range(N)])).to(dev) for k in range(2)]
-    want = [t.track_clips(f) for t, f in zip(trks, frames)]
-    torch.cuda.synchronize()
-    streams = parallel.cu_partition_streams(dev, 2)
-    for _ in range(3):
-        got = parallel.track_clips_partitions(trks, frames, streams)
-        torch.cuda.synchronize()
-        for g, w in zip(got, want):
-            for k in ("boxes", "counts", "ids", "nids", "netout"):
-                assert torch.equal(g[k], w[k]), k
-    assert float(want[0]["netout"].std()) > 0 and not torch.equal(want[0]["netout"], want[1]["netout"])
-
-
 _WORLDS = r'''
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
@@ -396,8 +362,8 @@ frames = bench.make_frames(n_clips, T, size, size, dev, seed0=42)
 trk, blob, tw = bench.build_tracker(size, size, T, 32, frames)
 trk.OBJ_THRESHOLD, trk.NMS_THRESHOLD, trk.ASSOC_THRESHOLD = 0.5, 0.45, 0.3      # the reference's defaults (KerasYOLO.py:43-44)
 out = {}
-for tag, det in (("default", False), ("pinned", True)):
-    r = track_clips_frame_sharded(trk, frames, cap=cap, deterministic=det)
+for tag, det, rows in (("default", False, None), ("pinned", True, None), ("pinnedz", True, "z")):
+    r = track_clips_frame_sharded(trk, frames, cap=cap, deterministic=det, rows=rows)
     for k in ("boxes", "counts", "ids", "gids"):
         out[tag + "_" + k] = r[k].cpu().numpy()
 if rank == 0:
@@ -412,7 +378,7 @@ def test_frame_shard_world_sizes_agree(tmp_path):
     """track_clips_frame_sharded at world 1 / 2 / 4 (gloo, all ranks on this box's GPU) on the SAME nine 30-frame 416x416 clips at the
     reference's default thresholds.  A rank's detector batch shrinks with the world size, and the library's kernel selection looks at
     the batch, so under the DEFAULT policy the same frame is another rounding of the network: how many frames / boxes / ids then differ
-    between world sizes is REPORTED (gpurun_out/parity_r05_world_sizes.json).  With deterministic=True (DT_PIN=1: selection independent
+    between world sizes is REPORTED (gpurun_out/parity_r06_world_sizes.json).  With deterministic=True (DT_PIN=1: selection independent
     of the batch) boxes, counts and global ids must be BIT-IDENTICAL for every world size."""
     import numpy as np
     script = tmp_path / "worlds.py"
@@ -446,9 +412,12 @@ def test_frame_shard_world_sizes_agree(tmp_path):
                 "bit_identical": bool(np.array_equal(r[tag + "_boxes"], base[tag + "_boxes"]) and np.array_equal(r[tag + "_gids"], base[tag + "_gids"]))}
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    with open(os.path.join(d, "parity_r05_world_sizes.json"), "w") as f:
+    with open(os.path.join(d, "parity_r06_world_sizes.json"), "w") as f:
         json.dump(report, f, indent=1)
     print(json.dumps(report))
+    for world in (1, 2, 4):      # deterministic=True is ONE rounding of the network whichever rows travel (rows="z": the owner runs the projection)
+        for k in ("boxes", "counts", "gids"):
+            assert np.array_equal(res[world]["pinnedz_" + k], res[1]["pinned_" + k]), (world, k)
     for world in (2, 4):
         assert report["world%d_pinned" % world]["bit_identical"], report
         assert report["world%d_default" % world]["max_box_value_difference"] < 1.0      # default policy: rounding-level values, discrete flips reported above
