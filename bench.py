@@ -516,7 +516,7 @@ def _run():
         stage_ms = rec
 
     kern = {}
-    for name in ("conv_gemm_s3", "conv_igemm", "conv_fused", "wino_input", "wino_output", "conv1_direct", "convlstm_gates", "decode_nms", "associate", "splitk_reduce", "pool",
+    for name in ("conv_gemm_s3", "conv_igemm", "conv_direct_h2", "conv_fused", "wino_input", "wino_output", "conv1_direct", "convlstm_gates", "decode_nms", "associate", "splitk_reduce", "pool",
                  "lstm_step", "misc"):
         p = ctx.profile_read(name)
         if p["launches"]:
@@ -527,13 +527,14 @@ def _run():
     ig = ctx.profile_read("conv_igemm")
     s3 = ctx.profile_read("conv_gemm_s3")
     fused = ctx.profile_read("conv_fused")
+    c3h2 = ctx.profile_read("conv_direct_h2")
     conv1 = ctx.profile_read("conv1_direct")
     wino_in, wino_out = ctx.profile_read("wino_input"), ctx.profile_read("wino_output")
     wino_ms = wino_in["ms"] + wino_out["ms"]
     # direct-form work (2*M*K*N of the reference's layer; in + W + out fp32 bytes) of the layers EACH family's
     # launches computed -- booked per family by the library (network.hip:prof_direct_form), never across families
     df = {"conv_gemm_s3": ctx.profile_read("conv_direct_form_s3"), "conv_igemm": ctx.profile_read("conv_direct_form"),
-          "conv_fused": ctx.profile_read("conv_direct_form_fused"),
+          "conv_fused": ctx.profile_read("conv_direct_form_fused"), "conv_direct_h2": ctx.profile_read("conv_direct_form_c3h2"),
           "conv1_direct": ctx.profile_read("conv_direct_form_conv1")}
     conv1_bf16 = ctx.profile_read("conv1_direct:bf16")["launches"] > 0      # conv1_s3_kernel (default) or the fp32 MFMA kernel (DT_S3_CONV1=0 / DT_S3=0)
     tr = load_traffic(args.clips, args.T, args.size) if args.workload == "track" else None
@@ -571,6 +572,9 @@ def _run():
                                PEAK_BF16_MFMA_TFLOPS, "wino_gemm_s3"),
         "conv_igemm_f32": family("conv_igemm", ig, "conv_igemm_f32 (implicit GEMM: the 1x1 layers with fewer than 128 output channels -- conv_4, conv_21, conv_23, tconv_2)",
                                  "v_mfma_f32_32x32x2_f32", PEAK_F32_MFMA_TFLOPS, "conv_igemm_f32"),
+        "conv3_h2": family("conv_direct_h2", c3h2, "conv3_h2_kernel (conv_2 / conv_3 / conv_5: direct 3x3 convolution, patch resident in LDS, + BN + LeakyReLU [+ 2x2 max])",
+                           "v_mfma_f32_32x32x16_f16 on 2-term split fp32 operands scaled into fp16's range, three per fp32 multiply-add, fp32 accumulate",
+                           PEAK_BF16_MFMA_TFLOPS, "conv3_h2"),
         "wino4s_fused": family("conv_fused", fused, "wino4s_fused_kernel (conv_2 / conv_3 / conv_5: fused F(4x4,3x3))", "v_mfma_f32_16x16x4_f32",
                                PEAK_F32_MFMA_TFLOPS, "wino4s_fused"),
         "conv1_mfma": family("conv1_direct", conv1, "conv1_s3_kernel (conv_1 + x/255 + BN + LeakyReLU + 2x2 max; K = 27 padded to 32)" if conv1_bf16 else
@@ -601,9 +605,9 @@ def _run():
     dominant = max((k for k in families if families[k]), key=lambda k: families[k]["ms_per_step"], default=None)
     # whole conv path: time the matrix pipe would need AT ITS PEAKS for everything the conv kernels execute (bf16 and fp32
     # instructions have different peaks) / the time the conv path takes, transforms included
-    conv_path_ms = s3["ms"] + ig["ms"] + fused["ms"] + conv1["ms"] + wino_ms
+    conv_path_ms = s3["ms"] + ig["ms"] + fused["ms"] + c3h2["ms"] + conv1["ms"] + wino_ms
     conv_path_flops = ig["flops"] + fused["flops"] + (0.0 if conv1_bf16 else conv1["flops"])      # executed on the fp32 MFMA instructions
-    conv_path_bf16 = s3["flops"] + (conv1["flops"] if conv1_bf16 else 0.0)                          # ... on the bf16 instruction
+    conv_path_bf16 = s3["flops"] + c3h2["flops"] + (conv1["flops"] if conv1_bf16 else 0.0)           # ... on the 16-bit instructions
     conv_path_pipe_frac = ((conv_path_bf16 / (PEAK_BF16_MFMA_TFLOPS * 1e12) + conv_path_flops / (PEAK_F32_MFMA_TFLOPS * 1e12)) /
                            (conv_path_ms * 1e-3)) if conv_path_ms > 0 else None
     direct_form_all = sum(v["flops"] for v in df.values())
@@ -630,7 +634,7 @@ def _run():
             "achieved_GBps": regimes["hbm"][1] / (regimes["hbm"][2] * 1e-3) / 1e9,
             "frac_of_8TBps": regimes["hbm"][1] / (regimes["hbm"][2] * 1e-3) / 8e12,
             "executed_tflops": regimes["hbm"][0] / (regimes["hbm"][2] * 1e-3) / 1e12}
-    for key, fam in (("conv_gemm_s3:", "wino_gemm_s3"), ("conv_igemm:", "conv_igemm_f32"), ("conv_fused:", "wino4s_fused")):
+    for key, fam in (("conv_gemm_s3:", "wino_gemm_s3"), ("conv_igemm:", "conv_igemm_f32"), ("conv_fused:", "wino4s_fused"), ("conv_direct_h2:", "conv3_h2")):
         if not families[fam]:
             continue
         layers = {}
@@ -718,13 +722,13 @@ def _run():
                 "frac_whole_conv_path": conv_path_pipe_frac,
                 "whole_conv_path": {"executed_fp32_mfma_tflop_per_step": conv_path_flops / steps / 1e12,
                                     "executed_bf16_mfma_tflop_per_step": conv_path_bf16 / steps / 1e12,
-                                    "fp32_equivalent_tflops": ((conv_path_flops + s3["flops"] / s3_products + (conv1["flops"] / 3.0 if conv1_bf16 else 0.0)) / (conv_path_ms * 1e-3) / 1e12)
+                                    "fp32_equivalent_tflops": ((conv_path_flops + s3["flops"] / s3_products + c3h2["flops"] / 3.0 + (conv1["flops"] / 3.0 if conv1_bf16 else 0.0)) / (conv_path_ms * 1e-3) / 1e12)
                                     if conv_path_ms > 0 else None,
                                     "ms_per_step": conv_path_ms / steps,
                                     "direct_form_tflop_per_step": direct_form_all / steps / 1e12,
                                     "direct_form_tflops": (direct_form_all / (conv_path_ms * 1e-3) / 1e12) if conv_path_ms > 0 else None,
                                     "direct_form_bytes_per_step": direct_form_bytes_all / steps,
-                                    "implementation_bytes_per_step": (s3["bytes"] + ig["bytes"] + wino_in["bytes"] + wino_out["bytes"] + fused["bytes"] + conv1["bytes"]) / steps},
+                                    "implementation_bytes_per_step": (s3["bytes"] + ig["bytes"] + wino_in["bytes"] + wino_out["bytes"] + fused["bytes"] + c3h2["bytes"] + conv1["bytes"]) / steps},
                 "note": "achieved / peak / frac / traffic = the DOMINANT kernel family (most time in the step): MFMA FLOPs its launches execute / "
                         "their HIP-event time, against the dense peak of the instruction it issues (pipe utilisation, <= 1). Per family "
                         "(families.*): executed = FLOPs on the matrix pipe; algorithmic = SURVEY.md 8d direct-form FLOPs (2MKN of the "

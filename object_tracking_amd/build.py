@@ -23,8 +23,8 @@ SOURCES = {
     # no SLP vectorisation: hipcc otherwise packs the transforms' scalar f32 adds / fmas into v_pk_* with a v_mov per operand --
     # more instructions, and packed f32 issues slowly beside MFMAs (MI355X_MICROARCH.md)
     "wino4s_fused.hip": ["-fno-slp-vectorize"],
-    "wino4b_fused.hip": [],
     "wino_gemm_s3.hip": [],
+    "conv3_h2.hip": [],
     "ingest.hip": [],
     "extract.hip": [],
     "exchange.hip": [],

@@ -20,6 +20,7 @@ struct Conv1Args {
     int tpw;             // tiles a workgroup walks along x
     const unsigned *w3;     // [2 k-blocks][3 terms][64 lanes][4]: the weights as the B operand of v_mfma_f32_32x32x16_bf16, split into three bf16 terms
     const unsigned *w3u8;   // the same for weights / 255 (uint8 frames: conv1_s3_kernel<true>)
+    unsigned *amax_out;     // conv1_s3_kernel: non-null = max |x| of the stored outputs into this slot (dt_amax_publish); conv_2's fp16 form scales by it
 };
 
 // K = 27 is short, but the fp32 MFMA peak equals the packed-FMA peak and an MFMA is ONE issue slot per 64 cycles: the
@@ -197,6 +198,7 @@ __device__ __forceinline__ float c1_bf16_f32(unsigned short h) { return __uint_a
 template <bool U8, bool FULL = false>      // FULL: H and W are multiples of 16 -- every tile is whole, no bounds checks around the stores
 __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
 {
+    float out_am = 0.0f;      // the largest |value| this lane stored (Conv1Args::amax_out)
     constexpr int NT = U8 ? 1 : 3;                    // bf16 terms of a patch value
     __shared__ unsigned short s_pl[3 * NT * C1_PL];   // [term][ci 3][18 x 18 (+4)]
 
@@ -357,7 +359,10 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
                     const float mx = fmaxf(fmaxf(acc[gi][4 * j], acc[gi][4 * j + 1]), fmaxf(acc[gi][4 * j + 2], acc[gi][4 * j + 3])) + bias;
                     const float v = mx > 0.0f ? mx : mx * p.slope;
                     const int ox = bx * 8 + h + 2 * j;
-                    if ((C1_ABLATE & 1) ? v == 12345.678f : (FULL || (oy < H2 && ox < W2))) C1_STORE(&p.out[(((long long)b * H2 + oy) * W2 + ox) * 32 + n], v);
+                    if ((C1_ABLATE & 1) ? v == 12345.678f : (FULL || (oy < H2 && ox < W2))) {
+                        out_am = fmaxf(out_am, fabsf(v));
+                        C1_STORE(&p.out[(((long long)b * H2 + oy) * W2 + ox) * 32 + n], v);
+                    }
                 }
             }
         }
@@ -379,6 +384,7 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
             tile(bx + 1, rawB);
         }
         if (bx < bx_last) tile(bx, rawA);
+        if (p.amax_out) dt_amax_publish(p.amax_out, out_am);
         return;
     }
     if (C1_PF == 2 && bx_first + 1 < bx_last) fetch(bx_first + 1, rawB);
@@ -387,6 +393,7 @@ __global__ __launch_bounds__(256) void conv1_s3_kernel(Conv1Args p)
         tile(bx, rawA);
         if (C1_PF == 2 && bx + 1 < bx_last) tile(bx + 1, rawB);
     }
+    if (p.amax_out) dt_amax_publish(p.amax_out, out_am);
 }
 
 // Host: the weight tables of conv1_s3_kernel.
@@ -408,11 +415,17 @@ void conv1_split_tables(const float *w_in /*[27][32]*/, bool scale255, unsigned 
             }
 }
 
+// does launch_conv1_direct take the kernel that fills `amax_out` for these arguments?
+bool conv1_direct_fills_amax(const void *frames, int dtype, int W, const unsigned *w3, const unsigned *w3u8)
+{
+    return w3 && w3u8 && (dtype != DT_FRAMES_U8 || (W % 4 == 0 && (reinterpret_cast<uintptr_t>(frames) & 3) == 0));
+}
 int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, int H, int W, const float *w_packed,
-                        const float *bias, const float *lut, float slope, float *out, const unsigned *w3, const unsigned *w3u8)
+                        const float *bias, const float *lut, float slope, float *out, const unsigned *w3, const unsigned *w3u8, unsigned *amax_out)
 {
     if ((H & 1) || (W & 1) || B <= 0) return 2;
     Conv1Args a;
+    a.amax_out = amax_out;
     a.frames = frames; a.dtype = dtype; a.B = B; a.H = H; a.W = W;
     a.w = w_packed; a.bias = bias; a.lut = lut; a.slope = slope; a.out = out;
     a.w3 = w3; a.w3u8 = w3u8;

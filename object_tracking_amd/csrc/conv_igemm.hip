@@ -382,6 +382,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
     constexpr bool AB_LSTORE = (DT_ABLATE & 4) != 0, AB_LFRAG = (DT_ABLATE & 8) != 0;
     // ---- epilogue (per tile) --------------------------------------------------
     const int hi = lane >> 5;
+    float out_am = 0.0f;      // the largest |value| this lane stored (ConvArgs::amax_out), over all its tiles
     auto epilogue = [&](const Tile &T) {
         const int m0 = T.m0, n0 = T.n0;
         float *outz = p.out + (long long)T.z * p.z_out;
@@ -459,14 +460,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
                     } else if (EPI == EPI_PLAIN) {
     #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (rbase + q < p.M) outz[(long long)(rbase + q) * p.out_ld + col] = v[q];
+                            if (rbase + q < p.M) { out_am = fmaxf(out_am, fabsf(v[q])); outz[(long long)(rbase + q) * p.out_ld + col] = v[q]; }
                     } else if (EPI == EPI_S2D) {
                         // tf.space_to_depth(2): pixel m>>2, channel (m&3)*N + col
     #pragma unroll
-                        for (int q = 0; q < 4; ++q)
+                        for (int q = 0; q < 4; ++q) {
+                            out_am = fmaxf(out_am, fabsf(v[q]));
                             outz[(long long)(rbase >> 2) * p.out_ld + q * p.N + col] = v[q];
+                        }
                     } else {
                         const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        out_am = fmaxf(out_am, fabsf(mx));      // (EPI_POOL_BOTH: the pooled tensor's maximum -- the one the next layer reads)
                         if (EPI == EPI_POOL) {
                             outz[(long long)(rbase >> 2) * p.out_ld + col] = mx;
                         } else {  // EPI_POOL_BOTH: out = unpooled (standard NHWC), out2 = pooled
@@ -719,6 +723,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN > 4 ? (WGM * WGN) / 4 : 
     }
     epilogue(cur_t);   // this staging variant is launched one tile per workgroup
 #endif
+    if ((EPI == EPI_PLAIN || EPI == EPI_POOL || EPI == EPI_POOL_BOTH || EPI == EPI_S2D) && p.amax_out) dt_amax_publish(p.amax_out, out_am);
 }
 
 template <int KS, int BM, int BN, int WGM, int WGN, int ORDER, int EPI, bool PERSIST = false>

@@ -81,6 +81,7 @@ struct ConvArgs {
     long long z_in, z_wt, z_out;
     int force_cfg; // > 0: tile configuration + 1 forced by the caller's policy (Policy::conv_cfg); 0: none
     int no_persist; // 1: one tile per workgroup even where the persistent tile loop applies (Policy::persist = 0, A/B runs)
+    unsigned *amax_out; // EPI_PLAIN (no split-K) / EPI_POOL / EPI_S2D: non-null = max |x| of the stored outputs into this slot (dt_amax_publish)
     int gn_default; // > 0: column-group width + 1 used when tile_gn is 0 (Policy::tile_gn, A/B runs); 0: the per-layer default
 };
 
@@ -160,10 +161,29 @@ struct Wino4FusedArgs {
 // U staged through LDS by DMA, in-register output transform, persistent over (block pair, 64-channel slice) items
 int launch_wino4s_fused(hipStream_t st, const Wino4FusedArgs &a, const float *zeros);
 void wino4s_fused_pack(const float *u36, int npad, int cin, int cout, float *dst);
-// the same layers on the BF16 matrix pipe with three-term split operands and an accumulated output transform (wino4b_fused.hip): items of
-// 64 tiles x 64 channels, a.u = the bf16 stage images of wino4b_fused_pack (36 * cin * cout * 3 unsigned shorts)
-int launch_wino4b_fused(hipStream_t st, const Wino4FusedArgs &a, const float *zeros);
-void wino4b_fused_pack(const float *u36, int npad, int cin, int cout, unsigned short *dst);
+// direct 3x3 convolution in the two-term fp16 form (conv3_h2.hip): conv_2 / conv_3 / conv_5's shapes
+struct Conv3H2Args {
+    const float *in;           // NHWC fp32, pixel stride in_ld, frame stride in_bs
+    long long in_bs;
+    int in_ld;
+    int B, H, W, Cin, N, Np;   // Cin % 32 == 0; N % 64 == 0 output channels, Np rows in w / bias
+    const unsigned short *w;   // two fp16 terms of the scaled packed weights [2][9 Cin / 16][Np][16], k = ((ci / 32) * 9 + tap) * 32 + ci % 32
+    const float *pscale;       // [1]: 1 / the weights' power of two
+    const unsigned *amax;      // max-|x| slot of the input tensor
+    const float *bias;         // [Np]
+    float slope;
+    float *out;                // full-resolution output (pixel stride out_ld, frame stride out_bs) or null
+    long long out_bs;
+    int out_ld;
+    float *out2;               // 2x2 max-pooled output [B][H/2][W/2][out2_ld] or null (exactly one of out / out2)
+    int out2_ld;
+    const float *zeros;        // >= 16 B of device zeros: where the loads of out-of-image patch pixels point
+    unsigned *amax_out;        // non-null: max |x| of the stored outputs into this slot
+    int tiles_x, tiles_y;      // set by the launcher
+};
+int launch_conv3_h2(hipStream_t st, const Conv3H2Args &a);
+bool conv3_h2_usable(const Conv3H2Args &a);
+double conv3_h2_flops(const Conv3H2Args &a);
 // split-bf16 batched GEMM of the F(6x6,3x3) layers (wino_gemm_s3.hip): fp32 operands as three bf16 terms, six MFMAs per product
 struct GemmS3Args {
     const unsigned short *a;   // V terms  [P][3][K/16][Mp][16]   (winograd.hip split input transform) -- the Winograd GEMMs; null for a 1x1 layer:
@@ -271,7 +291,9 @@ void wino_pack_weights(int ts, const float *hwio, int cin_src, int cout_src, con
 int launch_conv1_direct(hipStream_t st, const void *frames, int dtype, int B, int H, int W,
                         const float *w_packed /*[27][32]*/, const float *bias /*[32]*/,
                         const float *lut /*[256] or null*/, float slope, float *out /*[B,H/2,W/2,32]*/,
-                        const unsigned *w3 = nullptr /*[2][3][64][4]*/, const unsigned *w3u8 = nullptr /*weights / 255: both set -> conv1_s3_kernel*/);
+                        const unsigned *w3 = nullptr /*[2][3][64][4]*/, const unsigned *w3u8 = nullptr /*weights / 255: both set -> conv1_s3_kernel*/,
+                        unsigned *amax_out = nullptr /*conv1_s3_kernel: max |x| of the outputs into this slot*/);
+bool conv1_direct_fills_amax(const void *frames, int dtype, int W, const unsigned *w3, const unsigned *w3u8);
 #define C1_W3_WORDS 1540      // 1536 table words + 16 bytes of zeros: where conv1_s3_kernel points the loads of out-of-image pixels
 void conv1_split_tables(const float *w /*[27][32]*/, bool scale255, unsigned *w3 /*[1536 of C1_W3_WORDS]*/);
 
@@ -341,11 +363,12 @@ struct ConvLayer {
     unsigned short *bias_s3 = nullptr;   // device, with wt_s3: the bias as the B rows of one extra K stage, [3][npad][16]
     unsigned short *wt_h2 = nullptr;     // device, 1x1 layers: wt as two fp16 terms of the scaled weights [2][cin/16][npad][16] (wino_gemm_s3.hip's fp16 form) or null
     float *pscale_h2 = nullptr;          // device, with wt_h2: [1] the epilogue factor 1 / (the weights' power of two)
+    unsigned short *w3_h2 = nullptr;     // device, narrow 3x3 layers (conv_2 / 3 / 5's shapes): wt as two fp16 terms [2][9 cin / 16][npad][16] for conv3_h2.hip, or null
+    float *pscale_w3 = nullptr;          // device, with w3_h2: [1]
     float *wino = nullptr;               // device, [P][npad][cin] Winograd-domain weights (wide 3x3 layers) or null
     int wino_ts = 0;                     // their output tile size (2, 4 or 6)
     float *wino_alt = nullptr;           // device, F(4x4) weights kept next to F(6x6) ones for small-batch launches, or null
     float *fused4s = nullptr;            // device, fused F(4x4,3x3) weights (wino4s_fused.hip: conv_2 / 3 / 5 / 6 / 8's shapes) or null
-    unsigned short *fused4b = nullptr;   // device, the same as bf16 terms in wino4b_fused.hip's stage images, or null
     float *bias = nullptr;               // device, [npad]
     float *scale = nullptr;              // device, [cout]: folded BatchNorm scale (dt_detector_extract un-folds with it) or null
     bool scale_has_zero = false;
@@ -369,7 +392,9 @@ struct Policy {
                              //         frame in batches of other sizes for other world sizes): Winograd wherever defined, no frame mosaics, the fused kernel
                              //         and the split GEMM at any size, one tile form, no split-K, no F(4x4)/F(6x6) choice by tile count.  Slower at small
                              //         batch; results -- and track ids -- then do not depend on the number of ranks (parallel.py: deterministic=True)
-    int f4b = 0;             // DT_F4B: the fused layers run wino4b_fused.hip (bf16 pipe, split operands): 1 / 0 = wino4s_fused.hip (fp32 MFMA; default while the new kernel is slower)
+    int c3h2 = 1;            // DT_C3H2: conv_2 / conv_3 / conv_5 as DIRECT 3x3 convolutions in the two-term fp16 form (conv3_h2.hip) from 1024 16x16-pixel blocks
+                             //          (where the fused F(4x4) fp32 kernel ran until round 5); 0 = the fused kernel; 2 = at any size (parity tests).  Needs the fp16
+                             //          form (DT_S3_H2, not DT_PIN).  Read at weight load (0: no fp16 copy of the weights) and per launch
     int wino_cfg = -1, wino_gn = -1;   // DT_WINO_CFG / DT_WINO_GN (A/B runs)
     int ksplit = 0;          // DT_KSPLIT
     int conv_cfg = -1;       // DT_CONV_CFG

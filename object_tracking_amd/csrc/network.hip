@@ -274,10 +274,11 @@ extern "C" void dt_destroy(dt_ctx *ctx)
         if (ctx->layers[i].bias_s3) (void)hipFree(ctx->layers[i].bias_s3);
         if (ctx->layers[i].wt_h2) (void)hipFree(ctx->layers[i].wt_h2);
         if (ctx->layers[i].pscale_h2) (void)hipFree(ctx->layers[i].pscale_h2);
+        if (ctx->layers[i].w3_h2) (void)hipFree(ctx->layers[i].w3_h2);
+        if (ctx->layers[i].pscale_w3) (void)hipFree(ctx->layers[i].pscale_w3);
         if (ctx->layers[i].wino) (void)hipFree(ctx->layers[i].wino);
         if (ctx->layers[i].wino_alt) (void)hipFree(ctx->layers[i].wino_alt);
         if (ctx->layers[i].fused4s) (void)hipFree(ctx->layers[i].fused4s);
-        if (ctx->layers[i].fused4b) (void)hipFree(ctx->layers[i].fused4b);
         if (ctx->layers[i].scale) (void)hipFree(ctx->layers[i].scale);
     }
     if (ctx->trk_wxm_wino) { s3_drop(ctx, ctx->trk_wxm_wino); (void)hipFree(ctx->trk_wxm_wino); }
@@ -410,6 +411,16 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
             return dt_fail(ctx, DT_ERR_DEVICE, "fp16-form weight pack launch failed");
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    if (L.w3_h2) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.w3_h2); L.w3_h2 = nullptr; }
+    if (L.pscale_w3) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.pscale_w3); L.pscale_w3 = nullptr; }
+    if (ks == 3 && (cin == 32 || cin == 64) && cout % 64 == 0 && cout <= 128 && ctx->pol.s3 != 0 && ctx->pol.s3_h2 != 0 && ctx->pol.c3h2 != 0) {
+        // conv_2 / conv_3 / conv_5's shapes: the packed direct-form weights as two fp16 terms for conv3_h2.hip (the same k order)
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&L.w3_h2), packed.size() * 2 * sizeof(unsigned short)));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&L.pscale_w3), sizeof(float)));
+        if (launch_wino_h2_pack(ctx->stream, L.wt, 1, L.npad, 9 * cin, 0, amax_slot(ctx, AMAX_PACK), L.w3_h2, L.pscale_w3))
+            return dt_fail(ctx, DT_ERR_DEVICE, "fp16-form weight pack launch failed");
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (L.scale) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.scale); L.scale = nullptr; }
     L.scale_has_zero = false;
     if (scale) {
@@ -420,7 +431,6 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
     if (L.wino) { (void)hipStreamSynchronize(ctx->stream); s3_drop(ctx, L.wino); (void)hipFree(L.wino); L.wino = nullptr; }
     if (L.wino_alt) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.wino_alt); L.wino_alt = nullptr; }
     if (L.fused4s) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused4s); L.fused4s = nullptr; }
-    if (L.fused4b) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(L.fused4b); L.fused4b = nullptr; }
     const bool f4_shape = ((cin == 64 || cin == 128) && cout % 128 == 0 && cout <= 256) || (cin == 32 && cout == 64);
     if (ks == 3 && f4_shape && ctx->pol.wino != 0 && ctx->pol.fused4 != 0) {
         // conv_2 / conv_3 / conv_5 / conv_6 / conv_8's shapes: the fused F(4x4,3x3) kernel (wino4s_fused.hip)
@@ -428,13 +438,6 @@ static int load_conv_layer(dt_ctx *ctx, int idx, int ks, int cin, int cout, cons
         wino_pack_weights(4, hwio, cin, cout, nullptr, cin, nullptr, L.npad, scale, u36.data());
         wino4s_fused_pack(u36.data(), L.npad, cin, cout, uf.data());
         if ((rc = upload(ctx, &L.fused4s, uf))) return rc;
-        if (ctx->pol.f4b != 0) {
-            // ... and as bf16 terms in the stage images of wino4b_fused.hip (DT_F4B=1 only: the fp32 kernel is the default)
-            std::vector<unsigned short> ub((size_t)36 * cin * cout * 3);
-            wino4b_fused_pack(u36.data(), L.npad, cin, cout, ub.data());
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&L.fused4b), ub.size() * sizeof(unsigned short)));
-            HIP_TRY(ctx, hipMemcpy(L.fused4b, ub.data(), ub.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-        }
     }
     if (wino_wanted(ctx, ks, cin, cout)) {
         L.wino_ts = wino_tile(ctx, false);
@@ -595,11 +598,12 @@ extern "C" int dt_load_darknet_weights(dt_ctx *ctx, const float *h_blob, size_t 
 // under the kernel FAMILY whose launch computed it -- "conv_direct_form" (conv_igemm_f32 launches), "conv_direct_form_s3"
 // (wino_gemm_s3 launches), "conv_direct_form_fused" (the fused Winograd kernel) -- so that bench.py divides each family's
 // algorithmic work by that family's own time and no family is credited with work another kernel did.
-enum { DF_IGEMM = 0, DF_FUSED = 1, DF_S3 = 2, DF_CONV1 = 3 };
+enum { DF_IGEMM = 0, DF_FUSED = 1, DF_S3 = 2, DF_CONV1 = 3, DF_C3H2 = 4 };
 static void prof_direct_form(dt_ctx *ctx, double flops, double bytes, int family = DF_IGEMM)
 {
     if (!ctx->prof) return;
-    ProfEntry &e = ctx->prof_tab[family == DF_FUSED ? "conv_direct_form_fused" : (family == DF_S3 ? "conv_direct_form_s3" : (family == DF_CONV1 ? "conv_direct_form_conv1" : "conv_direct_form"))];
+    ProfEntry &e = ctx->prof_tab[family == DF_FUSED ? "conv_direct_form_fused" : (family == DF_S3 ? "conv_direct_form_s3" : (family == DF_CONV1 ? "conv_direct_form_conv1" :
+                                 (family == DF_C3H2 ? "conv_direct_form_c3h2" : "conv_direct_form")))];
     e.flops += flops;
     e.bytes += bytes;   // in + weights + out of the reference's layer, float32
 }
@@ -624,7 +628,7 @@ void policy_from_env(Policy &p, int pin_override)
     { const char *e = getenv("DT_WINO_WS_GB"); p.wino_ws_gb = e ? atof(e) : d.wino_ws_gb; }
     p.mosaic = geti("DT_WINO_MOSAIC", d.mosaic);
     p.fused4 = geti("DT_WINO_FUSED4", d.fused4);
-    p.f4b = geti("DT_F4B", d.f4b);
+    p.c3h2 = geti("DT_C3H2", d.c3h2);
     p.wino_cfg = geti("DT_WINO_CFG", d.wino_cfg);
     p.wino_gn = geti("DT_WINO_GN", d.wino_gn);
     p.ksplit = geti("DT_KSPLIT", d.ksplit);
@@ -1000,6 +1004,32 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
                                 (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0));
     char tag[32];
     snprintf(tag, sizeof(tag), L.idx == 102 ? "tconv_2" : "conv_%d", L.idx);
+    // conv_2 / 3 / 5's shapes: the DIRECT convolution in the two-term fp16 form (conv3_h2.hip) once there are enough tiles to fill the chip
+    if (L.w3_h2 && L.pscale_w3 && ctx->pol.c3h2 != 0 && h2_wanted(ctx) && in_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
+        ((epi == EPI_PLAIN && order == ORD_LINEAR) || (epi == EPI_POOL && !((H | W) & 1)))) {
+        const long long blocks = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((L.cout + 127) / 128);
+        if (ctx->pol.c3h2 == 2 || blocks >= 1024) {
+            Conv3H2Args c;
+            memset(&c, 0, sizeof(c));
+            c.in = in; c.in_bs = a.in_bs; c.in_ld = in_ld; c.B = B; c.H = H; c.W = W; c.Cin = L.cin; c.N = L.cout; c.Np = L.npad;
+            c.w = L.w3_h2; c.pscale = L.pscale_w3; c.bias = L.bias; c.slope = slope;
+            if (epi == EPI_POOL) { c.out2 = out; c.out2_ld = out_ld; }
+            else { c.out = out; c.out_ld = out_ld; c.out_bs = a.out_bs; }
+            c.zeros = ws_get(ctx, "zeros256", 256, /*zero_on_grow=*/true);
+            if (!c.zeros) return DT_ERR_DEVICE;
+            c.amax = ensure_amax(ctx, in, (long long)B * H * W, L.cin, in_ld, L.idx >= 1 && L.idx <= 23 ? AMAX_IN + L.idx : AMAX_TEST);
+            if (!c.amax) return DT_ERR_DEVICE;
+            if (amax_out_slot(L)) c.amax_out = amax_slot(ctx, amax_out_slot(L));
+            // executed fp16 MFMA FLOPs (three products per multiply, whole tiles); bytes: the input once per channel tile (+ halo 27 / 41 %) and the output
+            ProfScope ps(ctx, "conv_direct_h2", conv3_h2_flops(c),
+                         4.0 * ((double)B * H * W * L.cin * (L.cout % 128 ? 1.27 : 1.41) * ((L.cout + 127) / 128) + (double)a.M * L.cout / (epi == EPI_POOL ? 4.0 : 1.0)), tag);
+            prof_direct_form(ctx, flops, bytes, DF_C3H2);
+            const int rc = launch_conv3_h2(ctx->stream, c);
+            if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: direct fp16-form 3x3 launch failed", tag);
+            if (c.amax_out) amax_note(ctx, out, (long long)a.M / (epi == EPI_POOL ? 4 : 1) * out_ld, L.cout, amax_out_slot(L));
+            return DT_OK;
+        }
+    }
     // conv_2 / 3 / 5 (6 / 8)'s shapes: the fused F(4x4,3x3) kernel (V and M' stay on the CU) once there are enough 16x16-pixel
     // blocks to fill the chip several times over; below that the unfused forms win (few, half-empty workgroups)
     if (L.fused4s && ctx->pol.fused4 != 0 && in_ld % 4 == 0 && ((epi == EPI_PLAIN && order == ORD_LINEAR) || (epi == EPI_POOL && !((H | W) & 1)))) {
@@ -1018,11 +1048,8 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
             prof_direct_form(ctx, flops, bytes, DF_FUSED);
             float *zeros = ws_get(ctx, "zeros256", 256, /*zero_on_grow=*/true);
             if (!zeros) return DT_ERR_DEVICE;
-            const bool f4b = L.fused4b && ctx->pol.f4b != 0;
-            if (f4b) f.u = reinterpret_cast<const float *>(L.fused4b);
-            if (!f4b && h2_wanted(ctx) && amax_out_slot(L)) f.amax_out = amax_slot(ctx, amax_out_slot(L));
-            if (ctx->prof) ctx->prof_tab[f4b ? "conv_fused_kernel:bf16_split" : "conv_fused_kernel:fp32"].launches += 1;
-            const int rc = f4b ? launch_wino4b_fused(ctx->stream, f, zeros) : launch_wino4s_fused(ctx->stream, f, zeros);
+            if (h2_wanted(ctx) && amax_out_slot(L)) f.amax_out = amax_slot(ctx, amax_out_slot(L));
+            const int rc = launch_wino4s_fused(ctx->stream, f, zeros);
             if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused F(4x4) launch failed", tag);
             if (f.amax_out) amax_note(ctx, out, (long long)a.M / (epi == EPI_POOL ? 4 : 1) * out_ld, L.cout, amax_out_slot(L));
             return DT_OK;
@@ -1088,8 +1115,16 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
         return DT_OK;
     }
     ProfScope ps(ctx, "conv_igemm", flops, bytes, tag);
+    const bool am_epi = epi == EPI_PLAIN || epi == EPI_POOL || epi == EPI_POOL_BOTH || epi == EPI_S2D;
+    if (am_epi && h2_wanted(ctx) && amax_out_slot(L)) a.amax_out = amax_slot(ctx, amax_out_slot(L));
     const int rc = launch_igemm(ctx, a, L.ks, order, epi, cfg);
     if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "conv_%d launch failed (rc=%d)", L.idx, rc);
+    if (a.amax_out) {      // the tensor the next layer reads: pooled where the epilogue pools, 4 N channels per quarter-resolution pixel after space_to_depth
+        if (epi == EPI_POOL_BOTH) amax_note(ctx, out2, (long long)a.M / 4 * out2_ld, L.cout, amax_out_slot(L));
+        else if (epi == EPI_POOL) amax_note(ctx, out, (long long)a.M / 4 * out_ld, L.cout, amax_out_slot(L));
+        else if (epi == EPI_S2D) amax_note(ctx, out, (long long)a.M / 4 * out_ld, 4 * L.cout, amax_out_slot(L));
+        else amax_note(ctx, out, (long long)a.M * out_ld, L.cout, amax_out_slot(L));
+    }
     return DT_OK;
 }
 
@@ -1206,9 +1241,12 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
         prof_direct_form(ctx, 2.0 * B * H * W * 27.0 * 32.0, c1_bytes, DF_CONV1);
         amax_forget(ctx, bufA, (long long)per_frame * B);
         if (int rcz = amax_begin(ctx)) return rcz;
+        // (its epilogue takes max |x| of what it writes: conv_2's direct fp16-form kernel scales its input by it)
+        unsigned *am1 = c1s3 && h2_wanted(ctx) && conv1_direct_fills_amax(frames, dtype, W, ctx->conv1_w3, ctx->conv1_w3u8) ? amax_slot(ctx, 1) : nullptr;
         if (launch_conv1_direct(ctx->stream, frames, dtype, B, H, W, ctx->conv1_w, ctx->conv1_b, ctx->lut255, LEAKY,
-                                bufA, c1s3 ? ctx->conv1_w3 : nullptr, c1s3 ? ctx->conv1_w3u8 : nullptr))
+                                bufA, c1s3 ? ctx->conv1_w3 : nullptr, c1s3 ? ctx->conv1_w3u8 : nullptr, am1))
             return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");
+        if (am1) amax_note(ctx, bufA, (long long)B * (H / 2) * (W / 2) * 32, 32, 1);
     }
     const int h = H / 32, w = W / 32;
     int rc = graphed(ctx, "trunk:" + std::to_string(B), [&]() -> int {   // conv_2 .. conv_21: library-owned buffers only

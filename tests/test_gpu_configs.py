@@ -190,7 +190,9 @@ def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_pol
     assoc_thr = np.zeros(n_clips, dtype=np.float32)
     m_assoc = np.inf
     for i in range(n_clips):
-        link = [iou_matrix(rb[i, t, :rc[i, t]], rb[i, t - 1, :rc[i, t - 1]]).ravel() for t in range(1, T)]
+        # (a box can only take the id of a box of its own label: DESIGN.md section 6 -- the other pairs decide nothing)
+        link = [iou_matrix(rb[i, t, :rc[i, t]], rb[i, t - 1, :rc[i, t - 1]])[rb[i, t, :rc[i, t], 5][:, None] == rb[i, t - 1, :rc[i, t - 1], 5][None, :]]
+                for t in range(1, T)]
         thr, mg = gap_threshold(np.concatenate(link), 0.3, 0.2, 0.4)
         assoc_thr[i] = np.float32(thr)
         m_assoc = min(m_assoc, mg - abs(float(assoc_thr[i]) - thr))
@@ -207,7 +209,7 @@ def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_pol
     for bad in forbid_policy:
         assert bad not in names, "%s ran although the policy under test excludes it" % bad
     assert ctx.profile_read("wino_input:convlstm_step")["launches"] == T - 1
-    assert ctx.profile_read("conv_fused")["launches"] == 3          # conv_2, conv_3 and conv_5: the fused F(4x4) kernel (wino4s_fused.hip)
+    assert ctx.profile_read("conv_direct_h2")["launches"] == 3 and "conv_fused" not in names      # conv_2, conv_3 and conv_5: the direct fp16-form kernel (conv3_h2.hip)
 
     # ---- tracking grid: per-channel error overall and as a function of t (rounding growth of the recurrence)
     got = res["netout"].cpu().numpy()
@@ -281,7 +283,7 @@ def _track_config_vs_oracle(size, n_clips, T, target_boxes, cap, tag, expect_pol
             if counts[i, t] == rc[i, t] and counts[i, t - 1] == rc[i, t - 1] and rc[i, t] and rc[i, t - 1]:
                 ir = iou_matrix(rb[i, t, :rc[i, t]], rb[i, t - 1, :rc[i, t - 1]])
                 ig = iou_matrix(gb[i, t, :rc[i, t]], gb[i, t - 1, :rc[i, t - 1]])
-                near = np.abs(ir - float(assoc_thr[i])) < 0.01
+                near = (np.abs(ir - float(assoc_thr[i])) < 0.01) & (rb[i, t, :rc[i, t], 5][:, None] == rb[i, t - 1, :rc[i, t - 1], 5][None, :])
                 if near.any():
                     eps_assoc = max(eps_assoc, float(np.abs(ir - ig)[near].max()))
     assert m_assoc > 2.0 * eps_assoc, "association margin %g vs observed IoU error %g" % (m_assoc, eps_assoc)
@@ -364,7 +366,7 @@ def test_configs2_track_416_default_policy_vs_oracle():
     test_configs2_bench_kernel_selection_416_vs_oracle and test_configs2_bench_size_48_clips_vs_oracle)."""
     _track_config_vs_oracle(416, 9, 30, 32, 128, "r06_track416",
                             ["wino_input:convlstm_xproj", "wino_input:convlstm_step", "wino_input:conv_22",
-                             "conv_fused:conv_3", "conv_fused:conv_5", "wino_input:conv_6", "conv_fused:conv_2",
+                             "conv_direct_h2:conv_3", "conv_direct_h2:conv_5", "wino_input:conv_6", "conv_direct_h2:conv_2",
                              "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4", "conv_gemm_s3:conv_9", "conv_igemm:conv_14"],
                             min_boxes_per_frame=12)      # 32 candidates/frame; ~14-20 survive NMS (bench.py reports the same)
 
@@ -374,7 +376,7 @@ def test_configs2_bench_kernel_selection_416_vs_oracle():
     oracle can be run on every frame: every GEMM the bench runs on the split-bf16 kernel runs on it here -- asserted
     launch by launch from the profile -- with 128-row tiles (two workgroups per CU, DT_S3_HALF=1) throughout."""
     _track_config_vs_oracle(416, 9, 30, 32, 128, "r06_track416_bench_selection",
-                            ["conv_fused:conv_2", "conv_fused:conv_3", "conv_fused:conv_5", "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4",
+                            ["conv_direct_h2:conv_2", "conv_direct_h2:conv_3", "conv_direct_h2:conv_5", "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4",
                              "s3_tile:128x2"] + S3_BENCH_LAUNCHES,
                             min_boxes_per_frame=12, policy_env=dict(BENCH_SELECTION, DT_S3_HALF="1"),
                             forbid_policy=["s3_tile:256", "conv_igemm:conv_14", "conv_igemm:conv_22", "conv_igemm:convlstm_xproj",
@@ -394,7 +396,7 @@ def test_configs4_track_608_128_boxes_vs_oracle():
     split-bf16 GEMM on every launch the 24-clip bench shard (extra.track_608_128boxes) runs it on."""
     _track_config_vs_oracle(608, 4, 30, 400, 640, "r06_track608",
                             ["wino_input:convlstm_xproj", "wino_input:convlstm_step", "wino_input:conv_22",
-                             "conv_fused:conv_2", "conv_fused:conv_3", "s3_tile:256"] + S3_BENCH_LAUNCHES, min_boxes_per_frame=100,    # 400 candidates/frame -> >= 100 tracks after NMS
+                             "conv_direct_h2:conv_2", "conv_direct_h2:conv_3", "s3_tile:256"] + S3_BENCH_LAUNCHES, min_boxes_per_frame=100,    # 400 candidates/frame -> >= 100 tracks after NMS
                             policy_env=dict(BENCH_SELECTION, DT_S3_HALF="-1"), forbid_policy=["conv_igemm:conv_14", "conv_igemm:convlstm_step"])
 
 
@@ -430,7 +432,7 @@ def test_configs2_bench_size_48_clips_vs_oracle():
     res = trk.track_clips(frames, cap=cap)
     ctx.profile_enable(False)
     names = set(ctx.profile_names())
-    for want in S3_BENCH_LAUNCHES + ["conv_fused:conv_2", "conv_fused:conv_3", "conv_fused:conv_5", "s3_tile:128x2", "s3_tile:256",
+    for want in S3_BENCH_LAUNCHES + ["conv_direct_h2:conv_2", "conv_direct_h2:conv_3", "conv_direct_h2:conv_5", "s3_tile:128x2", "s3_tile:256",
                                      "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4", "conv_igemm:conv_4", "conv_igemm:conv_21"]:
         assert want in names, "%s did not run; ran: %s" % (want, sorted(n for n in names if ":" in n))
     assert ctx.profile_read("conv_gemm_s3:convlstm_step")["launches"] == T - 1

@@ -1209,16 +1209,15 @@ def test_graph_replay_lstm_sequence(ctx):
 
 
 # ---- conv_2's shape (32 -> 64 channels, pooled) through the fused F(4x4,3x3) kernel (csrc/wino4s_fused.hip) ---------
-F4_KERNELS = [("0", "conv_fused_kernel:fp32"), ("1", "conv_fused_kernel:bf16_split")]      # DT_F4B: wino4s_fused.hip (default) / wino4b_fused.hip
+F4_KERNELS = [("0", "conv_fused")]      # wino4s_fused.hip (round 5's bf16 twin wino4b_fused.hip is gone: conv3_h2.hip took its place)
 
 
-@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma", "bf16_split"])
+@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma"])
 @pytest.mark.parametrize("B,H,W", [(2, 16, 16), (3, 32, 48), (1, 18, 34), (2, 2, 2), (5, 104, 104)])
 def test_conv2_fused_winograd_vs_oracle(ctx, monkeypatch, B, H, W, f4b, ktag):
     """32 -> 64 channels with the 2x2 pooling epilogue through the fused kernels (forced at any size): whole and
     partial blocks, image borders, several frames; against the oracle and against the direct form."""
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
-    monkeypatch.setenv("DT_F4B", f4b)
     rs = np.random.RandomState(B * 100 + H + W)
     x = rs.randn(B, H, W, 32).astype(np.float32)
     w = (rs.randn(3, 3, 32, 64) * np.sqrt(2.0 / (9 * 32))).astype(np.float32)
@@ -1238,11 +1237,10 @@ def test_conv2_fused_winograd_vs_oracle(ctx, monkeypatch, B, H, W, f4b, ktag):
     assert relerr(got.cpu().numpy(), direct.cpu().numpy()) < 1e-4
 
 
-@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma", "bf16_split"])
+@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma"])
 def test_conv2_fused_winograd_one_hot(ctx, monkeypatch, f4b, ktag):
     """one-hot taps on small integers: any misplaced tile / channel / position is off by >= 1"""
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
-    monkeypatch.setenv("DT_F4B", f4b)
     B, H, W = 2, 20, 12
     x = (np.arange(B * H * W * 32, dtype=np.float32).reshape(B, H, W, 32) % 251)
     w = np.zeros((3, 3, 32, 64), dtype=np.float32)
@@ -1252,15 +1250,15 @@ def test_conv2_fused_winograd_one_hot(ctx, monkeypatch, f4b, ktag):
     assert np.abs(got - orc.maxpool2(orc.conv2d(x, w))).max() < 0.05
 
 
-@pytest.mark.parametrize("mode", ["default", "all_winograd", "bf16_fused"])
+@pytest.mark.parametrize("mode", ["default", "all_winograd", "direct_h2"])
 def test_detector_non_square_odd_grid_vs_oracle(ctx, monkeypatch, mode):
     """352x288 frames (grid 11x9: odd, non-square, not a multiple of any Winograd tile), 5 frames (ragged mosaic
     groups, partial 16x16-pixel blocks of the fused kernel at 176x144 / 88x72 pixels): whole detector vs oracle."""
     if mode != "default":
         monkeypatch.setenv("DT_WINO", "2")
         monkeypatch.setenv("DT_WINO_FUSED4", "2")
-    if mode == "bf16_fused":
-        monkeypatch.setenv("DT_F4B", "1")            # conv_2 / 3 / 5 (and 6 / 8 under DT_WINO_FUSED4=2) on wino4b_fused.hip inside the whole network
+    if mode == "direct_h2":
+        monkeypatch.setenv("DT_C3H2", "2")           # conv_2 / 3 / 5 on conv3_h2.hip at this small batch too, inside the whole network
     det, layers, _ = _detector(ctx, 352, 288, 12)
     frames = synth.synth_clip(5, 352, 288, 3, seed=21)
     ref_net, ref_feat, _ = orc.yolov2_forward(orc.normalize_u8(frames), layers)
@@ -1268,8 +1266,8 @@ def test_detector_non_square_odd_grid_vs_oracle(ctx, monkeypatch, mode):
     c.profile_reset(); c.profile_enable(True)
     net, feat = c.detect_forward(dev(frames, c), want_feat=True)
     c.profile_enable(False)
-    if mode == "bf16_fused":
-        assert c.profile_read("conv_fused_kernel:bf16_split")["launches"] >= 3 and c.profile_read("conv_fused_kernel:fp32")["launches"] == 0
+    if mode == "direct_h2":
+        assert c.profile_read("conv_direct_h2")["launches"] == 3
     assert net.shape == (5, 11, 9, 5, 17)
     assert chan_err(flat_c(net.cpu().numpy()), flat_c(ref_net)) < NET_TOL
     assert chan_err(feat.cpu().numpy(), ref_feat) < NET_TOL
@@ -1318,10 +1316,9 @@ def test_winograd_randomized_shapes_vs_oracle(ctx, monkeypatch):
     (1, 13, 13, 128, 256, 0),     # odd size, smaller than a block
     (5, 104, 104, 64, 128, 0),    # conv_3's real geometry (6.5 blocks per side)
 ])
-@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma", "bf16_split"])
+@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma"])
 def test_conv_fused_f4x4_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool, f4b, ktag):
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
-    monkeypatch.setenv("DT_F4B", f4b)
     rs = np.random.RandomState(B * 100 + H + W + Cin)
     x = rs.randn(B, H, W, Cin).astype(np.float32)
     w = (rs.randn(3, 3, Cin, Cout) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
@@ -1340,12 +1337,61 @@ def test_conv_fused_f4x4_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool, f
     assert relerr(got.cpu().numpy(), other.cpu().numpy()) < 2e-4
 
 
-@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma", "bf16_split"])
+# ---- conv_2 / conv_3 / conv_5 as DIRECT 3x3 convolutions in the two-term fp16 form (csrc/conv3_h2.hip) ----------------------
+@pytest.mark.parametrize("B,H,W,Cin,Cout,pool", [
+    (2, 16, 16, 64, 128, 0),      # exactly one 16-wide tile column, two 8-row tiles per frame; two 32-channel chunks
+    (3, 32, 48, 64, 128, 1),      # pooled epilogue (conv_5), several tiles
+    (1, 26, 22, 64, 128, 0),      # partial tiles on both edges
+    (5, 104, 104, 64, 128, 0),    # conv_3's real geometry (6.5 tiles per row)
+    (3, 32, 48, 32, 64, 1),       # conv_2's shape class: one chunk, 64 output channels (16x16 tiles, waves 4 x 1), pooled
+    (2, 208, 208, 32, 64, 1),     # conv_2's real geometry
+    (1, 26, 22, 32, 64, 0),
+    (2, 24, 40, 64, 64, 1),       # 64 -> 64: two chunks on the 16x16-tile instance
+    (2, 16, 32, 32, 128, 0),      # 32 -> 128: one chunk on the 8x16-tile instance
+    (70, 13, 13, 64, 128, 0),     # frames smaller than a tile, more items than workgroups (the persistent loop turns over)
+])
+def test_conv3_direct_h2_vs_oracle(ctx, monkeypatch, B, H, W, Cin, Cout, pool):
+    monkeypatch.setenv("DT_C3H2", "2")
+    monkeypatch.setenv("DT_WINO_FUSED4", "2")
+    rs = np.random.RandomState(B * 100 + H + W + Cin)
+    x = rs.randn(B, H, W, Cin).astype(np.float32)
+    w = (rs.randn(3, 3, Cin, Cout) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32)
+    ref = orc.conv2d(x, w, b)
+    ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
+    if pool:
+        ref = orc.maxpool2(ref)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=pool)
+    ctx.profile_enable(False)
+    assert ctx.profile_read("conv_direct_h2")["launches"] == 1 and ctx.profile_read("conv_fused")["launches"] == 0 and ctx.profile_read("absmax")["launches"] == 1
+    assert relerr(got.cpu().numpy(), ref) < 5e-6            # direct form, fp32-class products: the fp32 MFMA kernel's own level
+    e = 12
+    got2 = ctx.conv2d(dev(np.ldexp(x, e), ctx), w, None, leaky_slope=0.1, pool=pool).cpu().numpy()      # the scale follows the data: exact powers of two
+    base = ctx.conv2d(dev(x, ctx), w, None, leaky_slope=0.1, pool=pool).cpu().numpy()
+    assert np.array_equal(got2, np.ldexp(base, e))
+
+
+def test_conv3_direct_h2_one_hot(ctx, monkeypatch):
+    """one-hot taps on small integers: every tap / chunk / half / tile offset / channel slot of the direct kernel must line up"""
+    monkeypatch.setenv("DT_C3H2", "2")
+    for (B, H, W, Cin, Cout) in ((2, 20, 36, 64, 128), (2, 20, 36, 32, 64)):
+        x = (np.arange(B * H * W * Cin, dtype=np.float32).reshape(B, H, W, Cin) % 251)
+        w = np.zeros((3, 3, Cin, Cout), dtype=np.float32)
+        for n in range(Cout):
+            w[n % 3, (n // 3) % 3, (n * 7) % Cin, n] = 1.0
+        ctx.profile_reset(); ctx.profile_enable(True)
+        got = ctx.conv2d(dev(x, ctx), w, None, leaky_slope=1.0, pool=0).cpu().numpy()
+        ctx.profile_enable(False)
+        assert ctx.profile_read("conv_direct_h2")["launches"] == 1
+        assert np.array_equal(got, orc.conv2d(x, w)), (Cin, Cout)      # integers below 2^11: exact in hi alone
+
+
+@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma"])
 @pytest.mark.parametrize("B,H,W,pool", [(3, 32, 48, 1), (2, 208, 208, 1), (1, 26, 22, 0)])
 def test_conv2_shape_through_staged_f4x4_kernel(ctx, monkeypatch, B, H, W, pool, f4b, ktag):
     """conv_2's shape (32 -> 64 channels) through the fused F(4x4) kernels: pooled and plain epilogue, the real 208x208 geometry"""
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
-    monkeypatch.setenv("DT_F4B", f4b)
     rs = np.random.RandomState(B + H + W)
     x = rs.randn(B, H, W, 32).astype(np.float32)
     w = (rs.randn(3, 3, 32, 64) * np.sqrt(2.0 / (9 * 32))).astype(np.float32)
@@ -1361,11 +1407,10 @@ def test_conv2_shape_through_staged_f4x4_kernel(ctx, monkeypatch, B, H, W, pool,
     assert relerr(got.cpu().numpy(), ref) < 1e-4
 
 
-@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma", "bf16_split"])
+@pytest.mark.parametrize("f4b,ktag", F4_KERNELS, ids=["fp32_mfma"])
 def test_conv_fused_f4x4_one_hot(ctx, monkeypatch, f4b, ktag):
     """one-hot taps on small integers: every position / tile offset / channel slot of the fused kernels must line up"""
     monkeypatch.setenv("DT_WINO_FUSED4", "2")
-    monkeypatch.setenv("DT_F4B", f4b)
     B, H, W, Cin, Cout = 2, 20, 36, 64, 128
     x = (np.arange(B * H * W * Cin, dtype=np.float32).reshape(B, H, W, Cin) % 251)
     w = np.zeros((3, 3, Cin, Cout), dtype=np.float32)

@@ -8,7 +8,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 run() { n=$1; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$n -o pmc -- python $R/tools/fused4_probe.py $L $N > $O/pmc_$n.log 2>&1
-  for c in "$@"; do python $R/tools/rocprof_summary.py pmc $O/pmc_$n $c | grep -i "fused\|wino\|igemm" | head -4 | cut -c1-40,88- | sed "s/^/$c /"; done
+  for c in "$@"; do python $R/tools/rocprof_summary.py pmc $O/pmc_$n $c | grep -i "fused\|wino\|igemm\|conv3" | head -4 | cut -c1-40,88- | sed "s/^/$c /"; done
 }
 run a GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES
 run b SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
