@@ -246,6 +246,42 @@ def detect_batch8_extra(device, H, W, seed0):
         out[label] = {"ms_per_batch": ms, "frames_per_s": B / (ms * 1e-3),
                       "direct_form_tflops": B * GFLOP_DETECT_416_C80 * (H * W) / (416.0 * 416.0) / ms}
     det.model.ctx.graph_enable(False)
+    # roofline-style block of this configuration: an instrumented pass (HIP events per launch), the bytes of weights a forward streams by the
+    # library's own count (at batch 8 the 13x13 layers are bound by them: Winograd-domain weights are 64 / 9 (F(6x6)) or 36 / 9 (F(4x4)) times
+    # the direct form's), and what those bytes cost at the 5 TB/s a streaming kernel reaches
+    ctx = det.model.ctx
+    ctx.profile_reset(); ctx.profile_enable(True)
+    n = 10
+    for _ in range(n):
+        det.detect(frames)
+    ctx.profile_enable(False)
+    fam = {}
+    for name in ("conv_gemm_s3", "conv_igemm", "conv_direct_h2", "conv_fused", "wino_input", "wino_output", "conv1_direct", "splitk_reduce", "decode_nms", "absmax"):
+        pr = ctx.profile_read(name)
+        if pr["launches"]:
+            fam[name] = {"launches_per_forward": pr["launches"] / n, "ms_per_forward": pr["ms"] / n,
+                         "executed_tflops": (pr["flops"] / (pr["ms"] * 1e-3) / 1e12) if pr["ms"] > 0 else None,
+                         "implementation_GBps": (pr["bytes"] / (pr["ms"] * 1e-3) / 1e9) if pr["ms"] > 0 else None}
+    wbytes = 0.0
+    layers = {}
+    for name in ctx.profile_names():
+        if name.startswith("conv_igemm:") or name.startswith("conv_gemm_s3:"):
+            pr = ctx.profile_read(name)
+            if pr["ms"] > 0:
+                layers[name] = {"ms_per_forward": pr["ms"] / n, "executed_tflops": pr["flops"] / (pr["ms"] * 1e-3) / 1e12,
+                                "implementation_MB_per_forward": pr["bytes"] / n / 1e6}
+                wbytes += pr["bytes"] / n
+    direct_w = 203.8e6
+    kernel_ms = sum(v["ms_per_forward"] for v in fam.values())
+    out["roofline"] = {"bound": "hbm (weights) at this batch: 23 layers, %d launches, no layer has more than 8 x 43264 rows" % int(sum(v["launches_per_forward"] for v in fam.values())),
+                       "kernel_ms_per_forward": kernel_ms, "families": fam,
+                       "gemm_operand_bytes_per_forward": wbytes, "direct_form_weight_bytes": direct_w,
+                       "hbm_ms_of_gemm_operand_bytes_at_5TBps": wbytes / 5e12 * 1e3,
+                       "hbm_ms_of_direct_form_weights_at_5TBps": direct_w / 5e12 * 1e3,
+                       "direct_form_tflops_over_kernel_time": B * GFLOP_DETECT_416_C80 * (H * W) / (416.0 * 416.0) / kernel_ms if kernel_ms > 0 else None,
+                       "gemm_layers": layers,
+                       "note": "instrumented pass (plain launches, an event pair per launch); gemm_operand_bytes = V + U + M' of every GEMM launch by the library's own "
+                               "count -- dominated by the Winograd-domain weights U of the 13x13 layers; the gap between kernel_ms and ms_per_batch is launch latency"}
     return out
 
 

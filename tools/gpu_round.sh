@@ -34,8 +34,8 @@ if [ "${SKIP_PMC:-0}" != "1" ]; then
 fi
 # the split-bf16 GEMM on its own: rate, error against float64, effective clock with / without the LDS fragment reads and the DMA
 if [ -x $R/tools/micro/gemm_s3_bench ]; then
-  (cd $R && timeout 300 tools/micro/gemm_s3_bench > $O/gemm_s3_micro.txt 2>&1; cat $O/gemm_s3_micro.txt | cut -c1-170)
-  (bash $R/tools/s3_clock.sh - _a1 _a2 _a3 -zero -const > $O/gemm_s3_clock.txt 2>&1; cat $O/gemm_s3_clock.txt)
+  (cd $R && for NT in 2 3; do S3_NT=$NT timeout 300 tools/micro/gemm_s3_bench; done > $O/gemm_s3_micro.txt 2>&1; cat $O/gemm_s3_micro.txt | cut -c1-170)
+  (export S3_NT=2; bash $R/tools/s3_clock.sh - _a1 _a2 _a3 -zero -const > $O/gemm_s3_clock.txt 2>&1; export S3_NT=3; bash $R/tools/s3_clock.sh - -zero >> $O/gemm_s3_clock.txt 2>&1; cat $O/gemm_s3_clock.txt)
 fi
 # practical HBM ceilings of this box per traffic mix (read / write / copy / the transforms' mixes)
 [ -x $R/tools/micro/hbm_rw ] && (cd $R && timeout 120 tools/micro/hbm_rw > $O/hbm_ceilings.txt 2>&1; cat $O/hbm_ceilings.txt)

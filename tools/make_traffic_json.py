@@ -56,8 +56,8 @@ def main():
     }
     out["traffic_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
     # the whole conv family of ONE step (the probe runs the path twice: head calibration + the measured step):
-    # MFMA GEMMs + Winograd transforms + the fused conv_2 / conv_3 / conv_5 kernels (conv_1 is listed separately: it was never part of this sum)
-    fam2 = lambda k: any(t in k for t in ("wino_gemm_s3", "conv_igemm_f32", "wino_input", "wino_output", "wino4s_fused", "splitk_reduce"))
+    # MFMA GEMMs + Winograd transforms + the direct (round 6) / fused conv_2 / conv_3 / conv_5 kernels (conv_1 is listed separately: it was never part of this sum)
+    fam2 = lambda k: any(t in k for t in ("wino_gemm_s3", "conv_igemm_f32", "wino_input", "wino_output", "wino4s_fused", "conv3_h2", "absmax", "splitk_reduce"))
     passes = 2.0
     out["conv_family_fetch_bytes_per_step"] = sum(v for _, k, v in fetch if fam2(k)) * 1024.0 * f_read / passes
     out["conv_family_write_bytes_per_step"] = sum(v for _, k, v in write if fam2(k)) * 1024.0 * f_write / passes
@@ -71,7 +71,7 @@ def main():
             by.setdefault(k.split("(")[0][:60], [0.0, 0.0])[1] += v * 1024.0 * f_write / passes
     out["per_kernel_bytes_per_step"] = {k: {"fetch": a, "write": b} for k, (a, b) in sorted(by.items())}
     # per kernel FAMILY of bench.py's roofline.families (each family's own launches only)
-    fams = {"wino_gemm_s3": ("wino_gemm_s3",), "conv_igemm_f32": ("conv_igemm_f32",), "wino4s_fused": ("wino4s_fused",),
+    fams = {"wino_gemm_s3": ("wino_gemm_s3",), "conv_igemm_f32": ("conv_igemm_f32",), "wino4s_fused": ("wino4s_fused",), "conv3_h2": ("conv3_h2",),
             "conv1_mfma": ("conv1_mfma", "conv1_s3"), "wino_transforms": ("wino_input", "wino_output")}
     out["family_bytes_per_step"] = {
         f: (sum(v for _, k, v in fetch if any(t in k for t in pats)) * f_read + sum(v for _, k, v in write if any(t in k for t in pats)) * f_write) * 1024.0 / passes

@@ -22,6 +22,6 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
 ks = [k for k in gui if k in dur][2:]
 if ks:
     us = sum(dur[k] for k in ks) / len(ks); cyc = sum(gui[k] for k in ks) / len(ks) / 8; m = sum(mf.get(k, 0) for k in ks) / len(ks) / 1024
-    print("variant '%s': %.0f us  %.2fM cycles  clock %.3f GHz  MFMA busy %.2fM cycles/SIMD (%.0f%%)" % (suf, us, cyc / 1e6, cyc / us / 1e3, m / 1e6, 100 * m / cyc))
+    print("NT=%s variant '%s': %.0f us  %.2fM cycles  clock %.3f GHz  MFMA busy %.2fM cycles/SIMD (%.0f%%)" % (os.environ.get("S3_NT", "3"), suf, us, cyc / 1e6, cyc / us / 1e3, m / 1e6, 100 * m / cyc))
 PY
 done
