@@ -407,6 +407,9 @@ struct Policy {
                              //           matrix-pipe work and 4 instead of 6 bytes per operand element; wino_gemm_s3.hip) -- wherever the bf16 form would run; 0 = three
                              //           bf16 terms / six products (round 3).  Read at weight load (the fp16 terms are built then) and per launch.  DT_PIN takes the
                              //           bf16 form: the fp16 form's scale is the batch's max |x|, so its rounding of small elements depends on the batch
+    int h2_minframes = 32;   // DT_H2_MINFRAMES: a forward of fewer frames takes round 5's forms (bf16 terms, fused fp32 kernel) and its producers publish no max |x|:
+                             //                  at batch 8 the publications (a dependent load + atomic at the tail of 40-us kernels) and the one stand-alone absmax pass
+                             //                  cost 0.16 ms of a 1.26 ms forward and the fp16 form has nothing to win there (weights-bound GEMMs on the fp32 kernel)
     int s3_half = 0;          // DT_S3_HALF: 128-row tiles / two workgroups per CU in the split GEMM: 0 where it needs fewer rounds (default) / 1 always (N % 256 == 0) / -1 never
     int s3_rec_minrows = 512; // DT_S3_REC_MINROWS: the ConvLSTM recurrent step's F(4x4) GEMM (gate update in its output transform) takes the split
                               //                    kernel from this many GEMM rows (48 clips at 13x13: 588); 0 = never
@@ -447,6 +450,7 @@ struct dt_ctx {
     // 64..127: scratch of the weight packs
     unsigned *amax = nullptr;
     struct AmaxTag { const float *lo, *hi; int cols, slot; };   // the tensor that occupies [lo, hi), `cols` channels per pixel -> the slot that holds its max |x|
+    bool h2_small = false;                   // the running call carries fewer than Policy::h2_minframes frames: no fp16 form, no max-|x| publication
     std::vector<AmaxTag> amax_tag;           // valid inside one API call only (amax_reset), and until a layer writes into [lo, hi) (amax_forget)
     float *conv1_w = nullptr, *conv1_b = nullptr, *lut255 = nullptr;
     unsigned *conv1_w3 = nullptr, *conv1_w3u8 = nullptr;   // device: split-bf16 weight tables of conv1_s3_kernel: w and w / 255 (conv1.hip:conv1_split_tables)

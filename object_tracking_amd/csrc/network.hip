@@ -50,13 +50,21 @@ static void graphs_clear(dt_ctx *ctx)
 // Runs `body` (a sequence of launches on ctx->stream that touches library-owned buffers only), as a replayed
 // hipGraph when graphs are on: first sighting of `key` runs plainly (allocates workspaces, one-time kernel
 // attribute calls), the second captures on the internal stream and instantiates, later ones replay.
-static int graphed(dt_ctx *ctx, const std::string &key, const std::function<int()> &body)
+//   in_tensor: the tensor the sequence reads from outside (or null).  A replay runs no host code, so what the host knows about a tensor's
+//   max |x| when the graph is captured must hold at every replay: the tag of `in_tensor` -- "its producer, which ran just before in this
+//   call, published into slot s" -- is kept and becomes part of the key (another precondition, another graph); every other tag is dropped,
+//   i.e. the sequence measures whatever else it reads itself.  What the sequence leaves behind is re-applied on replay.
+static int graphed(dt_ctx *ctx, const std::string &key_in, const std::function<int()> &body, const float *in_tensor = nullptr)
 {
     if (!ctx->graph_on || ctx->prof || ctx->capturing) return body();
     hipStream_t user = ctx->stream;
-    // a graphed sequence measures the max |x| of whatever it reads from outside ITSELF (a replay runs no host code: what the host knew at
-    // capture time may not hold then); what it leaves behind is re-applied on replay
-    ctx->amax_tag.clear();
+    std::string key = key_in;
+    {
+        std::vector<dt_ctx::AmaxTag> keep;
+        for (const auto &t : ctx->amax_tag)
+            if (in_tensor && t.lo == in_tensor) { keep.push_back(t); key += ":am" + std::to_string(t.slot) + "c" + std::to_string(t.cols); }
+        ctx->amax_tag.swap(keep);
+    }
     auto it = ctx->graphs.find(key);
     if (it == ctx->graphs.end()) {
         int &seen = ctx->graph_seen[key];
@@ -168,7 +176,7 @@ static void s3_drop(dt_ctx *ctx, const void *wino)
 enum { AMAX_ONE = 0, AMAX_IN = 32, AMAX_TRK = 56, AMAX_TEST = 57, AMAX_PACK = 64 };
 static unsigned *amax_slot(dt_ctx *ctx, int slot) { return ctx->amax ? ctx->amax + (size_t)slot * DT_AMAX_SUB : nullptr; }
 // every API entry that runs layers starts here: what a previous call knew about a tensor's maximum says nothing about the bytes behind the pointer now
-static void amax_reset(dt_ctx *ctx) { ctx->amax_tag.clear(); }
+static void amax_reset(dt_ctx *ctx) { ctx->amax_tag.clear(); ctx->h2_small = false; }
 // the slot that holds max |x| of the rows x cols tensor at x: the one its producer filled (tagged), else measured here into `slot`
 // a layer is about to write `floats` floats from `lo` on: what was known about tensors in that range is void
 static void amax_forget(dt_ctx *ctx, const float *lo, long long floats)
@@ -207,7 +215,7 @@ static const unsigned *ensure_amax(dt_ctx *ctx, const float *x, long long rows, 
     return s;
 }
 // does this launch take the fp16 form of the split GEMM?  (DT_PIN keeps the bf16 form: see Policy::s3_h2)
-static bool h2_wanted(const dt_ctx *ctx) { return ctx->pol.s3 != 0 && ctx->pol.s3_h2 != 0 && !ctx->pol.pin; }
+static bool h2_wanted(const dt_ctx *ctx) { return ctx->pol.s3 != 0 && ctx->pol.s3_h2 != 0 && !ctx->pol.pin && !ctx->h2_small; }
 
 static int upload(dt_ctx *ctx, float **dst, const std::vector<float> &h)
 {
@@ -644,6 +652,7 @@ void policy_from_env(Policy &p, int pin_override)
     p.s3_rec_minrows = geti("DT_S3_REC_MINROWS", d.s3_rec_minrows);
     p.s3_half = geti("DT_S3_HALF", d.s3_half);
     p.s3_h2 = geti("DT_S3_H2", d.s3_h2);
+    p.h2_minframes = geti("DT_H2_MINFRAMES", d.h2_minframes);
     p.persist = geti("DT_PERSIST", d.persist);
     p.xcd_remap = geti("DT_XCD_REMAP", d.xcd_remap);
     p.tile_gn = geti("DT_TILE_GN", d.tile_gn);
@@ -1223,6 +1232,7 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
     float *cat = ws_get(ctx, "cat", (size_t)B * (H / 32) * (W / 32) * 1280 * sizeof(float));
     if (!bufA || !bufB || !skip || !cat) return DT_ERR_DEVICE;
     ctx->last_batch = B;
+    ctx->h2_small = B < ctx->pol.h2_minframes;
     {   // dt_detector_tap may only hand out 'feat' / 'netout' if THIS forward wrote the library-owned workspaces
         auto owned = [&](const char *name, const float *p) {
             auto it = ctx->ws.find(name);
@@ -1251,7 +1261,7 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
     const int h = H / 32, w = W / 32;
     int rc = graphed(ctx, "trunk:" + std::to_string(B), [&]() -> int {   // conv_2 .. conv_21: library-owned buffers only
         return run_trunk(ctx, B, bufA, bufB, skip, cat, nullptr);
-    });
+    }, bufA);
     if (rc) return rc;
     // conv_22 -> 'conv_feat'
     rc = run_conv(ctx, ctx->layers[22], cat, 1280, B, h, w, feat.p, feat.ld, ORD_LINEAR, EPI_PLAIN, LEAKY);
@@ -1575,6 +1585,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
                              const float *wx_wino = nullptr, const float *wh_wino = nullptr, float *xproj_ext = nullptr)
 {
     const int GG = gh * gw, F = n_clips * T, N4 = 4 * U;
+    ctx->h2_small = F < ctx->pol.h2_minframes;
     float *xproj = xproj_ext ? xproj_ext : ws_get(ctx, "trk_xproj", (size_t)F * GG * N4 * sizeof(float));
     float *cst = hseq ? ws_get(ctx, "trk_c", (size_t)n_clips * GG * U * sizeof(float)) : nullptr;
     if (!xproj || (hseq && !cst)) return DT_ERR_DEVICE;
@@ -1670,7 +1681,7 @@ static int convlstm_sequence(dt_ctx *ctx, const float *z, int Cx, int n_clips, i
         return graphed(ctx, "clstm:" + shape, [&]() -> int {
             const int rc = input_projection();
             return rc ? rc : recurrence();
-        });
+        }, z);
     const int rc = input_projection();
     return rc ? rc : graphed(ctx, "clstm_steps:" + shape, recurrence);
 }

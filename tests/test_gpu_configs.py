@@ -539,7 +539,7 @@ def test_configs3_tinytracker_T64_vs_oracle():
         ref[:, t] = orc.dense_sigmoid(h, tw["dense_kernel"], tw["dense_bias"])
     e_t = [float(np.abs(got[:, t] - ref[:, t]).max()) for t in range(T)]
     assert max(e_t) < 1e-4
-    _report("parity_r04_tiny64.json", dict(config="TinyTracker 32 sequences x T=64 @416", frames_with_box=int(nbox),
+    _report("parity_r06_tiny64.json", dict(config="TinyTracker 32 sequences x T=64 @416", frames_with_box=int(nbox),
                                            out_err_t0=e_t[0], out_err_t31=e_t[31], out_err_t63=e_t[63], out_err_max=max(e_t)))
 
 
@@ -565,5 +565,5 @@ def test_configs1_detector_batch8_vs_oracle_and_f64_graph(golden_dir):
     e64_oracle = chan_err(ref_net[:1].reshape(1, 13, 13, -1), d["netout"].reshape(1, 13, 13, -1))
     assert e_net < 3e-4 and e_feat < 3e-4
     assert e64 < 3e-4, "HIP path vs float64 graph: %g (oracle vs float64: %g)" % (e64, e64_oracle)
-    _report("parity_r04_detect8.json", dict(netout_chan_err_vs_oracle=e_net, feat_chan_err_vs_oracle=e_feat,
+    _report("parity_r06_detect8.json", dict(netout_chan_err_vs_oracle=e_net, feat_chan_err_vs_oracle=e_feat,
                                             netout_chan_err_vs_f64_graph=e64, oracle_vs_f64_graph=e64_oracle))

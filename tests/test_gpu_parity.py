@@ -1259,6 +1259,7 @@ def test_detector_non_square_odd_grid_vs_oracle(ctx, monkeypatch, mode):
         monkeypatch.setenv("DT_WINO_FUSED4", "2")
     if mode == "direct_h2":
         monkeypatch.setenv("DT_C3H2", "2")           # conv_2 / 3 / 5 on conv3_h2.hip at this small batch too, inside the whole network
+        monkeypatch.setenv("DT_H2_MINFRAMES", "0")
     det, layers, _ = _detector(ctx, 352, 288, 12)
     frames = synth.synth_clip(5, 352, 288, 3, seed=21)
     ref_net, ref_feat, _ = orc.yolov2_forward(orc.normalize_u8(frames), layers)
@@ -1600,6 +1601,52 @@ def test_h2_scale_follows_the_data(ctx, monkeypatch, k):
         ref = orc.conv2d(xs[:2], w)
         assert np.abs(got[1] - ref[1]).max() < bar * np.abs(ref[1]).max(), (e, np.abs(got[1] - ref[1]).max() / np.abs(ref[1]).max())
         assert np.abs(got[0] - ref[0]).max() < 1e-3 * np.abs(ref[0]).max()      # (F(6x6) itself cancels spike-sized numbers in that tile)
+
+
+def test_split_bf16_default_policy_engages_on_deep_layers(ctx, monkeypatch):
+    """Default policy (DT_S3=1): K >= 256 and >= 2048 GEMM rows take the split form, short K / few rows stay on fp32 MFMA."""
+    monkeypatch.delenv("DT_S3", raising=False)
+    rs = np.random.RandomState(11)
+    for (B, H, W, Cin, Cout), want in (((384, 13, 13, 256, 256), 1), ((8, 13, 13, 256, 256), 0), ((96, 26, 26, 128, 256), 0)):
+        x, w, b = _conv_case(rs, B, H, W, Cin, Cout)
+        ctx.profile_reset(); ctx.profile_enable(True)
+        got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=0)
+        ctx.profile_enable(False)
+        assert ctx.profile_read("conv_gemm_s3")["launches"] == want, (B, H, W, Cin, Cout)
+        ref = orc.conv2d(x[:2], w, b)
+        ref = np.where(ref > 0, ref, ref * np.float32(0.1)).astype(np.float32)
+        assert relerr(got[:2].cpu().numpy(), ref) < 2e-4
+
+
+def test_split_bf16_handover_to_1x1_layers(ctx, monkeypatch):
+    """conv_7, 10, 12, 15, 17 (and conv_23: ragged N = 85, unaligned output rows) as split GEMMs straight on the producing layer's fp32 activation (DT_S3_1X1=1, the default: the kernel
+    splits its A fragments itself, bias as an extra K stage, LeakyReLU in its epilogue) against the same network with those layers
+    on the fp32 MFMA kernel, and against the oracle on the frames the oracle is run on."""
+    B, H, W, C = 16, 416, 416, 12
+    frames = np.random.RandomState(3).randint(0, 256, (B, H, W, 3)).astype(np.uint8)
+    outs = {}
+    layers = None
+    for mode in ("1", "b", "0"):      # fp16 form (default) / bf16 form / fp32 MFMA
+        monkeypatch.setenv("DT_S3_H2", "0" if mode == "b" else "1")
+        monkeypatch.setenv("DT_H2_MINFRAMES", "0")     # (the default policy takes the fp16 form from 32 frames per forward)
+        monkeypatch.setenv("DT_S3_1X1", "0" if mode == "0" else "1")          # read when the context is created (dt_create)
+        monkeypatch.setenv("DT_S3_1X1_MINK", "256")    # (the default)
+        monkeypatch.setenv("DT_S3_1X1_MINROWS", "0")   # (the default policy takes these layers from 16384 pixels per launch)
+        det, layers, _ = _detector(ctx, H, W, C, seed=77)
+        c = det.model.ctx
+        c.profile_reset(); c.profile_enable(True)
+        outs[mode] = c.detect_forward(dev(frames, c)).cpu().numpy()
+        c.profile_enable(False)
+        hand = sorted(int(n.split("_")[-1]) for n in c.profile_names() if n.startswith("conv_gemm_s3:conv_") and c.profile_read(n)["launches"]
+                      and int(n.split("_")[-1]) in (4, 7, 10, 12, 15, 17, 21, 23))
+        # (conv_23 joins since round 5: the row-form epilogue stores 4 bytes per lane, so the netout's 85-float rows need no alignment)
+        assert hand == ([7, 10, 12, 15, 17, 23] if mode != "0" else []), hand
+        assert c.profile_read("wino_output:conv_14")["launches"] == 1
+        assert (c.profile_read("s3_form:f16x2")["launches"] > 0) == (mode != "b") and (c.profile_read("s3_form:bf16x3")["launches"] > 0) == (mode == "b")
+    assert chan_err(flat_c(outs["1"]), flat_c(outs["0"])) < 1e-4          # two roundings of the same network (measured 5e-5)
+    assert chan_err(flat_c(outs["b"]), flat_c(outs["0"])) < 1e-4
+    ref_net, _, _ = orc.yolov2_forward(orc.normalize_u8(frames[:2]), layers, taps=())
+    assert chan_err(flat_c(outs["1"][:2]), flat_c(ref_net)) < NET_TOL
 
 
 @pytest.mark.parametrize("tile", ["", "4"], ids=["projection_F6x6", "recurrent_F4x4"])
