@@ -42,9 +42,17 @@ __device__ __forceinline__ void c3_mfma(c3_f16 &c, const c3_u4 &w, const c3_u4 &
 }
 
 // WN = 1: 64 output channels per workgroup, waves 4 (rows) x 1, tile 16 x 16 pixels.  WN = 2: 128 channels, waves 2 x 2, tile 8 rows x 16.
-template <int WN, bool POOL>
+// FUSE (WN = 2, no pooling: conv_3): the 1x1 layer that follows (conv_4: 128 -> 64, the only reader of this layer's output) is applied to
+// the tile's activations before anything leaves the CU -- the 128-channel tensor (8 GB written, 8 GB read back per 1440 frames) never
+// exists.  After the last tap: y = LeakyReLU(acc * inv + bias) in registers; the tile's own max |y| (a workgroup-local reduction) gives the
+// power of two for y's two fp16 terms -- the second GEMM only ever sees this tile, so its scale need not wait for the tensor's maximum;
+// four more pipeline stages (K = 128 in quarters of 32): the waves that hold a quarter's channels write them to LDS in the A operand's
+// image (the patch region is free: the next patch waits in registers), every wave multiplies its 32 pixels x 64 output channels against
+// the quarter's weights, which came through the same DMA ring as two more "taps" ... four more.
+template <int WN, bool POOL, bool FUSE = false>
 __global__ __launch_bounds__(C3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3_h2_kernel(Conv3H2Args p)
 {
+    static_assert(!FUSE || (WN == 2 && !POOL), "the fused 1x1 follows the 128-channel, un-pooled instance");
     constexpr int WM = 4 / WN;                       // waves along the pixel rows
     constexpr int TH = 4 * WM, TW = 16;              // tile: each wave owns 4 image rows = two MFMA blocks of 2 rows x 16 pixels
     constexpr int BN = 64 * WN;
@@ -58,6 +66,9 @@ __global__ __launch_bounds__(C3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     extern __shared__ __attribute__((aligned(16))) unsigned char c3_lds[];
     unsigned char *patch = c3_lds, *bring = c3_lds + PATCH;
     float *btab = reinterpret_cast<float *>(c3_lds + PATCH + C3_NS * BSTAGE);      // [BN] bias of this workgroup's channel tile ... per item
+    [[maybe_unused]] float *btab1 = btab + BN;        // FUSE: [64] bias of the fused 1x1 | [4] the waves' max |y|
+    constexpr int SPL = 128 * 32;                     // FUSE: bytes of one (half, term) plane of the y scratch (128 pixels x 16 channels)
+    constexpr int BPL1 = 64 * 32;                     // FUSE: ... of a stage of the 1x1's weights (64 rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int rl = lane & 31, gl = lane >> 5;
@@ -163,6 +174,26 @@ __global__ __launch_bounds__(C3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         return pix * 32 + ((gl ^ ((pix >> 3) & 1)) * 16);
     };
 
+    // FUSE: pieces of a stage of the 1x1's weights (a quarter of K: k blocks 2 q, 2 q + 1): 8 of 1 KiB, two per wave
+    [[maybe_unused]] const unsigned short *w1src[2] = {nullptr, nullptr};
+    [[maybe_unused]] int w1dst[2] = {0, 0};
+    if constexpr (FUSE) {
+        const long long w1term = (long long)8 * p.Np1 * 16;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pc = wave * 2 + q, grp = pc & 1, ht = pc >> 1, half = ht >> 1, term = ht & 1;
+            w1src[q] = p.w1 + term * w1term + ((long long)half * p.Np1 + 32 * grp + lrow) * 16 + dgran * 8;
+            w1dst[q] = ht * BPL1 + grp * 1024;
+        }
+        for (int i = tid; i < 64; i += C3_THREADS) btab1[i] = i < p.N1 ? p.bias1[i] : 0.0f;
+    }
+    auto fstage_issue = [&](int buf, int q, int k) {      // piece k (0, 1) of this wave of the 1x1's stage q
+        if constexpr (FUSE)
+            __builtin_amdgcn_global_load_lds((c3_gptr_t *)(w1src[k] + (long long)(2 * q) * p.Np1 * 16), (c3_lptr_t *)(bring + buf * BSTAGE + w1dst[k]), 16, 0, 0);
+    };
+    int sbase = 0;      // FUSE: ring buffer of a unit's tap 0 (an item ends with four more stages: 13 % 3 = 1); otherwise always 0
+    auto bufof = [&](int k) { return FUSE ? (sbase + k) % C3_NS : k % C3_NS; };
+
     // ---- the sequence of units of this workgroup ----
     Unit cur = unit_of(item, 0);
     // prologue: first patch straight in, weight stages 0 and 1 in flight
@@ -201,9 +232,10 @@ __global__ __launch_bounds__(C3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             __builtin_amdgcn_s_barrier();
             // the buffer stage tap - 1 occupied is refilled with stage tap + 2 (of the next unit from tap 7 on) -- its PB pieces one per MFMA slot
             // of the first half's tail (a DMA instruction holds its issuer for 60 - 180 cycles: four at the head of a stage are felt)
-            const bool refill = tap < 7 || has_next;
+            const bool fnext = FUSE && last_chunk && tap >= 7;      // what follows the ninth tap is the fused 1x1's first stages
+            const bool refill = tap < 7 || (has_next && !fnext);
             const long long roff = tap < 7 ? stage_off(cur.n0, cur.chunk, tap + 2) : stage_off(nxt.n0, nxt.chunk, tap - 7);
-            const unsigned char *sb = bring + (tap % C3_NS) * BSTAGE, *sn = bring + ((tap + 1) % C3_NS) * BSTAGE;
+            const unsigned char *sb = bring + bufof(tap) * BSTAGE, *sn = bring + bufof(tap + 1) * BSTAGE;
             if (tap == 0) {      // a unit's first stage reads its own first fragments (the patch was just turned over)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -238,7 +270,8 @@ __global__ __launch_bounds__(C3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                             else fb[0][blk][t] = *reinterpret_cast<const c3_u4 *>(sn + t * BPL + offB[blk]);
                         }
                     }
-                    if (hf == 0 && m >= 8 && m - 8 < PB && refill) piece_issue((tap + 2) % C3_NS, roff, m - 8);
+                    if (hf == 0 && m >= 8 && m - 8 < PB && refill) piece_issue(bufof(tap + 2), roff, m - 8);
+                    if (FUSE && hf == 0 && m >= 8 && m - 8 < 2 && fnext) fstage_issue(bufof(tap + 2), tap - 7, m - 8);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // the next unit's patch: requested behind the weight pieces of stage 0 (the newest operations in flight at stage 1's wait)
@@ -249,7 +282,106 @@ __global__ __launch_bounds__(C3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         stage(std::integral_constant<int, 3>{}); stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
         stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{}); stage(std::integral_constant<int, 8>{});
 
-        if (last_chunk) {
+        if (FUSE && last_chunk) {
+            // ---- the fused 1x1 (see the kernel's header) ----
+            float am = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float bl = btab[wn * 64 + 32 * j + rl];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float z = __builtin_fmaf(acc[j][i][e], inv, bl);
+                        const float y = fmaxf(z, z * p.slope);
+                        acc[j][i][e] = y;
+                        am = fmaxf(am, fabsf(y));
+                    }
+            }
+#pragma unroll
+            for (int o = 32; o; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+            if (lane == 0) btab1[64 + wave] = am;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();      // (also: every wave has finished reading the patch -- its region becomes the y scratch)
+            const float tmax = fmaxf(fmaxf(btab1[64], btab1[65]), fmaxf(btab1[66], btab1[67]));
+            const unsigned tb = __float_as_uint(tmax);
+            const float f1 = dt_h2_base(tb), inv1 = p.pscale1[0] * dt_h2_base_inv(tb);
+            c3_f16 acc2[2];
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[jn][e] = 0.0f;
+            const int prow = 32 * wave + rl;                                        // this lane's pixel row of the scratch as an A operand
+            const int offS = prow * 32 + ((gl ^ ((prow >> 3) & 1)) * 16);
+            int offB1[2];
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) { const int n = 32 * jn + rl; offB1[jn] = (2 * n + (gl ^ ((n >> 3) & 1))) * 16; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (wn == (q >> 1)) {      // this wave holds the quarter's 32 channels (its block j = q & 1): lane = channel, 16 rows per block
+                    const int j = q & 1, half = rl >> 4, g = (rl >> 3) & 1;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int pp = 64 * wm + 32 * i + 8 * (r >> 2) + 4 * gl + (r & 3);
+                            const float x = acc[j][i][r] * f1;
+                            const _Float16 hi = (_Float16)x;
+                            const _Float16 lo = (_Float16)(x - (float)hi);
+                            unsigned char *dst = patch + (half * 2) * SPL + pp * 32 + ((g ^ ((pp >> 3) & 1)) * 16) + (rl & 7) * 2;
+                            *reinterpret_cast<_Float16 *>(dst) = hi;
+                            *reinterpret_cast<_Float16 *>(dst + SPL) = lo;
+                        }
+                }
+                c3_wait_vm<0>();                             // the quarter's weights (and everything else in flight) have landed
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+                // two stages ahead: the 1x1's quarters 2, 3, then the next unit's taps 0, 1
+                if (q < 2) { fstage_issue(bufof(11 + q), q + 2, 0); fstage_issue(bufof(11 + q), q + 2, 1); }
+                else if (has_next) stage_issue(bufof(11 + q), nxt.n0, nxt.chunk, q - 2);
+                const unsigned char *sq = bring + bufof(9 + q) * BSTAGE;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    c3_u4 a2[2], b2[2][2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) a2[t] = *reinterpret_cast<const c3_u4 *>(patch + (hf * 2 + t) * SPL + offS);
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) b2[jn][t] = *reinterpret_cast<const c3_u4 *>(sq + (hf * 2 + t) * BPL1 + offB1[jn]);
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) c3_mfma(acc2[jn], b2[jn][1], a2[0]);
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) c3_mfma(acc2[jn], b2[jn][0], a2[1]);
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn) c3_mfma(acc2[jn], b2[jn][0], a2[0]);
+                }
+                if (q < 3) {                                 // the scratch is rewritten for the next quarter
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            sbase = (sbase + 13) % C3_NS;
+            // the 1x1's epilogue: lane holds channel 32 jn + rl of pixel rows m of block `wave` = (wm' = wave >> 1, i' = wave & 1)
+            const int yb = cur.ty0 + 4 * (wave >> 1) + 2 * (wave & 1);
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const int n = 32 * jn + rl;
+                const float b1 = btab1[n];
+                const bool nok = n < p.N1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = 8 * (r >> 2) + 4 * gl + (r & 3);
+                    const int y = yb + (m >> 4), x = cur.tx0 + (m & 15);
+                    const float z = __builtin_fmaf(acc2[jn][r], inv1, b1);
+                    const float v = fmaxf(z, z * p.slope1);
+                    if (nok && y < p.H && x < p.W) {
+                        if (p.amax_out) out_am = fmaxf(out_am, fabsf(v));
+                        __builtin_nontemporal_store(v, p.out + (long long)cur.b * p.out_bs + ((long long)y * p.W + x) * p.out_ld + n);
+                    }
+                }
+            }
+        } else if (last_chunk) {
             // ---- epilogue: lane holds channel n0 + 64 wn + 32 j + rl of rows m = 8 (r >> 2) + 4 gl + (r & 3) of block i:
             //      image row 4 wm + 2 i + (m >> 4), column m & 15 ----
 #pragma unroll
@@ -308,7 +440,8 @@ __global__ __launch_bounds__(C3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 bool conv3_h2_usable(const Conv3H2Args &a)
 {
     return a.Cin % 32 == 0 && a.Cin >= 32 && a.N >= 64 && a.N % 64 == 0 && a.Np % 64 == 0 && a.in_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
-           a.w && a.pscale && a.amax && a.bias && a.zeros && (a.out != nullptr) != (a.out2 != nullptr) && (!a.out2 || !((a.H | a.W) & 1));
+           a.w && a.pscale && a.amax && a.bias && a.zeros && (a.out != nullptr) != (a.out2 != nullptr) && (!a.out2 || !((a.H | a.W) & 1)) &&
+           (!a.w1 || (a.N == 128 && a.out && a.pscale1 && a.bias1 && a.N1 > 0 && a.N1 <= 64 && a.Np1 >= 64 && a.Np1 % 32 == 0));
 }
 // executed fp16 MFMA FLOPs of one launch (three products per multiply, whole tiles)
 double conv3_h2_flops(const Conv3H2Args &a)
@@ -316,17 +449,17 @@ double conv3_h2_flops(const Conv3H2Args &a)
     const bool wide = a.N % 128 == 0;
     const int th = wide ? 8 : 16;
     const double tiles = (double)a.B * ((a.H + th - 1) / th) * ((a.W + 15) / 16);
-    return 6.0 * tiles * th * 16 * 9.0 * a.Cin * a.N;
+    return 6.0 * tiles * th * 16 * (9.0 * a.Cin * a.N + (a.w1 ? (double)a.N * 64 : 0.0));      // (+ the fused 1x1: N x 64 per pixel)
 }
 
-template <int WN, bool POOL>
+template <int WN, bool POOL, bool FUSE = false>
 static int c3_launch(hipStream_t st, const Conv3H2Args &a, int cus)
 {
     constexpr int TH = 16 / WN, BN = 64 * WN;
-    const size_t lds = (size_t)4 * (TH + 2) * C3_PW * 32 + (size_t)C3_NS * 4 * BN * 32 + BN * 4;
+    const size_t lds = (size_t)4 * (TH + 2) * C3_PW * 32 + (size_t)C3_NS * 4 * BN * 32 + BN * 4 + (FUSE ? 68 * 4 : 0);
     static PerDeviceOnce attr;
     if (attr.ensure(nullptr, [&](int) {
-            return hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h2_kernel<WN, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess;
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(conv3_h2_kernel<WN, POOL, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess;
         }))
         return 1;
     Conv3H2Args p = a;
@@ -335,7 +468,7 @@ static int c3_launch(hipStream_t st, const Conv3H2Args &a, int cus)
     const long long items = (long long)a.B * p.tiles_x * p.tiles_y * ((a.N + BN - 1) / BN);
     long long grid = 2ll * cus;      // two workgroups per CU, persistent over the items
     if (grid > items) grid = items;
-    hipLaunchKernelGGL((conv3_h2_kernel<WN, POOL>), dim3((unsigned)grid), dim3(C3_THREADS), lds, st, p);
+    hipLaunchKernelGGL((conv3_h2_kernel<WN, POOL, FUSE>), dim3((unsigned)grid), dim3(C3_THREADS), lds, st, p);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -354,6 +487,7 @@ int launch_conv3_h2(hipStream_t st, const Conv3H2Args &a)
         return 1;
     const int cus = cu_of[dev];
     const bool wide = a.N % 128 == 0, pool = a.out2 != nullptr;
+    if (a.w1) return c3_launch<2, false, true>(st, a, cus);
     if (wide) return pool ? c3_launch<2, true>(st, a, cus) : c3_launch<2, false>(st, a, cus);
     return pool ? c3_launch<1, true>(st, a, cus) : c3_launch<1, false>(st, a, cus);
 }

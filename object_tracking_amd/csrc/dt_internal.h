@@ -180,6 +180,13 @@ struct Conv3H2Args {
     const float *zeros;        // >= 16 B of device zeros: where the loads of out-of-image patch pixels point
     unsigned *amax_out;        // non-null: max |x| of the stored outputs into this slot
     int tiles_x, tiles_y;      // set by the launcher
+    // the 1x1 layer fused behind (N = 128, no pooling: conv_3 -> conv_4): non-null w1 = apply it to the tile before anything is stored; `out` then is ITS
+    // output [..][N1] (out_ld / out_bs describe it), amax_out its maximum
+    const unsigned short *w1;  // two fp16 terms of the scaled 1x1 weights [2][N / 16][Np1][16]
+    const float *pscale1;      // [1]
+    const float *bias1;        // [N1]
+    int N1, Np1;               // N1 <= 64 output channels, Np1 rows in w1
+    float slope1;
 };
 int launch_conv3_h2(hipStream_t st, const Conv3H2Args &a);
 bool conv3_h2_usable(const Conv3H2Args &a);
@@ -407,6 +414,7 @@ struct Policy {
                              //           matrix-pipe work and 4 instead of 6 bytes per operand element; wino_gemm_s3.hip) -- wherever the bf16 form would run; 0 = three
                              //           bf16 terms / six products (round 3).  Read at weight load (the fp16 terms are built then) and per launch.  DT_PIN takes the
                              //           bf16 form: the fp16 form's scale is the batch's max |x|, so its rounding of small elements depends on the batch
+    int c3fuse = 1;          // DT_C3FUSE: conv_4 (1x1, 128 -> 64) applied inside conv_3's direct kernel (conv3_h2.hip, FUSE): one launch, no 128-channel tensor; 0 = two launches
     int h2_minframes = 32;   // DT_H2_MINFRAMES: a forward of fewer frames takes round 5's forms (bf16 terms, fused fp32 kernel) and its producers publish no max |x|:
                              //                  at batch 8 the publications (a dependent load + atomic at the tail of 40-us kernels) and the one stand-alone absmax pass
                              //                  cost 0.16 ms of a 1.26 ms forward and the fp16 form has nothing to win there (weights-bound GEMMs on the fp32 kernel)

@@ -637,6 +637,7 @@ void policy_from_env(Policy &p, int pin_override)
     p.mosaic = geti("DT_WINO_MOSAIC", d.mosaic);
     p.fused4 = geti("DT_WINO_FUSED4", d.fused4);
     p.c3h2 = geti("DT_C3H2", d.c3h2);
+    p.c3fuse = geti("DT_C3FUSE", d.c3fuse);
     p.wino_cfg = geti("DT_WINO_CFG", d.wino_cfg);
     p.wino_gn = geti("DT_WINO_GN", d.wino_gn);
     p.ksplit = geti("DT_KSPLIT", d.ksplit);
@@ -1162,6 +1163,42 @@ static int extract_layer(dt_ctx *ctx, const ConvLayer &L, const float *in, int i
     return DT_OK;
 }
 
+// conv_3 and the 1x1 conv_4 behind it as ONE launch of conv3_h2.hip (its FUSE instance: the 128-channel tensor between them never exists): where
+// conv_3 would take the direct fp16-form kernel anyway, conv_4 is a 128 -> <= 64 channel 1x1 layer with fp16-form weights, and DT_C3FUSE is on
+static bool conv34_fusable(const dt_ctx *ctx, const ConvLayer &L3, const ConvLayer &L4, const float *in, int in_ld, int B, int H, int W)
+{
+    const long long blocks = (long long)B * ((H + 15) / 16) * ((W + 15) / 16);
+    return ctx->pol.c3fuse != 0 && L3.ks == 3 && L3.w3_h2 && L3.pscale_w3 && L3.cout == 128 && L4.ks == 1 && L4.cin == 128 && L4.cout <= 64 && L4.wt_h2 && L4.pscale_h2 &&
+           ctx->pol.c3h2 != 0 && h2_wanted(ctx) && in_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (ctx->pol.c3h2 == 2 || blocks >= 1024);
+}
+static int run_conv34_fused(dt_ctx *ctx, const ConvLayer &L3, const ConvLayer &L4, const float *in, int in_ld, int B, int H, int W, float *out, int out_ld, float slope)
+{
+    const long long M = (long long)B * H * W;
+    amax_forget(ctx, out, M * out_ld);
+    Conv3H2Args c;
+    memset(&c, 0, sizeof(c));
+    c.in = in; c.in_bs = (long long)H * W * in_ld; c.in_ld = in_ld; c.B = B; c.H = H; c.W = W; c.Cin = L3.cin; c.N = L3.cout; c.Np = L3.npad;
+    c.w = L3.w3_h2; c.pscale = L3.pscale_w3; c.bias = L3.bias; c.slope = slope;
+    c.w1 = L4.wt_h2; c.pscale1 = L4.pscale_h2; c.bias1 = L4.bias; c.N1 = L4.cout; c.Np1 = L4.npad; c.slope1 = slope;
+    c.out = out; c.out_ld = out_ld; c.out_bs = (long long)H * W * out_ld;
+    c.zeros = ws_get(ctx, "zeros256", 256, /*zero_on_grow=*/true);
+    if (!c.zeros) return DT_ERR_DEVICE;
+    c.amax = ensure_amax(ctx, in, M, L3.cin, in_ld, AMAX_IN + L3.idx);
+    if (!c.amax) return DT_ERR_DEVICE;
+    if (amax_out_slot(L4)) c.amax_out = amax_slot(ctx, amax_out_slot(L4));
+    char tag[32];
+    snprintf(tag, sizeof(tag), "conv_%d", L3.idx);
+    if (ctx->prof && !ctx->capturing) ctx->prof_tab["conv_direct_h2:fused_1x1"].launches += 1;
+    // bytes: conv_3's input once (+ 41 % halo), conv_4's output; direct form: both layers
+    ProfScope ps(ctx, "conv_direct_h2", conv3_h2_flops(c), 4.0 * ((double)M * L3.cin * 1.41 + (double)M * L4.cout), tag);
+    prof_direct_form(ctx, 2.0 * M * (9.0 * L3.cin * L3.cout + (double)L4.cin * L4.cout),
+                     4.0 * ((double)M * L3.cin + 9.0 * L3.cin * L3.cout + 2.0 * (double)M * L3.cout + (double)L4.cin * L4.cout + (double)M * L4.cout), DF_C3H2);
+    const int rc = launch_conv3_h2(ctx->stream, c);
+    if (rc) return dt_fail(ctx, rc == 2 ? DT_ERR_ARG : DT_ERR_DEVICE, "%s: fused direct 3x3 + 1x1 launch failed", tag);
+    if (c.amax_out) amax_note(ctx, out, M * out_ld, L4.cout, amax_out_slot(L4));
+    return DT_OK;
+}
+
 // conv_2 .. conv_21 on the library-owned buffers (bufA holds conv_1's pooled output).  With `ex` the walk stops at
 // the requested layer and writes it to ex->out instead.
 static int run_trunk(dt_ctx *ctx, int B, float *bufA, float *bufB, float *skip, float *cat, Extract *ex)
@@ -1175,6 +1212,14 @@ static int run_trunk(dt_ctx *ctx, int B, float *bufA, float *bufB, float *skip, 
         const int idx = TRUNK[li][0], pool = TRUNK[li][4];
         const ConvLayer &L = ctx->layers[idx];
         if (ex && ex->idx == idx && ex->kind <= EX_ACT) return extract_layer(ctx, L, cur, L.cin, B, h, w, *ex);
+        if (idx == 3 && !ex && TRUNK[li + 1][0] == 4 && conv34_fusable(ctx, L, ctx->layers[4], cur, L.cin, B, h, w)) {
+            // conv_3 + conv_4 in one launch: conv_4's output goes to `nxt`, one swap, conv_4's turn of the walk is skipped
+            rc = run_conv34_fused(ctx, L, ctx->layers[4], cur, L.cin, B, h, w, nxt, ctx->layers[4].cout, LEAKY);
+            if (rc) return rc;
+            float *t = cur; cur = nxt; nxt = t;
+            ++li;                      // conv_4 is done
+            continue;
+        }
         if (idx == 13) {   // skip tapped before the pool (KerasYOLO.py:347)
             rc = run_conv(ctx, L, cur, L.cin, B, h, w, skip, 512, ORD_QUAD, EPI_POOL_BOTH, LEAKY, nxt, 512);
         } else if (idx == 20) {   // writes channels [256,1280) of the concat buffer (KerasYOLO.py:391)

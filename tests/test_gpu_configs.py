@@ -433,7 +433,7 @@ def test_configs2_bench_size_48_clips_vs_oracle():
     ctx.profile_enable(False)
     names = set(ctx.profile_names())
     for want in S3_BENCH_LAUNCHES + ["conv_direct_h2:conv_2", "conv_direct_h2:conv_3", "conv_direct_h2:conv_5", "s3_tile:128x2", "s3_tile:256",
-                                     "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4", "conv_igemm:conv_4", "conv_igemm:conv_21"]:
+                                     "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4", "conv_direct_h2:fused_1x1", "conv_igemm:conv_21"]:
         assert want in names, "%s did not run; ran: %s" % (want, sorted(n for n in names if ":" in n))
     assert ctx.profile_read("conv_gemm_s3:convlstm_step")["launches"] == T - 1
     assert ctx.profile_read("s3_tile:128x2")["launches"] == T - 1      # the recurrent step only (588 rows = 5 x 128)

@@ -1268,7 +1268,16 @@ def test_detector_non_square_odd_grid_vs_oracle(ctx, monkeypatch, mode):
     net, feat = c.detect_forward(dev(frames, c), want_feat=True)
     c.profile_enable(False)
     if mode == "direct_h2":
-        assert c.profile_read("conv_direct_h2")["launches"] == 3
+        # conv_2, conv_3 (+ conv_4 inside it: no conv_4 launch of any family), conv_5
+        assert c.profile_read("conv_direct_h2")["launches"] == 3 and c.profile_read("conv_direct_h2:fused_1x1")["launches"] == 1
+        assert not [n for n in c.profile_names() if n.endswith(":conv_4")]
+        monkeypatch.setenv("DT_C3FUSE", "0")
+        c.reload_policy()
+        c.profile_reset(); c.profile_enable(True)
+        net2, feat2 = c.detect_forward(dev(frames, c), want_feat=True)
+        c.profile_enable(False)
+        assert c.profile_read("conv_direct_h2:fused_1x1")["launches"] == 0 and c.profile_read("conv_igemm:conv_4")["launches"] == 1
+        assert chan_err(flat_c(net.cpu().numpy()), flat_c(net2.cpu().numpy())) < 5e-5      # the same network, conv_4 in its own launch
     assert net.shape == (5, 11, 9, 5, 17)
     assert chan_err(flat_c(net.cpu().numpy()), flat_c(ref_net)) < NET_TOL
     assert chan_err(feat.cpu().numpy(), ref_feat) < NET_TOL
@@ -1642,7 +1651,7 @@ def test_split_bf16_handover_to_1x1_layers(ctx, monkeypatch):
         # (conv_23 joins since round 5: the row-form epilogue stores 4 bytes per lane, so the netout's 85-float rows need no alignment)
         assert hand == ([7, 10, 12, 15, 17, 23] if mode != "0" else []), hand
         assert c.profile_read("wino_output:conv_14")["launches"] == 1
-        assert (c.profile_read("s3_form:f16x2")["launches"] > 0) == (mode != "b") and (c.profile_read("s3_form:bf16x3")["launches"] > 0) == (mode == "b")
+        assert (c.profile_read("s3_form:f16x2")["launches"] > 0) == (mode == "1") and (c.profile_read("s3_form:bf16x3")["launches"] > 0) == (mode == "b")
     assert chan_err(flat_c(outs["1"]), flat_c(outs["0"])) < 1e-4          # two roundings of the same network (measured 5e-5)
     assert chan_err(flat_c(outs["b"]), flat_c(outs["0"])) < 1e-4
     ref_net, _, _ = orc.yolov2_forward(orc.normalize_u8(frames[:2]), layers, taps=())
