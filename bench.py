@@ -24,10 +24,11 @@ low-frequency backgrounds with moving rectangles.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline     -- achieved / peak / frac / traffic of the DOMINANT kernel family (the one with the most HIP-event
-                  time inside the timed region; with the default policy wino_gemm_s3_kernel: executed bf16 MFMA
-                  FLOPs against the 2.5 PFLOP/s dense bf16 peak of MI355X), and under roofline.families one
-                  self-contained block per conv kernel family (wino_gemm_s3 / conv_igemm_f32 against the 157.3
-                  TFLOP/s fp32 matrix peak / wino4s_fused / conv1_mfma): launches, time, executed and
+                  time inside the timed region; with the default policy wino_gemm_s3_kernel: executed fp16 MFMA
+                  FLOPs -- three per fp32 multiply-add of two-term split operands -- against the 2.5 PFLOP/s dense
+                  16-bit peak of MI355X), and under roofline.families one self-contained block per conv kernel family
+                  (wino_gemm_s3 / conv3_h2 / conv_igemm_f32 against the 157.3 TFLOP/s fp32 matrix peak / wino4s_fused /
+                  conv1_mfma): launches, time, executed and
                   direct-form FLOPs of the layers THOSE launches computed, bytes, PMC traffic
   cpu_baseline -- the CPU oracle ("port") timed on a bounded sample on this host.
 """
