@@ -108,6 +108,8 @@ struct WinoArgs {
     int B, H, W, th, tw, Mt, ts;
     int g;   // frames per side of the virtual mosaic the tiles live on (1: one frame; winograd.hip:vpixel)
     int coop;  // F(6x6) lane-cooperative transform kernels: -1 small launches only (default), 0 never, 1 always (Policy::wino_coop)
+    int grid_in, grid_out, thr_out;   // A/B knobs (Policy::wino_grid_in / wino_grid_out / wino_thr_out): workgroup cap of the big input / output transform launches
+                                      // and the output kernel's workgroup size; 0 = the built-in choice
     // input transform: in (NHWC, pixel stride in_ld, image stride in_bs), C channels -> v [P][Mt][C]
     const float *in;
     long long in_bs;
@@ -403,6 +405,7 @@ struct Policy {
                              //          (where the fused F(4x4) fp32 kernel ran until round 5); 0 = the fused kernel; 2 = at any size (parity tests).  Needs the fp16
                              //          form (DT_S3_H2, not DT_PIN).  Read at weight load (0: no fp16 copy of the weights) and per launch
     int wino_cfg = -1, wino_gn = -1;   // DT_WINO_CFG / DT_WINO_GN (A/B runs)
+    int wino_grid_in = 0, wino_grid_out = 0, wino_thr_out = 0;   // DT_WINO_GRID_IN / DT_WINO_GRID_OUT / DT_WINO_THR_OUT (A/B runs: WinoArgs::grid_in / grid_out / thr_out)
     int ksplit = 0;          // DT_KSPLIT
     int conv_cfg = -1;       // DT_CONV_CFG
     int s3_conv1 = 1;        // DT_S3_CONV1: conv_1 on the bf16 pipe with split operands (conv1_s3_kernel); 0 = conv1_mfma_kernel (fp32 MFMA)

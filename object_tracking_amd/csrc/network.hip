@@ -640,6 +640,9 @@ void policy_from_env(Policy &p, int pin_override)
     p.c3fuse = geti("DT_C3FUSE", d.c3fuse);
     p.wino_cfg = geti("DT_WINO_CFG", d.wino_cfg);
     p.wino_gn = geti("DT_WINO_GN", d.wino_gn);
+    p.wino_grid_in = geti("DT_WINO_GRID_IN", d.wino_grid_in);
+    p.wino_grid_out = geti("DT_WINO_GRID_OUT", d.wino_grid_out);
+    p.wino_thr_out = geti("DT_WINO_THR_OUT", d.wino_thr_out);
     p.ksplit = geti("DT_KSPLIT", d.ksplit);
     p.conv_cfg = geti("DT_CONV_CFG", d.conv_cfg);
     p.wino_coop = geti("DT_WINO_COOP", d.wino_coop);
@@ -832,6 +835,7 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
     memset(&w, 0, sizeof(w));
     w.B = B; w.H = H; w.W = W; w.ts = ts;
     w.coop = ctx->pol.wino_coop;
+    w.grid_in = ctx->pol.wino_grid_in; w.grid_out = ctx->pol.wino_grid_out; w.thr_out = ctx->pol.wino_thr_out;
     {
         const WinoGeom q = wino_geometry(ctx, ts, B, H, W, io.out2 != nullptr);
         w.g = q.g; w.th = q.th; w.tw = q.tw; w.Mt = q.Mt;

@@ -899,7 +899,10 @@ int launch_wino_input(hipStream_t st, const WinoArgs &a)
     if (a.v_s3 && a.nt == 2) {      // the fp16 form: the cooperative 8-channel producer only
         if ((a.ts != 6 && a.ts != 4) || a.C % 32 || a.Mp < a.Mt || !a.amax) return 2;
         const long long wgs = ((long long)((a.Mt + 3) & ~3) * (a.C / 8) + WINO_S3IN_THREADS / 8 - 1) / (WINO_S3IN_THREADS / 8);
-        const unsigned grid = (unsigned)(wgs < 262144 ? wgs : 262144);
+        // workgroup cap: 24576 (grid-stride beyond) instead of one workgroup per 16 items -- measured in the step on two boxes
+        // (profiles/r06_experiments.txt section 9): 9.84-10.09 -> 9.34-9.45 ms per step for caps of 8192 .. 32768, back to 9.8 at 65536
+        const long long cap = a.grid_in > 0 ? a.grid_in : 24576;
+        const unsigned grid = (unsigned)(wgs < cap ? wgs : cap);
         if (a.ts == 6) hipLaunchKernelGGL((wino_input_s3_kernel<6, 2>), dim3(grid), dim3(WINO_S3IN_THREADS), 0, st, a);
         else hipLaunchKernelGGL((wino_input_s3_kernel<4, 2>), dim3(grid), dim3(WINO_S3IN_THREADS), 0, st, a);
     } else if (a.v_s3 && a.ts == 4) {
@@ -962,9 +965,13 @@ int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates)
         if (a.ts == 6 && wino_coop_wanted(a, (long long)a.Mt * (a.N / 2))) {
             const long long wgs = ((long long)a.Mt * (a.N / 4) + WINO_THREADS / 8 - 1) / (WINO_THREADS / 8);
             hipLaunchKernelGGL(wino_output_coop6_kernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(WINO_THREADS), 0, st, a);
-        } else if (a.ts == 6)
-            hipLaunchKernelGGL((wino_output_kernel<6, 2>), dim3(wino_blocks((long long)a.Mt * (a.N / 2))), dim3(wino_threads((long long)a.Mt * (a.N / 2))),
-                               0, st, a);
+        } else if (a.ts == 6) {
+            const long long items = (long long)a.Mt * (a.N / 2);
+            unsigned th = wino_threads(items), nb = wino_blocks(items);
+            if (th == WINO_THREADS && (a.thr_out == 64 || a.thr_out == 128)) { th = (unsigned)a.thr_out; nb = (unsigned)((items + th - 1) / th < 256 * 32 * (WINO_THREADS / th) ? (items + th - 1) / th : 256 * 32 * (WINO_THREADS / th)); }
+            if (a.grid_out > 0 && nb > (unsigned)a.grid_out) nb = (unsigned)a.grid_out;
+            hipLaunchKernelGGL((wino_output_kernel<6, 2>), dim3(nb), dim3(th), 0, st, a);
+        }
         else if (a.ts == 2)
             hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(wino_blocks((long long)a.Mt * (a.N / 4))), dim3(wino_threads((long long)a.Mt * (a.N / 4))),
                                0, st, a);
