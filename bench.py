@@ -637,8 +637,12 @@ def _run():
         # what a plain streaming kernel reaches on an MI355X of this pool, per traffic mix (tools/micro/hbm_rw, profiles/r04_hbm_ceilings.txt):
         # the split input transforms write 2.7 bytes per byte read, the output transforms read 1.8 per byte written
         "streaming_kernel_GBps": {"read_only": 5670, "write_only": 4400, "copy": 4800, "1_read_to_2.7_writes": 4250, "1.8_reads_to_1_write": 4850,
-                                  "note": "means over three boxes; +/- 5 % between boxes",
-                                  "source": "profiles/r04_hbm_ceilings.txt"}}
+                                  "note": "means over three boxes; +/- 5 % between boxes; ONE launch geometry (grid 4096 x 256, 16 B per lane, nontemporal)",
+                                  "source": "profiles/r04_hbm_ceilings.txt"},
+        # the best of a sweep over grid / block / unroll / cache policy per mix (tools/probes/hbm_sweep.hip, profiles/r06_experiments.txt section 9):
+        # a plain stream's rate moves +/- 25 % with the launch geometry
+        "streaming_kernel_best_geometry_GBps": {"read_only": 7200, "write_only": 6300, "copy": 6000, "1_read_to_2.7_writes": 4800, "1.8_reads_to_1_write": 5400,
+                                                "source": "profiles/r06_hbm_sweep.txt (one box)"}}
     dominant = max((k for k in families if families[k]), key=lambda k: families[k]["ms_per_step"], default=None)
     # whole conv path: time the matrix pipe would need AT ITS PEAKS for everything the conv kernels execute (bf16 and fp32
     # instructions have different peaks) / the time the conv path takes, transforms included
