@@ -413,17 +413,24 @@ struct Policy {
                              //        0 never (fp32 MFMA) / 1 where it wins (K >= s3_mink, GEMM rows >= s3_minrows) / 2 wherever the shape allows
     int s3_mink = 128, s3_minrows = 2048;   // DT_S3_MINK / DT_S3_MINROWS (K >= 128 since round 4: with the line-sized epilogue stores the K = 128 GEMMs of
                                             // conv_6 / conv_8 take 3.4 instead of 4.3 ms on the fp32 kernel, their split input transform costs 0.7 back)
+    int s3_minrows_h2 = 128; // ... the row threshold where the launch would take the fp16 form (three products per multiply: the split GEMM beats the fp32 MFMA
+                             //     kernel from far fewer rows than the bf16 form does -- detector forward at 32 / 64 / 128 / 192 frames: 3.50 -> 2.85, 6.60 -> 4.45,
+                             //     9.91 -> 7.17, 14.5 -> 10.2 ms; profiles/r06_experiments.txt section 10).  DT_S3_MINROWS, when set, is the threshold of BOTH forms
     int s3_h2 = 1;           // DT_S3_H2: the split GEMMs in the fp16 form -- two terms of SCALED operands, three products on v_mfma_f32_32x32x16_f16 (half the
                              //           matrix-pipe work and 4 instead of 6 bytes per operand element; wino_gemm_s3.hip) -- wherever the bf16 form would run; 0 = three
                              //           bf16 terms / six products (round 3).  Read at weight load (the fp16 terms are built then) and per launch.  DT_PIN takes the
                              //           bf16 form: the fp16 form's scale is the batch's max |x|, so its rounding of small elements depends on the batch
     int c3fuse = 1;          // DT_C3FUSE: conv_4 (1x1, 128 -> 64) applied inside conv_3's direct kernel (conv3_h2.hip, FUSE): one launch, no 128-channel tensor; 0 = two launches
-    int h2_minframes = 32;   // DT_H2_MINFRAMES: a forward of fewer frames takes round 5's forms (bf16 terms, fused fp32 kernel) and its producers publish no max |x|:
+    int h2_minframes = 20;   // DT_H2_MINFRAMES: a forward of fewer frames takes round 5's forms (bf16 terms, fused fp32 kernel) and its producers publish no max |x|:
                              //                  at batch 8 the publications (a dependent load + atomic at the tail of 40-us kernels) and the one stand-alone absmax pass
-                             //                  cost 0.16 ms of a 1.26 ms forward and the fp16 form has nothing to win there (weights-bound GEMMs on the fp32 kernel)
+                             //                  cost 0.16 ms of a 1.26 ms forward and the fp16 form has nothing to win there (weights-bound GEMMs on the fp32 kernel).
+                             //                  Detector forward with the fp16 form from 8 frames against from 32: batch 8 1.41 vs 1.26 ms, 12: 1.98 vs 1.81, 16: 2.13 vs 2.10,
+                             //                  24: 2.29 vs 2.81 -- the crossover lies between 16 and 24 frames
     int s3_half = 0;          // DT_S3_HALF: 128-row tiles / two workgroups per CU in the split GEMM: 0 where it needs fewer rounds (default) / 1 always (N % 256 == 0) / -1 never
     int s3_rec_minrows = 512; // DT_S3_REC_MINROWS: the ConvLSTM recurrent step's F(4x4) GEMM (gate update in its output transform) takes the split
                               //                    kernel from this many GEMM rows (48 clips at 13x13: 588); 0 = never
+    int s3_rec_minrows_h2 = 32; // ... where the step would take the fp16 form (8 / 12 / 24 / 36 clips = 98 / 147 / 294 / 441 rows: the step on the split kernel
+                                //     is 6-9 % of the whole tracking step faster); DT_S3_REC_MINROWS, when set, is the threshold of both forms
     int s3_1x1_mink = 256;   // DT_S3_1X1_MINK: ... only for 1x1 layers with at least this many input channels (conv_7 / 10 / 12 / 15 / 17 / 23; 512 while the
                              //                  producer had to write split rows -- the kernel reads the fp32 activation itself since round 4; conv_4 at
                              //                  K = 128, N = 64 measured 3.55 ms there against 2.85 on the fp32 kernel)

@@ -650,10 +650,12 @@ void policy_from_env(Policy &p, int pin_override)
     p.s3_conv1 = geti("DT_S3_CONV1", d.s3_conv1);
     p.s3_mink = geti("DT_S3_MINK", d.s3_mink);
     p.s3_minrows = geti("DT_S3_MINROWS", d.s3_minrows);
+    p.s3_minrows_h2 = getenv("DT_S3_MINROWS") ? p.s3_minrows : d.s3_minrows_h2;
     p.s3_1x1 = geti("DT_S3_1X1", d.s3_1x1);
     p.s3_1x1_mink = geti("DT_S3_1X1_MINK", d.s3_1x1_mink);
     p.s3_1x1_minrows = geti("DT_S3_1X1_MINROWS", d.s3_1x1_minrows);
     p.s3_rec_minrows = geti("DT_S3_REC_MINROWS", d.s3_rec_minrows);
+    p.s3_rec_minrows_h2 = getenv("DT_S3_REC_MINROWS") ? p.s3_rec_minrows : d.s3_rec_minrows_h2;
     p.s3_half = geti("DT_S3_HALF", d.s3_half);
     p.s3_h2 = geti("DT_S3_H2", d.s3_h2);
     p.h2_minframes = geti("DT_H2_MINFRAMES", d.h2_minframes);
@@ -850,8 +852,11 @@ static int run_wino(dt_ctx *ctx, const float *wino_wt, int ts, const float *bias
     // the GEMMs on the bf16 pipe with split operands (wino_gemm_s3.hip) where that form exists and wins: long K, enough rows
     const unsigned short *u_s3 = nullptr;
     const bool rec = ts == 4 && io.cstate;      // the recurrent step: F(4x4), gate update in the output transform
+    // (row thresholds: the fp16 form wins from far fewer rows than the bf16 form)
+    const bool h2_avail = h2_wanted(ctx) && ctx->wino_h2.find(wino_wt) != ctx->wino_h2.end();
+    const int minrows = h2_avail ? ctx->pol.s3_minrows_h2 : ctx->pol.s3_minrows, rec_minrows = h2_avail ? ctx->pol.s3_rec_minrows_h2 : ctx->pol.s3_rec_minrows;
     if (((ts == 6 && !io.cstate) || rec) && ctx->pol.s3 != 0 && cin % 32 == 0 && N % 128 == 0 && npad % 128 == 0 && wino_gemm_s3_usable(w.Mt, cin, N) &&
-        (ctx->pol.s3 == 2 || (cin >= ctx->pol.s3_mink && (rec ? (ctx->pol.s3_rec_minrows > 0 && w.Mt >= ctx->pol.s3_rec_minrows) : w.Mt >= ctx->pol.s3_minrows)))) {
+        (ctx->pol.s3 == 2 || (cin >= ctx->pol.s3_mink && (rec ? (rec_minrows > 0 && w.Mt >= rec_minrows) : w.Mt >= minrows)))) {
         auto it = ctx->wino_s3.find(wino_wt);
         if (it != ctx->wino_s3.end()) u_s3 = it->second;
     }

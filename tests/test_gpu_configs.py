@@ -100,11 +100,14 @@ def _report(name, payload):
 _SETUP = {}
 
 # The kernel selection of the 48-clip bench step, forced onto the smaller batches these tests can afford to run the
-# oracle on: at 48 clips the 13x13 layers have 7,840 GEMM rows (>= DT_S3_MINROWS 2048) and the recurrent step 588
-# (>= DT_S3_REC_MINROWS 512), so conv_14/16/18/19/20/22, convlstm_xproj and convlstm_step run on wino_gemm_s3.hip;
-# at 9 clips (1,470 / 147 rows) and 4 clips of 608x608 (1,400 / 100 rows) the DEFAULT thresholds keep them on the
-# fp32 MFMA kernel.  Lowering the two row thresholds selects exactly the bench's kernels for every launch.
+# oracle on: at 48 clips the 13x13 layers have 7,840 GEMM rows and the recurrent step 588, so conv_14/16/18/19/20/22,
+# convlstm_xproj and convlstm_step run on wino_gemm_s3.hip.  Until the row thresholds of the fp16 form were re-measured
+# (profiles/r06_experiments.txt section 10: 128 / 32 rows instead of the bf16 form's 2048 / 512) a 9-clip call (1,470 / 147
+# rows) or 4 clips of 608x608 (1,400 / 100 rows) kept them on the fp32 MFMA kernel by default; now the default policy
+# selects the split GEMM there as well, BENCH_SELECTION pins it whatever the defaults are, and FP32_GEMM_SELECTION (the old
+# thresholds) keeps the fp32 MFMA form of those launches under test.
 BENCH_SELECTION = {"DT_S3_MINROWS": "1024", "DT_S3_REC_MINROWS": "64"}
+FP32_GEMM_SELECTION = {"DT_S3_MINROWS": "2048", "DT_S3_REC_MINROWS": "512"}
 S3_BENCH_LAUNCHES = ["conv_gemm_s3:conv_6", "conv_gemm_s3:conv_7", "conv_gemm_s3:conv_8", "conv_gemm_s3:conv_9", "conv_gemm_s3:conv_10", "conv_gemm_s3:conv_11", "conv_gemm_s3:conv_12", "conv_gemm_s3:conv_13",
                      "conv_gemm_s3:conv_14", "conv_gemm_s3:conv_15", "conv_gemm_s3:conv_16", "conv_gemm_s3:conv_17", "conv_gemm_s3:conv_18",
                      "conv_gemm_s3:conv_19", "conv_gemm_s3:conv_20", "conv_gemm_s3:conv_22", "conv_gemm_s3:convlstm_xproj",
@@ -356,19 +359,40 @@ def _track_config_at_reference_defaults(size, n_clips, T, target_boxes, cap, tag
 # which side of a threshold a score 1e-5 away from it lands on is chance between two float32 implementations, so the bar is not 0 --
 # but it does not grow with the band either.
 def test_configs2_track_416_reference_default_thresholds():
-    """9 clips under the library's DEFAULT policy for 9 clips (the 13x13 layers and the recurrent step below the split
-    GEMM's row thresholds run on the fp32 MFMA kernel -- what a 9-clip user gets)."""
-    _track_config_at_reference_defaults(416, 9, 30, 32, 128, "r06_defaults_track416", max_flip_frames=1)
+    """9 clips under the library's DEFAULT policy for 9 clips -- what a 9-clip user gets: since the fp16 form's row thresholds
+    were re-measured, the split GEMM on the 13x13 layers and the recurrent step too (asserted)."""
+    _track_config_at_reference_defaults(416, 9, 30, 32, 128, "r06_defaults_track416", max_flip_frames=1,
+                                        expect_policy=["conv_gemm_s3:conv_14", "conv_gemm_s3:convlstm_xproj", "conv_gemm_s3:convlstm_step"],
+                                        forbid_policy=["conv_igemm:conv_14", "conv_igemm:convlstm_step"])
+
+
+def test_configs2_track_416_fp32_gemms_reference_default_thresholds():
+    """the same 9 clips with the 13x13 layers' and the recurrent step's GEMMs on the fp32 MFMA kernel (the row thresholds of the
+    bf16 form: the default selection of a 9-clip call until round 6)"""
+    _track_config_at_reference_defaults(416, 9, 30, 32, 128, "r06_defaults_track416_fp32_gemms", max_flip_frames=1,
+                                        policy_env=dict(FP32_GEMM_SELECTION),
+                                        expect_policy=["conv_igemm:conv_14", "conv_igemm:convlstm_step", "conv_gemm_s3:conv_9"],
+                                        forbid_policy=["conv_gemm_s3:conv_14", "conv_gemm_s3:convlstm_step"])
 
 
 def test_configs2_track_416_default_policy_vs_oracle():
-    """BASELINE configs[2], 9 clips, the DEFAULT policy of a 9-clip call (not the bench's kernel selection: see
+    """BASELINE configs[2], 9 clips, the DEFAULT policy of a 9-clip call (the tile form is the policy's own choice here; see
     test_configs2_bench_kernel_selection_416_vs_oracle and test_configs2_bench_size_48_clips_vs_oracle)."""
     _track_config_vs_oracle(416, 9, 30, 32, 128, "r06_track416",
                             ["wino_input:convlstm_xproj", "wino_input:convlstm_step", "wino_input:conv_22",
                              "conv_direct_h2:conv_3", "conv_direct_h2:conv_5", "wino_input:conv_6", "conv_direct_h2:conv_2",
-                             "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4", "conv_gemm_s3:conv_9", "conv_igemm:conv_14"],
-                            min_boxes_per_frame=12)      # 32 candidates/frame; ~14-20 survive NMS (bench.py reports the same)
+                             "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4"] + S3_BENCH_LAUNCHES,
+                            min_boxes_per_frame=12,      # 32 candidates/frame; ~14-20 survive NMS (bench.py reports the same)
+                            forbid_policy=["conv_igemm:conv_14", "conv_igemm:conv_22", "conv_igemm:convlstm_xproj", "conv_igemm:convlstm_step"])
+
+
+def test_configs2_track_416_fp32_gemms_vs_oracle():
+    """the same 9 clips with the 13x13 layers' and the recurrent step's GEMMs on the fp32 MFMA kernel (FP32_GEMM_SELECTION)"""
+    _track_config_vs_oracle(416, 9, 30, 32, 128, "r06_track416_fp32_gemms",
+                            ["wino_input:convlstm_xproj", "wino_input:convlstm_step", "wino_input:conv_22", "conv_direct_h2:conv_3",
+                             "wino_mosaic:g3_ts6", "wino_mosaic:g2_ts4", "conv_gemm_s3:conv_9", "conv_igemm:conv_14", "conv_igemm:convlstm_step"],
+                            min_boxes_per_frame=12, policy_env=dict(FP32_GEMM_SELECTION),
+                            forbid_policy=["conv_gemm_s3:conv_14", "conv_gemm_s3:convlstm_step"])
 
 
 def test_configs2_bench_kernel_selection_416_vs_oracle():

@@ -1613,10 +1613,14 @@ def test_h2_scale_follows_the_data(ctx, monkeypatch, k):
 
 
 def test_split_bf16_default_policy_engages_on_deep_layers(ctx, monkeypatch):
-    """Default policy (DT_S3=1): K >= 256 and >= 2048 GEMM rows take the split form, short K / few rows stay on fp32 MFMA."""
+    """Default policy (DT_S3=1): K >= 128 and enough GEMM rows take the split form -- 128 rows where the launch takes the fp16 form, 2048 in the bf16 form
+    (profiles/r06_experiments.txt section 10) --, few rows stay on fp32 MFMA."""
     monkeypatch.delenv("DT_S3", raising=False)
+    monkeypatch.delenv("DT_S3_MINROWS", raising=False)
     rs = np.random.RandomState(11)
-    for (B, H, W, Cin, Cout), want in (((384, 13, 13, 256, 256), 1), ((8, 13, 13, 256, 256), 0), ((96, 26, 26, 128, 256), 0)):
+    for (B, H, W, Cin, Cout), h2, want in (((384, 13, 13, 256, 256), "1", 1), ((8, 13, 13, 256, 256), "1", 0), ((96, 26, 26, 128, 256), "1", 1),      # 2107 / 49 / 1944 rows
+                                           ((384, 13, 13, 256, 256), "0", 1), ((96, 26, 26, 128, 256), "0", 0)):
+        monkeypatch.setenv("DT_S3_H2", h2)
         x, w, b = _conv_case(rs, B, H, W, Cin, Cout)
         ctx.profile_reset(); ctx.profile_enable(True)
         got = ctx.conv2d(dev(x, ctx), w, b, leaky_slope=0.1, pool=0)
@@ -1637,7 +1641,8 @@ def test_split_bf16_handover_to_1x1_layers(ctx, monkeypatch):
     layers = None
     for mode in ("1", "b", "0"):      # fp16 form (default) / bf16 form / fp32 MFMA
         monkeypatch.setenv("DT_S3_H2", "0" if mode == "b" else "1")
-        monkeypatch.setenv("DT_H2_MINFRAMES", "0")     # (the default policy takes the fp16 form from 32 frames per forward)
+        monkeypatch.setenv("DT_H2_MINFRAMES", "0")     # (the default policy takes the fp16 form from 20 frames per forward)
+        monkeypatch.setenv("DT_S3_MINROWS", "2048")    # (the Winograd-form layers of this 16-frame forward stay on the fp32 MFMA kernel in every mode: only the 1x1 layers differ)
         monkeypatch.setenv("DT_S3_1X1", "0" if mode == "0" else "1")          # read when the context is created (dt_create)
         monkeypatch.setenv("DT_S3_1X1_MINK", "256")    # (the default)
         monkeypatch.setenv("DT_S3_1X1_MINROWS", "0")   # (the default policy takes these layers from 16384 pixels per launch)
