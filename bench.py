@@ -790,6 +790,13 @@ def _run():
             for key, fn in (("detect_batch8", lambda: detect_batch8_extra(device, H, W, seed0=4242)),
                             ("track_608_128boxes", lambda: track_extra(device, 608, 24, args.T, 128)),
                             ("tiny_T64", lambda: tiny_extra(device, H, W, 32)),
+                            # ONE clip per call (the live-camera shape of configs[2]): the latency of a 30-frame clip through detector + ConvLSTM + decode +
+                            # association under the library's default policy for that size (fp16 form from 20 frames per forward, recurrent step in
+                            # Winograd form on the split kernel from one clip: profiles/r06_experiments.txt section 10)
+                            ("track_1_clip", lambda: track_extra(device, args.size, 1, args.T, args.boxes, steps=20,
+                                                                 what="BASELINE.json configs[2] with ONE clip per call: 1 x %d frames %dx%d (latency of a clip)" % (args.T, args.size, args.size))),
+                            ("track_8_clips", lambda: track_extra(device, args.size, 8, args.T, args.boxes, steps=10,
+                                                                  what="BASELINE.json configs[2] with 8 clips per call: 8 x %d frames %dx%d" % (args.T, args.size, args.size))),
                             # the headline workload with hipGraph replay of the detector trunk and the recurrence (dt_graph_enable): no
                             # per-launch events are possible inside a replayed graph, so the headline number (which carries them) runs without
                             ("track_plain_launches" if args.graphs else "track_hipgraph",

@@ -429,8 +429,8 @@ struct Policy {
     int s3_half = 0;          // DT_S3_HALF: 128-row tiles / two workgroups per CU in the split GEMM: 0 where it needs fewer rounds (default) / 1 always (N % 256 == 0) / -1 never
     int s3_rec_minrows = 512; // DT_S3_REC_MINROWS: the ConvLSTM recurrent step's F(4x4) GEMM (gate update in its output transform) takes the split
                               //                    kernel from this many GEMM rows (48 clips at 13x13: 588); 0 = never
-    int s3_rec_minrows_h2 = 32; // ... where the step would take the fp16 form (8 / 12 / 24 / 36 clips = 98 / 147 / 294 / 441 rows: the step on the split kernel
-                                //     is 6-9 % of the whole tracking step faster); DT_S3_REC_MINROWS, when set, is the threshold of both forms
+    int s3_rec_minrows_h2 = 16; // ... where the step would take the fp16 form (one clip at 13x13 = 16 rows: 5.30 -> 4.71 ms per 30-frame clip; 8 / 12 / 24 / 36 clips =
+                                //     98 / 147 / 294 / 441 rows: 6-9 % of the whole tracking step); DT_S3_REC_MINROWS, when set, is the threshold of both forms
     int s3_1x1_mink = 256;   // DT_S3_1X1_MINK: ... only for 1x1 layers with at least this many input channels (conv_7 / 10 / 12 / 15 / 17 / 23; 512 while the
                              //                  producer had to write split rows -- the kernel reads the fp32 activation itself since round 4; conv_4 at
                              //                  K = 128, N = 64 measured 3.55 ms there against 2.85 on the fp32 kernel)

@@ -702,7 +702,9 @@ static bool wino_runs(const dt_ctx *ctx, const float *wino_wt, int ts, int B, in
     // (detector-only sweep, batch 1/4/8/16: threshold 512 -> 679/1822/2672/3487 frames/s, 64 -> 695/1960/3341/4402,
     // 16 -> 556/1947/3337/4427)
     const int mint = ctx->pol.wino_mint;
-    return ctx->pol.wino == 2 || mt >= (mint > 0 ? mint : (ts == 2 ? 256 : (ts == 4 ? 64 : 32)));
+    // (F(4x4) -- the ConvLSTM recurrent step -- from 16 tiles = ONE clip at 13x13 since round 6: with the step's GEMM on the split kernel a 30-frame clip takes 4.7 instead
+    //  of 12.3 ms, two clips 6.5 instead of 14.3, three 7.7 instead of 15.7 (profiles/r06_experiments.txt section 10); on the fp32 kernel too the Winograd form wins there)
+    return ctx->pol.wino == 2 || mt >= (mint > 0 ? mint : (ts == 2 ? 256 : (ts == 4 ? 16 : 32)));
 }
 
 static int upload_wino(dt_ctx *ctx, float **dst, int ts, const float *hwio, int cin_src, int cout_src, const int *cin_map,
