@@ -223,6 +223,11 @@ struct GemmS3Args {
 // over the sub-slots; a reader takes the maximum).  base = 2^(14 - floor(log2 amax)): amax * base is in [2^14, 2^15), a factor 2 below
 // fp16's largest finite value 65504.  The exponent field is clamped to [27, 240] (amax = 0 -> base 2^114 on zeros; nothing overflows).
 #define DT_AMAX_SUB 16
+// The sub-words of a slot lie on DISTINCT 128-byte lines (DT_AMAX_LINE words apart): the first resident round of a producer finds the slot at zero and every one
+// of its waves performs the atomicMax -- on one line those serialise at one L2 channel (~12 ns each: 25 us for the ~2,000 waves of a small launch; round 6 measured
+// it as +0.36 ms per batch-8 forward over 13 output transforms), on sixteen lines they spread over sixteen channels
+#define DT_AMAX_LINE 32
+#define DT_AMAX_WORDS (DT_AMAX_SUB * DT_AMAX_LINE)      // words per slot
 __host__ __device__ inline unsigned dt_h2_expfield(unsigned amax_bits)
 {
     const unsigned e = (amax_bits >> 23) & 0xffu;
@@ -248,7 +253,7 @@ __host__ __device__ inline float dt_h2_rowfac(int ts, int i)
 #ifdef __HIPCC__
 __device__ __forceinline__ unsigned dt_amax_read(const unsigned *slot)      // wave-uniform
 {
-    unsigned v = slot[threadIdx.x & (DT_AMAX_SUB - 1)];
+    unsigned v = slot[(threadIdx.x & (DT_AMAX_SUB - 1)) * DT_AMAX_LINE];
 #pragma unroll
     for (int o = DT_AMAX_SUB / 2; o; o >>= 1) {
         const unsigned w = (unsigned)__shfl_xor((int)v, o);
@@ -265,7 +270,7 @@ __device__ __forceinline__ void dt_amax_publish(unsigned *slot, float am)
     for (int o = 32; o; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
     if ((threadIdx.x & 63) == 0) {
         const unsigned b = __float_as_uint(am);
-        unsigned *s = slot + ((blockIdx.x + (threadIdx.x >> 6)) & (DT_AMAX_SUB - 1));
+        unsigned *s = slot + ((blockIdx.x + (threadIdx.x >> 6)) & (DT_AMAX_SUB - 1)) * DT_AMAX_LINE;
         if (b > __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(s, b);
     }
 }
@@ -404,6 +409,7 @@ struct Policy {
     int c3h2 = 1;            // DT_C3H2: conv_2 / conv_3 / conv_5 as DIRECT 3x3 convolutions in the two-term fp16 form (conv3_h2.hip) from 1024 16x16-pixel blocks
                              //          (where the fused F(4x4) fp32 kernel ran until round 5); 0 = the fused kernel; 2 = at any size (parity tests).  Needs the fp16
                              //          form (DT_S3_H2, not DT_PIN).  Read at weight load (0: no fp16 copy of the weights) and per launch
+    int c3h2_blocks2 = 1024; // DT_C3H2_BLOCKS2: 16 x 16-pixel blocks from which conv_2 (Cin = 32) takes the direct kernel under DT_C3H2=1 (conv_3 / conv_5: 1024)
     int wino_cfg = -1, wino_gn = -1;   // DT_WINO_CFG / DT_WINO_GN (A/B runs)
     int wino_grid_in = 0, wino_grid_out = 0, wino_thr_out = 0;   // DT_WINO_GRID_IN / DT_WINO_GRID_OUT / DT_WINO_THR_OUT (A/B runs: WinoArgs::grid_in / grid_out / thr_out)
     int ksplit = 0;          // DT_KSPLIT
@@ -413,19 +419,23 @@ struct Policy {
                              //        0 never (fp32 MFMA) / 1 where it wins (K >= s3_mink, GEMM rows >= s3_minrows) / 2 wherever the shape allows
     int s3_mink = 128, s3_minrows = 2048;   // DT_S3_MINK / DT_S3_MINROWS (K >= 128 since round 4: with the line-sized epilogue stores the K = 128 GEMMs of
                                             // conv_6 / conv_8 take 3.4 instead of 4.3 ms on the fp32 kernel, their split input transform costs 0.7 back)
-    int s3_minrows_h2 = 128; // ... the row threshold where the launch would take the fp16 form (three products per multiply: the split GEMM beats the fp32 MFMA
+    int s3_minrows_h2 = 64;  // ... the row threshold where the launch would take the fp16 form (three products per multiply: the split GEMM beats the fp32 MFMA
                              //     kernel from far fewer rows than the bf16 form does -- detector forward at 32 / 64 / 128 / 192 frames: 3.50 -> 2.85, 6.60 -> 4.45,
-                             //     9.91 -> 7.17, 14.5 -> 10.2 ms; profiles/r06_experiments.txt section 10).  DT_S3_MINROWS, when set, is the threshold of BOTH forms
+                             //     9.91 -> 7.17, 14.5 -> 10.2 ms; 64 rather than 128 for the 75 / 98 rows of the 13 x 13 layers at 12 / 16 frames; profiles/r06_experiments.txt section 10).
+                             //     DT_S3_MINROWS, when set, is the threshold of BOTH forms
     int s3_h2 = 1;           // DT_S3_H2: the split GEMMs in the fp16 form -- two terms of SCALED operands, three products on v_mfma_f32_32x32x16_f16 (half the
                              //           matrix-pipe work and 4 instead of 6 bytes per operand element; wino_gemm_s3.hip) -- wherever the bf16 form would run; 0 = three
                              //           bf16 terms / six products (round 3).  Read at weight load (the fp16 terms are built then) and per launch.  DT_PIN takes the
                              //           bf16 form: the fp16 form's scale is the batch's max |x|, so its rounding of small elements depends on the batch
     int c3fuse = 1;          // DT_C3FUSE: conv_4 (1x1, 128 -> 64) applied inside conv_3's direct kernel (conv3_h2.hip, FUSE): one launch, no 128-channel tensor; 0 = two launches
-    int h2_minframes = 20;   // DT_H2_MINFRAMES: a forward of fewer frames takes round 5's forms (bf16 terms, fused fp32 kernel) and its producers publish no max |x|:
+    int h2_minframes = 12;   // DT_H2_MINFRAMES: a forward of fewer frames takes round 5's forms (bf16 terms, fused fp32 kernel) and its producers publish no max |x|:
                              //                  at batch 8 the publications (a dependent load + atomic at the tail of 40-us kernels) and the one stand-alone absmax pass
                              //                  cost 0.16 ms of a 1.26 ms forward and the fp16 form has nothing to win there (weights-bound GEMMs on the fp32 kernel).
                              //                  Detector forward with the fp16 form from 8 frames against from 32: batch 8 1.41 vs 1.26 ms, 12: 1.98 vs 1.81, 16: 2.13 vs 2.10,
-                             //                  24: 2.29 vs 2.81 -- the crossover lies between 16 and 24 frames
+                             //                  24: 2.29 vs 2.81 -- the crossover lay between 16 and 24 frames while every small producer paid ~25 us for its publication.
+                             //                  With the sub-words of a slot on distinct cache lines (DT_AMAX_LINE) and the cooperative output transform publishing too
+                             //                  (no stand-alone absmax passes): batch 8 1.25-1.31 vs 1.26, 12: 1.50 vs 1.81, 16: 1.74 vs 2.09, 20: 2.40 vs 2.53, 24: 1.91 vs 2.80
+                             //                  (row threshold 64-96) -- from 12 frames
     int s3_half = 0;          // DT_S3_HALF: 128-row tiles / two workgroups per CU in the split GEMM: 0 where it needs fewer rounds (default) / 1 always (N % 256 == 0) / -1 never
     int s3_rec_minrows = 512; // DT_S3_REC_MINROWS: the ConvLSTM recurrent step's F(4x4) GEMM (gate update in its output transform) takes the split
                               //                    kernel from this many GEMM rows (48 clips at 13x13: 588); 0 = never

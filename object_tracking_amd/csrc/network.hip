@@ -174,7 +174,7 @@ static void s3_drop(dt_ctx *ctx, const void *wino)
 // ---- max-|x| slots of the fp16 form (dt_internal.h: dt_ctx::amax) ------------------------------------------------------------------
 #define DT_AMAX_SLOTS 128
 enum { AMAX_ONE = 0, AMAX_IN = 32, AMAX_TRK = 56, AMAX_TEST = 57, AMAX_PACK = 64 };
-static unsigned *amax_slot(dt_ctx *ctx, int slot) { return ctx->amax ? ctx->amax + (size_t)slot * DT_AMAX_SUB : nullptr; }
+static unsigned *amax_slot(dt_ctx *ctx, int slot) { return ctx->amax ? ctx->amax + (size_t)slot * DT_AMAX_WORDS : nullptr; }
 // every API entry that runs layers starts here: what a previous call knew about a tensor's maximum says nothing about the bytes behind the pointer now
 static void amax_reset(dt_ctx *ctx) { ctx->amax_tag.clear(); ctx->h2_small = false; }
 // the slot that holds max |x| of the rows x cols tensor at x: the one its producer filled (tagged), else measured here into `slot`
@@ -196,10 +196,13 @@ static void amax_note(dt_ctx *ctx, const float *lo, long long floats, int cols, 
 static int amax_begin(dt_ctx *ctx)
 {
     if (!ctx->amax) return DT_OK;
-    HIP_TRY(ctx, hipMemsetAsync(amax_slot(ctx, 1), 0, (size_t)(AMAX_IN - 1) * DT_AMAX_SUB * sizeof(unsigned), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(amax_slot(ctx, 1), 0, (size_t)(AMAX_IN - 1) * DT_AMAX_WORDS * sizeof(unsigned), ctx->stream));
     return DT_OK;
 }
 // slot a layer's epilogue fills with the max |x| of what it writes: conv_1 .. conv_23 only (the test entry points run "layer 0")
+// blocks of 16 x 16 pixels from which a narrow 3x3 layer takes the direct fp16-form kernel (conv3_h2.hip) instead of the fused fp32 one (Policy::c3h2_blocks2 for
+// conv_2, Cin = 32; 1024 for conv_3 / conv_5)
+static long long c3h2_min_blocks(const dt_ctx *ctx, int cin) { return cin <= 32 ? ctx->pol.c3h2_blocks2 : 1024; }
 static int amax_out_slot(const ConvLayer &L) { return L.idx >= 1 && L.idx <= 23 ? L.idx : 0; }
 static const unsigned *ensure_amax(dt_ctx *ctx, const float *x, long long rows, int cols, long long ld, int slot)
 {
@@ -255,8 +258,8 @@ extern "C" int dt_create(dt_ctx **out)
         return DT_ERR_DEVICE;
     }
     {   // max-|x| slots; slot 0 = 1.0
-        std::vector<unsigned> am((size_t)DT_AMAX_SLOTS * DT_AMAX_SUB, 0u);
-        for (int q = 0; q < DT_AMAX_SUB; ++q) am[q] = 0x3f800000u;
+        std::vector<unsigned> am((size_t)DT_AMAX_SLOTS * DT_AMAX_WORDS, 0u);
+        for (int q = 0; q < DT_AMAX_SUB; ++q) am[(size_t)q * DT_AMAX_LINE] = 0x3f800000u;
         if (hipMalloc(reinterpret_cast<void **>(&c->amax), am.size() * sizeof(unsigned)) != hipSuccess ||
             hipMemcpy(c->amax, am.data(), am.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) {
             snprintf(g_static_err, sizeof(g_static_err), "dt_create: max-|x| slot allocation failed");
@@ -638,6 +641,7 @@ void policy_from_env(Policy &p, int pin_override)
     p.fused4 = geti("DT_WINO_FUSED4", d.fused4);
     p.c3h2 = geti("DT_C3H2", d.c3h2);
     p.c3fuse = geti("DT_C3FUSE", d.c3fuse);
+    p.c3h2_blocks2 = geti("DT_C3H2_BLOCKS2", d.c3h2_blocks2);
     p.wino_cfg = geti("DT_WINO_CFG", d.wino_cfg);
     p.wino_gn = geti("DT_WINO_GN", d.wino_gn);
     p.wino_grid_in = geti("DT_WINO_GRID_IN", d.wino_grid_in);
@@ -1029,7 +1033,7 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
     if (L.w3_h2 && L.pscale_w3 && ctx->pol.c3h2 != 0 && h2_wanted(ctx) && in_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
         ((epi == EPI_PLAIN && order == ORD_LINEAR) || (epi == EPI_POOL && !((H | W) & 1)))) {
         const long long blocks = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((L.cout + 127) / 128);
-        if (ctx->pol.c3h2 == 2 || blocks >= 1024) {
+        if (ctx->pol.c3h2 == 2 || blocks >= c3h2_min_blocks(ctx, L.cin)) {
             Conv3H2Args c;
             memset(&c, 0, sizeof(c));
             c.in = in; c.in_bs = a.in_bs; c.in_ld = in_ld; c.B = B; c.H = H; c.W = W; c.Cin = L.cin; c.N = L.cout; c.Np = L.npad;
@@ -1308,7 +1312,9 @@ static int detect_internal(dt_ctx *ctx, const void *frames, int dtype, int B, De
         amax_forget(ctx, bufA, (long long)per_frame * B);
         if (int rcz = amax_begin(ctx)) return rcz;
         // (its epilogue takes max |x| of what it writes: conv_2's direct fp16-form kernel scales its input by it)
-        unsigned *am1 = c1s3 && h2_wanted(ctx) && conv1_direct_fills_amax(frames, dtype, W, ctx->conv1_w3, ctx->conv1_w3u8) ? amax_slot(ctx, 1) : nullptr;
+        // (conv_1 publishes only where conv_2 will read it: the direct fp16-form kernel)
+        const bool c2_direct = ctx->pol.c3h2 == 2 || (ctx->pol.c3h2 != 0 && (long long)B * ((H / 2 + 15) / 16) * ((W / 2 + 15) / 16) >= c3h2_min_blocks(ctx, 32));
+        unsigned *am1 = c1s3 && h2_wanted(ctx) && c2_direct && conv1_direct_fills_amax(frames, dtype, W, ctx->conv1_w3, ctx->conv1_w3u8) ? amax_slot(ctx, 1) : nullptr;
         if (launch_conv1_direct(ctx->stream, frames, dtype, B, H, W, ctx->conv1_w, ctx->conv1_b, ctx->lut255, LEAKY,
                                 bufA, c1s3 ? ctx->conv1_w3 : nullptr, c1s3 ? ctx->conv1_w3u8 : nullptr, am1))
             return dt_fail(ctx, DT_ERR_DEVICE, "conv_1 launch failed");

@@ -722,6 +722,8 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
     const long long plane = (long long)p.Mt * p.m_ld;
     const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;
     float *st = s_t + slot * WINO_COOP_ITEM;
+    float am = 0.0f;      // largest |value| this lane stored (WinoArgs::amax_out: of out2 where there is one, else of out -- like wino_output_kernel)
+    const bool am_full = p.amax_out && !p.out2, am_pool = p.amax_out && p.out2;
     for (long long base = (long long)blockIdx.x * (WINO_THREADS / 8); base < items; base += (long long)gridDim.x * (WINO_THREADS / 8)) {
         const long long it = base + slot;
         const bool live = it < items;
@@ -759,6 +761,10 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
                         const int k = wino_border_case(p, h, w);
                         if (k) v = v + vload<4>(p.bias16 + (long long)k * p.N + c);
                     }
+                    if (am_full) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(lane_of<4>(v, e)));
+                    }
                     vstore_nt<4>(p.out + (long long)b * p.out_bs + (long long)(h * p.W + w) * p.out_ld + c, v);
                 }
             }
@@ -774,12 +780,18 @@ __global__ __launch_bounds__(WINO_THREADS) void wino_output_coop6_kernel(WinoArg
                     set_lane<4>(mx, e, fmaxf(a, __shfl_xor(a, 1)));
                 }
                 const int h2 = 3 * t.ty + (sub >> 1), w2 = 3 * t.tx + k;
-                if (live && sub < 6 && !(sub & 1) && h2 < H2 && w2 < W2)
+                if (live && sub < 6 && !(sub & 1) && h2 < H2 && w2 < W2) {
+                    if (am_pool) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(lane_of<4>(mx, e)));
+                    }
                     vstore<4>(p.out2 + ((long long)(t.grp * H2 + h2) * W2 + w2) * p.out2_ld + c, mx);
+                }
             }
         }
         wino_item_sync();
     }
+    if (p.amax_out) dt_amax_publish(p.amax_out, am);
 }
 
 // weights of the split-bf16 GEMM: one thread per (position, output channel, 4 input channels)
@@ -810,7 +822,7 @@ int launch_wino_s3_pack(hipStream_t st, const float *u, int P, int npad, int K, 
 }
 
 // ---- fp16 form: max |x| of a tensor, weights / caller operands as two fp16 terms --------------------------------------------------------
-// max |x| over rows x cols floats (row stride ld) per plane z -> slot z (DT_AMAX_SUB words, zeroed by the caller): the integer order of
+// max |x| over rows x cols floats (row stride ld) per plane z -> slot z (DT_AMAX_WORDS words, zeroed by the caller): the integer order of
 // the bits of non-negative floats is their order as numbers, so the reduction is an unsigned max and its result does not depend on
 // the order of the atomics
 __global__ __launch_bounds__(256) void absmax_kernel(const float *x, long long rows, int cols, long long ld, long long plane, unsigned *slots)
@@ -829,13 +841,13 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *x, long long r
     if ((cols & 3) && blockIdx.x == 0)      // ragged tail columns (caller tensors)
         for (long long r = threadIdx.x; r < rows; r += blockDim.x)
             for (int c = cq * 4; c < cols; ++c) m = fmaxf(m, fabsf(xz[r * ld + c]));
-    dt_amax_publish(slots + (long long)blockIdx.y * DT_AMAX_SUB, m);
+    dt_amax_publish(slots + (long long)blockIdx.y * DT_AMAX_WORDS, m);
 }
 int launch_absmax(hipStream_t st, const float *x, long long rows, int cols, long long ld, int planes, long long plane_stride, unsigned *slots, bool zero)
 {
     if (!x || !slots || rows <= 0 || cols <= 0 || planes <= 0 || planes > 65535) return 2;
     if (cols >= 4 && ((ld & 3) || (plane_stride & 3) || (reinterpret_cast<uintptr_t>(x) & 15))) return 2;
-    if (zero && hipMemsetAsync(slots, 0, (size_t)planes * DT_AMAX_SUB * sizeof(unsigned), st) != hipSuccess) return 1;
+    if (zero && hipMemsetAsync(slots, 0, (size_t)planes * DT_AMAX_WORDS * sizeof(unsigned), st) != hipSuccess) return 1;
     const long long items = rows * (cols >= 4 ? cols >> 2 : 1);
     long long nb = (items + 255) / 256 / 8;      // ~8 items (128 bytes) per thread
     nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
@@ -854,7 +866,7 @@ __global__ __launch_bounds__(256) void wino_h2_pack_kernel(const float *u, int P
         const int n = (int)(r % npad), pz = (int)(r / npad);
         unsigned am = 0;
 #pragma unroll
-        for (int q = 0; q < DT_AMAX_SUB; ++q) { const unsigned w = slots[pz * slot_stride + q]; am = w > am ? w : am; }
+        for (int q = 0; q < DT_AMAX_SUB; ++q) { const unsigned w = slots[pz * slot_stride + q * DT_AMAX_LINE]; am = w > am ? w : am; }
         wino_u2 tr[2];
         h2_split4(vload<4>(u + r * K + k) * dt_h2_base(am), tr);
 #pragma unroll
@@ -868,12 +880,12 @@ __global__ void wino_h2_pscale_kernel(const unsigned *slots, int P, int ts, floa
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     unsigned am = 0;
-    for (int q = 0; q < DT_AMAX_SUB; ++q) { const unsigned w = slots[p * DT_AMAX_SUB + q]; am = w > am ? w : am; }
+    for (int q = 0; q < DT_AMAX_SUB; ++q) { const unsigned w = slots[p * DT_AMAX_WORDS + q * DT_AMAX_LINE]; am = w > am ? w : am; }
     const int ni = ts + 2;
     const float rf = ts ? dt_h2_rowfac(ts, p / ni) * dt_h2_rowfac(ts, p % ni) : 1.0f;
     pscale[p] = dt_h2_base_inv(am) / rf;
 }
-// weights (or a caller's operand, ts = 0) in the fp16 form: plane maxima -> terms + per-position epilogue factors.  `slots`: P x DT_AMAX_SUB words of scratch
+// weights (or a caller's operand, ts = 0) in the fp16 form: plane maxima -> terms + per-position epilogue factors.  `slots`: P x DT_AMAX_WORDS words of scratch
 // pscale == null: ONE scale for all planes (an activation-like operand: `slots` is one slot, the maximum over the whole tensor)
 int launch_wino_h2_pack(hipStream_t st, const float *u, int P, int npad, int K, int ts, unsigned *slots, unsigned short *dst, float *pscale)
 {
@@ -882,7 +894,7 @@ int launch_wino_h2_pack(hipStream_t st, const float *u, int P, int npad, int K, 
     const long long n_items = (long long)P * npad * (K / 4);
     long long nb = (n_items + 255) / 256;
     if (nb > 65536) nb = 65536;
-    hipLaunchKernelGGL(wino_h2_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, u, P, npad, K, slots, pscale ? DT_AMAX_SUB : 0, dst);
+    hipLaunchKernelGGL(wino_h2_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, u, P, npad, K, slots, pscale ? DT_AMAX_WORDS : 0, dst);
     if (pscale) hipLaunchKernelGGL(wino_h2_pscale_kernel, dim3((P + 63) / 64), dim3(64), 0, st, slots, P, ts, pscale);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -941,11 +953,11 @@ int launch_wino_input(hipStream_t st, const WinoArgs &a)
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-// does launch_wino_output's kernel for these arguments fill WinoArgs::amax_out?  (the thread-per-item plain epilogues do)
+// does launch_wino_output's kernel for these arguments fill WinoArgs::amax_out?  (every plain epilogue does: the thread-per-item kernels and, since round 6,
+// the lane-cooperative F(6x6) kernel of the small launches, whose consumers otherwise run a stand-alone absmax pass each)
 bool wino_output_fills_amax(const WinoArgs &a, int gates)
 {
-    if (gates || !a.amax_out) return false;
-    return !(a.ts == 6 && wino_coop_wanted(a, (long long)a.Mt * (a.N / 2)));
+    return !gates && a.amax_out != nullptr;
 }
 int launch_wino_output(hipStream_t st, const WinoArgs &a, int gates)
 {

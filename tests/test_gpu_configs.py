@@ -386,16 +386,6 @@ def test_configs2_track_416_default_policy_vs_oracle():
                             forbid_policy=["conv_igemm:conv_14", "conv_igemm:conv_22", "conv_igemm:convlstm_xproj", "conv_igemm:convlstm_step"])
 
 
-def test_configs2_one_clip_default_policy_vs_oracle():
-    """BASELINE configs[2] with ONE 30-frame clip per call (the live-camera shape), default policy: the detector's 13x13 layers (196 GEMM
-    rows) and the ConvLSTM recurrent step (F(4x4), 16 rows: one clip) run on the split GEMM in the fp16 form since the thresholds of that
-    form were re-measured (profiles/r06_experiments.txt section 10) -- asserted from the profile -- and the path is bit-exact in its ids."""
-    _track_config_vs_oracle(416, 1, 30, 32, 128, "r06_track416_one_clip",
-                            ["wino_input:convlstm_xproj", "wino_input:convlstm_step", "conv_gemm_s3:convlstm_step", "conv_gemm_s3:convlstm_xproj",
-                             "conv_gemm_s3:conv_14", "conv_gemm_s3:conv_22", "conv_direct_h2:conv_2", "s3_form:f16x2"],
-                            min_boxes_per_frame=10, forbid_policy=["conv_igemm:convlstm_step", "conv_igemm:conv_14", "s3_form:bf16x3"])
-
-
 def test_configs2_track_416_fp32_gemms_vs_oracle():
     """the same 9 clips with the 13x13 layers' and the recurrent step's GEMMs on the fp32 MFMA kernel (FP32_GEMM_SELECTION)"""
     _track_config_vs_oracle(416, 9, 30, 32, 128, "r06_track416_fp32_gemms",
@@ -423,6 +413,16 @@ def test_configs2_bench_kernel_selection_416_reference_default_thresholds():
                                         policy_env=dict(BENCH_SELECTION, DT_S3_HALF="-1"),
                                         expect_policy=["s3_tile:256"] + S3_BENCH_LAUNCHES,
                                         forbid_policy=["s3_tile:128x2", "conv_igemm:conv_14", "conv_igemm:convlstm_step"])
+
+
+def test_configs2_one_clip_default_policy_vs_oracle():
+    """BASELINE configs[2] with ONE 30-frame clip per call (the live-camera shape), default policy: the detector's 13x13 layers (196 GEMM
+    rows) and the ConvLSTM recurrent step (F(4x4), 16 rows: one clip) run on the split GEMM in the fp16 form since the thresholds of that
+    form were re-measured (profiles/r06_experiments.txt section 10) -- asserted from the profile -- and the path is bit-exact in its ids."""
+    _track_config_vs_oracle(416, 1, 30, 32, 128, "r06_track416_one_clip",
+                            ["wino_input:convlstm_xproj", "wino_input:convlstm_step", "conv_gemm_s3:convlstm_step", "conv_gemm_s3:convlstm_xproj",
+                             "conv_gemm_s3:conv_14", "conv_gemm_s3:conv_22", "conv_direct_h2:conv_2", "s3_form:f16x2"],
+                            min_boxes_per_frame=10, forbid_policy=["conv_igemm:convlstm_step", "conv_igemm:conv_14", "s3_form:bf16x3"])
 
 
 def test_configs4_track_608_128_boxes_vs_oracle():

@@ -1641,7 +1641,7 @@ def test_split_bf16_handover_to_1x1_layers(ctx, monkeypatch):
     layers = None
     for mode in ("1", "b", "0"):      # fp16 form (default) / bf16 form / fp32 MFMA
         monkeypatch.setenv("DT_S3_H2", "0" if mode == "b" else "1")
-        monkeypatch.setenv("DT_H2_MINFRAMES", "0")     # (the default policy takes the fp16 form from 20 frames per forward)
+        monkeypatch.setenv("DT_H2_MINFRAMES", "0")     # (the default policy takes the fp16 form from 12 frames per forward)
         monkeypatch.setenv("DT_S3_MINROWS", "2048")    # (the Winograd-form layers of this 16-frame forward stay on the fp32 MFMA kernel in every mode: only the 1x1 layers differ)
         monkeypatch.setenv("DT_S3_1X1", "0" if mode == "0" else "1")          # read when the context is created (dt_create)
         monkeypatch.setenv("DT_S3_1X1_MINK", "256")    # (the default)
