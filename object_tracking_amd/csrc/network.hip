@@ -1095,7 +1095,11 @@ static int run_conv(dt_ctx *ctx, const ConvLayer &L, const float *in, int in_ld,
             const bool pooled = io.out2 != nullptr;
             const WinoGeom q6 = wino_geometry(ctx, 6, B, H, W, pooled), q4 = wino_geometry(ctx, 4, B, H, W, pooled);
             const long long t6 = 64ll * ((q6.Mt + 127) / 128) * ((L.cout + 127) / 128);
-            if (t6 <= 4096 && small_gemm_cost(q4.Mt, L.cout, 36, nullptr) < small_gemm_cost(q6.Mt, L.cout, 64, nullptr)) { wt = L.wino_alt; ts = 4; }
+            // (the cost model prices the fp32 MFMA kernel's tiles: where the F(6x6) launch takes the split GEMM in the fp16 form -- run_wino's own test -- F(4x4) on the
+            //  fp32 kernel is no alternative: at 20 frames it cost the 13x13 layers 0.10-0.24 ms each against 0.05-0.11 on the split kernel)
+            const bool s3_h2_takes_it = ctx->pol.s3 != 0 && h2_wanted(ctx) && ctx->wino_h2.find(L.wino) != ctx->wino_h2.end() && L.cin % 32 == 0 && L.cout % 128 == 0 &&
+                                        L.npad % 128 == 0 && (ctx->pol.s3 == 2 || (L.cin >= ctx->pol.s3_mink && q6.Mt >= ctx->pol.s3_minrows_h2));
+            if (!s3_h2_takes_it && t6 <= 4096 && small_gemm_cost(q4.Mt, L.cout, 36, nullptr) < small_gemm_cost(q6.Mt, L.cout, 64, nullptr)) { wt = L.wino_alt; ts = 4; }
         }
         return run_wino(ctx, wt, ts, L.bias, L.cin, L.cout, L.npad, B, H, W, io, slope, tag, 0, L.idx >= 1 && L.idx <= 23 ? AMAX_IN + L.idx : AMAX_TEST);
     }
